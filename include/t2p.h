@@ -1,0 +1,186 @@
+/*
+ * t2p.h -- C ABI of libt2p_hip.so: the MI355X (gfx950) implementation of the Text2Pos coarse
+ * cell-retrieval forward path.
+ *
+ * The reference (mako443/Text2Pos-CVPR2022) is pure Python and has no FFI/plugin interface; its boundary for
+ * this path is the Python class models/cell_retrieval.py::CellRetrievalNetwork plus the retrieval loop of
+ * training/coarse.py::eval_epoch.  The entry points below are what a ctypes binding of that class calls
+ * (INTEGRATION.md shows the stub); each one names the reference interface it replaces.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer (HBM) unless its name ends in _host.  Buffers are owned by the caller;
+ *     the library never allocates or frees device memory and keeps no global mutable state besides the
+ *     thread-local error string.  Scratch space is a caller-provided workspace, sized by the *_workspace_bytes
+ *     functions.
+ *   - Every call enqueues work on `stream` (a hipStream_t; NULL = the default stream) and returns without
+ *     synchronising.  Re-entrant; one process per GPU for multi-GPU use.
+ *   - Return value: 0 = success; > 0 = hipError_t of a failed launch; < 0 = T2P_E_* argument / workspace /
+ *     unsupported-configuration error.  t2p_last_error() returns the message of the calling thread's last failure.
+ *   - All floating-point tensors are fp32 row-major; weights are "k-major" ([in_features][out_features], i.e. the
+ *     transpose of torch.nn.Linear.weight) with eval-mode BatchNorm folded in by the host
+ *     (models/modules.py:21-29: Linear -> BatchNorm1d -> ReLU).
+ */
+#ifndef T2P_H
+#define T2P_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2P_ABI_VERSION 1
+#define T2P_E_ARG (-1)
+#define T2P_E_WORKSPACE (-2)
+#define T2P_E_UNSUPPORTED (-3)
+
+typedef void* t2p_stream_t; /* hipStream_t */
+
+int t2p_abi_version(void);
+const char* t2p_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Cell branch: CellRetrievalNetwork.encode_objects  (models/cell_retrieval.py:77-107), i.e.
+ * ObjectEncoder.forward (models/object_encoder.py:61-142) -> PointNet2.forward
+ * (models/pointcloud/pointnet2.py:80-100) -> DynamicEdgeConv + global_max_pool + lin + F.normalize.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct t2p_cell_weights {
+    /* PointNet2.sa{1,2,3}.point_conv.local_nn (models/pointcloud/pointnet2.py:57-59).  Layer 1 is applied to
+     * [x_j | pos_j - pos_i]; sa_w1[l] is [Kpad_l][H_l] with rows = [x features (3,64,128) | pos (3) | zero pad]
+     * (Kpad = 6, 72, 136; H = 32, 128, 256); sa_w2[l] is [H_l][C_l] (C = 64, 128, 256). */
+    const float* sa_w1[3];
+    const float* sa_b1[3];
+    const float* sa_w2[3];
+    const float* sa_b2[3];
+    /* PointNet2.ga.mlp (pointnet2.py:60): [264][512] (rows = [x 256 | pos 3 | pad 5]) and [512][1024] */
+    const float* ga_w1;
+    const float* ga_b1;
+    const float* ga_w2;
+    const float* ga_b2;
+    /* PointNet2.lin1 / lin2 (pointnet2.py:62-63,89-90): [1024][512], [512][256] */
+    const float* lin1_w;
+    const float* lin1_b;
+    const float* lin2_w;
+    const float* lin2_b;
+    /* ObjectEncoder.mlp_pointnet (object_encoder.py:53-58,98): [dim_f][D], dim_f = 1024/512/256 */
+    const float* pn_w;
+    const float* pn_b;
+    /* ObjectEncoder.color_encoder / pos_encoder (object_encoder.py:40-41): [3][64], [64][D] */
+    const float* col_w1;
+    const float* col_b1;
+    const float* col_w2;
+    const float* col_b2;
+    const float* pos_w1;
+    const float* pos_b1;
+    const float* pos_w2;
+    const float* pos_b2;
+    /* ObjectEncoder.mlp_merge (object_encoder.py:59,137-138): [n_features*D][D]; unused when n_features == 1 */
+    const float* merge_w;
+    const float* merge_b;
+    /* CellRetrievalNetwork.graph1.nn (cell_retrieval.py:46-48).  Layer 1 on [x_i | x_j - x_i] is split as
+     * P_i + Q_j: g_wp = (W1a - W1b)^T [D][D] with bias g_bp, g_wq = W1b^T [D][D]; layer 2 g_w2 [D][D], g_b2. */
+    const float* g_wp;
+    const float* g_bp;
+    const float* g_wq;
+    const float* g_w2;
+    const float* g_b2;
+    /* CellRetrievalNetwork.lin (cell_retrieval.py:49): [D][D] x 2 */
+    const float* lin_w1;
+    const float* lin_b1;
+    const float* lin_w2;
+    const float* lin_b2;
+} t2p_cell_weights;
+
+typedef struct t2p_cell_config {
+    int32_t n_pts;             /* points per object after T.FixedPoints (training/args.py:53); 256 */
+    int32_t embed_dim;         /* D; 256 */
+    int32_t pointnet_features; /* 0 | 1 | 2 (training/args.py:58) */
+    int32_t use_class;         /* "class" / "color" / "position" in args.use_features (training/args.py:21) */
+    int32_t use_color;
+    int32_t use_position;
+    int32_t self_loops;        /* 1 = PyG PointConv(add_self_loops=True) semantics (upstream default), 0 = none */
+    int32_t knn_k;             /* DynamicEdgeConv k (cell_retrieval.py:47); 8 */
+    int32_t variation;         /* args.variation (cell_retrieval.py:45-54); only 0 (max aggregation) is built */
+    float radius[3];           /* SA ball radii (pointnet2.py:57-59); 0.2, 0.3, 0.4 */
+    int32_t chunk_objects;     /* objects processed per internal chunk (whole cells); 0 = default */
+} t2p_cell_config;
+
+/* Optional stage outputs for parity tests (any member may be NULL).  Layouts:
+ *   fps_idx[l] uint8 [n_obj][n_cent_l]      local FPS indices into level l's dense ordering
+ *   nbr[l]     uint8 [n_obj][n_cent_l][32]  ball-query neighbours (first cnt valid), cnt[l] uint8 [n_obj][n_cent_l]
+ *   sa_out[l]  fp32  [n_obj*n_cent_l][C_l+8] rows = [features C_l | centroid xyz | 0 x 5]
+ *   features0  fp32  [n_obj][1024]; features2 [n_obj][256]; obj_emb [n_obj][D] (ObjectEncoder output)
+ *   knn_idx    int32 [n_obj][knn_k] global object rows (-1 = none) */
+typedef struct t2p_cell_trace {
+    uint8_t* fps_idx[3];
+    uint8_t* nbr[3];
+    uint8_t* cnt[3];
+    float* sa_out[3];
+    float* features0;
+    float* features2;
+    float* obj_emb;
+    int32_t* knn_idx;
+} t2p_cell_trace;
+
+size_t t2p_encode_cells_workspace_bytes(int64_t n_obj, int64_t n_cells, const t2p_cell_config* cfg);
+
+/* xyz, rgb [n_obj][n_pts][3] (PyG batch .pos / .x of dataloading/kitti360pose/utils.py:99-109, objects of all
+ * cells concatenated); center, mean_rgb [n_obj][3] (Object3d.get_center / get_color_rgb,
+ * datapreparation/kitti360pose/imports.py:28-41); cell_ptr [n_cells+1] int32 CSR over objects, given both in host
+ * memory (chunk planning) and in device memory.  out [n_cells][D], L2-normalised rows. */
+int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, const float* mean_rgb,
+                     const int32_t* cell_ptr_host, const int32_t* cell_ptr, int64_t n_obj, int64_t n_cells,
+                     const t2p_cell_weights* w, const t2p_cell_config* cfg, float* out, const t2p_cell_trace* trace,
+                     void* workspace, size_t workspace_bytes, t2p_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Text branch: CellRetrievalNetwork.encode_text (models/cell_retrieval.py:69-75) on token ids produced by the
+ * host tokeniser of LanguageEncoder.forward (models/modules.py:60-72).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct t2p_text_weights {
+    const float* embedding; /* word_embedding.weight [V][D] (row 0 = padding/<unk>) */
+    const float* w_ih;      /* [2][D][4D] k-major: lstm.weight_ih_l0^T, lstm.weight_ih_l0_reverse^T */
+    const float* w_hh;      /* [2][D][4D] k-major: lstm.weight_hh_l0^T, ..._reverse^T */
+    const float* bias;      /* [2][4D] = bias_ih + bias_hh (gate order i, f, g, o) */
+} t2p_text_weights;
+
+size_t t2p_encode_text_workspace_bytes(int64_t batch, int32_t vocab, int32_t embed_dim);
+
+/* tokens [batch][max_len] int32 right-padded with 0, lengths [batch] int32.  out_raw (nullable) receives the
+ * LanguageEncoder output (mean of the two final hidden states), out the L2-normalised rows; both [batch][D]. */
+int t2p_encode_text(const int32_t* tokens, const int32_t* lengths, int64_t batch, int32_t max_len, int32_t vocab,
+                    int32_t embed_dim, const t2p_text_weights* w, float* out_raw, float* out, void* workspace,
+                    size_t workspace_bytes, t2p_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Retrieval: replaces the per-query NumPy loop of training/coarse.py:134-140
+ * (float64 `cell_encodings @ text_encodings[q]`, `argsort(-scores)[:k]`).
+ * queries [nq][dim], cells [nc][dim] fp32; out_idx [nq][k] int64 (= cell row + index_offset, ties -> lower index,
+ * -1 when nc < k), out_score [nq][k] float64.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t t2p_sim_topk_workspace_bytes(int64_t nq, int64_t nc, int32_t k);
+int t2p_sim_topk(const float* queries, const float* cells, int64_t nq, int64_t nc, int32_t dim, int32_t k,
+                 int64_t index_offset, int64_t* out_idx, double* out_score, void* workspace, size_t workspace_bytes,
+                 t2p_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Stage-level exports (used by the stage-wise parity tests).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Fused gnn.fps + gnn.radius of the three SA levels (pointnet2.py:26-30); outputs as in t2p_cell_trace.
+ * n_cent_l = ceil(n_dense_l / 2), n_dense_0 = n_pts. */
+int t2p_sample_group(const float* xyz, int64_t n_obj, int32_t n_pts, const float* radius_host /*[3]*/,
+                     uint8_t* const* fps_idx /*[3]*/, uint8_t* const* nbr /*[3]*/, uint8_t* const* cnt /*[3]*/,
+                     t2p_stream_t stream);
+/* knn of DynamicEdgeConv (cell_retrieval.py:46-48): x [n][dim], seg_ptr [n_seg+1] int32, out [n][k] int32 */
+int t2p_knn(const float* x, int32_t dim, const int32_t* seg_ptr, int32_t n_seg, int32_t max_seg_rows, int32_t k,
+            int32_t* out_idx, t2p_stream_t stream);
+/* C[M][ldc] (+c0) = act(A[M][lda] W[K][N] + bias[N]);  K % 4 == 0, N % 8 == 0, lda % 4 == 0 */
+int t2p_gemm(const float* a, int32_t lda, const float* w, const float* bias, float* c, int32_t ldc, int32_t c0,
+             int64_t m, int32_t k, int32_t n, int32_t relu, t2p_stream_t stream);
+/* F.normalize(x, dim=-1), eps 1e-12 */
+int t2p_rownorm(const float* x, int64_t n_rows, int32_t dim, float* out, t2p_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2P_H */

@@ -1,0 +1,47 @@
+"""oracle/ -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement of the Text2Pos coarse cell-retrieval forward path
+(/root/reference: models/cell_retrieval.py, models/object_encoder.py,
+models/pointcloud/pointnet2.py, models/modules.py, training/coarse.py:100-140).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package -- as the checker, never as the thing measured or shipped.  The
+product package (text2pos-cvpr2022_amd/) must never import it.
+
+PARITY STATUS
+  * text path (LanguageEncoder / encode_text): PINNED -- tests/golden/text_*.npz were
+    produced by executing the reference's own models/modules.py::LanguageEncoder and
+    models/cell_retrieval.py::encode_text (tests/golden/make_golden.py).
+  * retrieval (fp64 scores + argsort): PINNED -- NumPy statements of
+    training/coarse.py:136-140 executed verbatim for the fixtures.
+  * object / cell path: glue PINNED, primitives UNPINNED ("parity unpinned").
+    The reference's glue code (PointNet2.forward, ObjectEncoder.forward,
+    CellRetrievalNetwork.encode_objects) was executed for the fixtures, but the
+    six torch_geometric operators it calls (fps, radius, PointConv, global_max_pool,
+    DynamicEdgeConv/knn, Batch) are absent from /root/reference and from this image
+    (torch_geometric / torch_cluster, version un-pinned in requirements.txt:9-10);
+    oracle/pyg_restated.py restates their published algorithms with the
+    nondeterministic choices pinned (see oracle/primitives.c header).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/primitives.c with gcc (Makefile in this directory)."""
+    so = os.path.join(_HERE, "_build", "libt2p_oracle.so")
+    src = os.path.join(_HERE, "primitives.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B" if force else "-s"])
+    return so
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB

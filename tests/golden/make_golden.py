@@ -1,0 +1,167 @@
+"""Generates the golden fixtures under tests/golden/ by executing the REFERENCE's own code from /root/reference.
+
+Run in the development container only (the reference never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+What runs for real (reference code, unmodified, imported from /root/reference):
+  * models/modules.py::LanguageEncoder, models/cell_retrieval.py::CellRetrievalNetwork.encode_text   (pure torch)
+  * the NumPy retrieval statements of training/coarse.py:136-140 (restated verbatim below: they live inside a
+    150-line function that needs the dataset, so they cannot be imported separately)
+  * the reference's glue for the cell branch -- PointNet2.forward, ObjectEncoder.forward,
+    CellRetrievalNetwork.encode_objects -- on top of oracle/pyg_restated.py bound as `torch_geometric.nn`, because
+    torch_geometric / torch_cluster are absent from the reference tree and from this image ("parity unpinned" at
+    that boundary; see oracle/__init__.py).
+Import-time stand-ins (no arithmetic): easydict, cv2, the absent dataloading.semantic3d / datapreparation.semantic3d
+packages, and np.int (removed from NumPy >= 1.24, used at models/modules.py:69).
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from oracle import pyg_restated  # noqa: E402
+import weights as W  # noqa: E402
+
+
+def install_standins():
+    np.int = int
+
+    class EasyDict(dict):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            self.__dict__ = self
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("easydict", EasyDict=EasyDict)
+    mod("cv2")
+    for pkg in ("dataloading.semantic3d", "datapreparation.semantic3d"):
+        mod(pkg).__path__ = []
+    dummy = type("Absent", (), {})
+    mod("dataloading.semantic3d.semantic3d", Semantic3dCellRetrievalDataset=dummy, Semantic3dPoseReferenceMockDataset=dummy)
+    mod("dataloading.semantic3d.semantic3d_poses", Semantic3dPosesDataset=dummy)
+    mod("dataloading.semantic3d.semantic3d_pointcloud", Semantic3dObjectDataset=dummy)
+    mod("datapreparation.semantic3d.imports", Object3D=dummy, ViewObject=dummy, Pose=dummy, DescriptionObject=dummy)
+    tg = mod("torch_geometric")
+    tg.__path__ = []
+    tg.nn = mod("torch_geometric.nn", **{k: getattr(pyg_restated, k) for k in
+                                         ("fps", "radius", "knn", "PointConv", "DynamicEdgeConv", "global_max_pool",
+                                          "global_mean_pool")})
+    tg.transforms = mod("torch_geometric.transforms", FixedPoints=pyg_restated.FixedPoints,
+                        NormalizeScale=pyg_restated.NormalizeScale, Compose=pyg_restated.Compose)
+    tg.data = mod("torch_geometric.data", Data=pyg_restated.Data, Batch=pyg_restated.Batch)
+    sys.path.insert(0, REF)
+
+
+def ref_args(**kw):
+    a = dict(embed_dim=256, use_features=["class", "color", "position"], variation=0, class_embed=False,
+             color_embed=False, pointnet_layers=3, pointnet_variation=0, pointnet_numpoints=256, pointnet_freeze=False,
+             pointnet_features=2)
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
+def build_reference_model(known_classes, known_colors, known_words, seed, **kw):
+    from models.cell_retrieval import CellRetrievalNetwork
+    from models.pointcloud.pointnet2 import PointNet2
+    args = ref_args(**kw)
+    with tempfile.TemporaryDirectory() as td:
+        args.pointnet_path = os.path.join(td, "pn.pth")
+        torch.save(PointNet2(len(known_classes), len(known_colors), args).state_dict(), args.pointnet_path)
+        model = CellRetrievalNetwork(known_classes, known_colors, known_words, args)
+    W.fill_state_dict(model, seed)
+    model.eval()
+    return model
+
+
+def golden_text(model, S):
+    cases = {}
+    base = S.make_texts(101, 0, 64)
+    ragged = [base[0], "The pose is north of a gray road.", base[2] + " The pose is on-top of a green parking.",
+              "Pose west, of a BEIGE wall.", "zzz unknown words only here", base[5], "a"]
+    for name, texts in (("b1", base[:1]), ("b7_ragged_unk", ragged), ("b64", base)):
+        with torch.no_grad():
+            raw = model.language_encoder(texts)
+            out = model.encode_text(texts)
+        cases[name] = dict(texts=np.array(texts), raw=raw.numpy(), out=out.numpy())
+    return cases
+
+
+def golden_cells(model, S):
+    from datapreparation.kitti360pose.imports import Object3d
+    xyz, rgb, center, mean_rgb, _ = S.make_cells(202, 16, fixed_n=1)      # 16 single objects, regrouped below
+    cell_ptr = np.array([0, 1, 7, 16], dtype=np.int32)                   # cells of 1, 6 and 9 objects
+    objects, points = [], []
+    for c in range(3):
+        lo, hi = cell_ptr[c], cell_ptr[c + 1]
+        # Object3d whose raw points have exactly the packed mean colour / centre (get_color_rgb / get_center)
+        objects.append([Object3d(i, i, np.tile(center[i].astype(np.float64), (2, 1)),
+                                 np.tile(mean_rgb[i].astype(np.float64), (2, 1)), "box") for i in range(lo, hi)])
+        n = hi - lo
+        points.append(pyg_restated.Batch(x=torch.from_numpy(rgb[lo:hi].reshape(n * 256, 3).copy()),
+                                         pos=torch.from_numpy(xyz[lo:hi].reshape(n * 256, 3).copy()),
+                                         batch=torch.arange(n).repeat_interleave(256)))
+    grabbed = {}
+    hooks = [model.object_encoder.register_forward_hook(lambda m, i, o: grabbed.__setitem__("obj_emb", o.detach().clone())),
+             model.object_encoder.pointnet.register_forward_hook(
+                 lambda m, i, o: grabbed.setdefault("features2", []).append(o.features2.detach().clone()))]
+    with torch.no_grad():
+        out = model.encode_objects(objects, points)
+    for h in hooks:
+        h.remove()
+    return dict(xyz=xyz, rgb=rgb, center=center, mean_rgb=mean_rgb, cell_ptr=cell_ptr,
+                features2=torch.cat(grabbed["features2"]).numpy(), obj_emb=grabbed["obj_emb"].numpy(), out=out.numpy())
+
+
+def golden_retrieval():
+    rng = np.random.default_rng(303)
+    c = rng.standard_normal((300, 256)).astype(np.float32)
+    q = rng.standard_normal((16, 256)).astype(np.float32)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    # training/coarse.py:100,103: float64 arrays filled with the fp32 encodings
+    cell_encodings = np.zeros((len(c), 256))
+    cell_encodings[:] = c
+    text_encodings = np.zeros((len(q), 256))
+    text_encodings[:] = q
+    top = []
+    for query_idx in range(len(text_encodings)):
+        scores = cell_encodings[:] @ text_encodings[query_idx]     # training/coarse.py:136
+        sorted_indices = np.argsort(-1.0 * scores)                 # training/coarse.py:138
+        top.append(sorted_indices[0:10])                           # training/coarse.py:140 (max(top_k) = 10 at eval)
+    return dict(cells=c, queries=q, top10=np.stack(top).astype(np.int64))
+
+
+def main():
+    install_standins()
+    import importlib
+    S = importlib.import_module("text2pos-cvpr2022_amd.synthetic")
+    known_classes = S.LABELS + ["pad"]
+    model = build_reference_model(known_classes, S.COLOR_NAMES, S.known_words(), seed=11)
+    text = golden_text(model, S)
+    np.savez_compressed(os.path.join(HERE, "text_encoder.npz"),
+                        **{f"{case}.{k}": v for case, d in text.items() for k, v in d.items()})
+    cells = golden_cells(model, S)
+    np.savez_compressed(os.path.join(HERE, "cell_encoder.npz"), **cells)
+    np.savez_compressed(os.path.join(HERE, "retrieval.npz"), **golden_retrieval())
+    for f in ("text_encoder.npz", "cell_encoder.npz", "retrieval.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

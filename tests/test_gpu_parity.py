@@ -1,0 +1,314 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the golden fixtures.
+
+Bars: integer / index outputs bit-exact; fp32 embeddings within 1e-4 absolute (BASELINE.json north_star);
+float64 retrieval scores within 1e-12.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stage level: FPS + ball query (bit-exact)
+# ---------------------------------------------------------------------------------------------------------------
+def _oracle_groups(xyz_np, radius=(0.2, 0.3, 0.4)):
+    """Level-by-level oracle (oracle/primitives.c) in the compact layout of t2p_sample_group."""
+    import ctypes as C
+    from oracle import lib
+    L = lib()
+    n_obj, n_pts, _ = xyz_np.shape
+    pos = np.ascontiguousarray(xyz_np, dtype=np.float32)
+    out = dict(fps_idx=[], nbr=[], cnt=[])
+    fp = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    nd = n_pts
+    for l in range(3):
+        nc = (nd + 1) // 2
+        idx = np.zeros((n_obj, nc), np.int32)
+        L.t2p_oracle_fps(fp(pos, C.c_float), C.c_int64(n_obj), C.c_int32(nd), C.c_int32(nc), fp(idx, C.c_int32))
+        nbr = np.zeros((n_obj, nc, 32), np.int32)
+        cnt = np.zeros((n_obj, nc), np.int32)
+        L.t2p_oracle_ball_query(fp(pos, C.c_float), fp(idx, C.c_int32), C.c_int64(n_obj), C.c_int32(nd), C.c_int32(nc),
+                                C.c_float(radius[l]), C.c_int32(32), fp(nbr, C.c_int32), fp(cnt, C.c_int32))
+        out["fps_idx"].append(idx)
+        out["nbr"].append(np.where(nbr < 0, 0, nbr))
+        out["cnt"].append(cnt)
+        pos = np.ascontiguousarray(np.take_along_axis(pos, idx[:, :, None].astype(np.int64), axis=1))
+        nd = nc
+    return out
+
+
+@pytest.mark.parametrize("n_pts", [256, 100, 16])
+def test_sample_group_bit_exact(n_pts):
+    from text2pos_amd import ops, synthetic as S
+    xyz = S.make_objects(5, 0, 96, 256)[0][:, :n_pts].copy()
+    # adversarial extras: all-duplicate object, collinear points, exact radius boundary
+    xyz[1] = xyz[1, :1]
+    xyz[2] = 0
+    xyz[2, :, 0] = np.linspace(-1, 1, n_pts, dtype=np.float32)
+    xyz[3] = 0
+    xyz[3, 1:, 0] = np.float32(0.2)   # d == r exactly for level 0 -> excluded (strict <)
+    got = ops.sample_group(torch.from_numpy(xyz).to(_dev()))
+    want = _oracle_groups(xyz)
+    for l in range(3):
+        assert np.array_equal(got["fps_idx"][l].cpu().numpy().astype(np.int32), want["fps_idx"][l]), f"fps level {l}"
+        assert np.array_equal(got["cnt"][l].cpu().numpy().astype(np.int32), want["cnt"][l]), f"cnt level {l}"
+        assert np.array_equal(got["nbr"][l].cpu().numpy().astype(np.int32), want["nbr"][l]), f"nbr level {l}"
+
+
+def test_knn_bit_exact():
+    import ctypes as C
+    from oracle import lib
+    from text2pos_amd import ops
+    rng = np.random.default_rng(0)
+    sizes = [1, 2, 7, 8, 9, 26, 40]
+    ptr = np.zeros(len(sizes) + 1, np.int32)
+    ptr[1:] = np.cumsum(sizes)
+    x = rng.standard_normal((ptr[-1], 256)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x[12] = x[11]           # duplicate rows -> distance ties
+    x[30] = x[29]
+    want = np.zeros((ptr[-1], 8), np.int32)
+    fp = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    lib().t2p_oracle_knn(fp(x, C.c_float), fp(ptr, C.c_int32), C.c_int32(len(sizes)), C.c_int32(256), C.c_int32(8),
+                         fp(want, C.c_int32))
+    got = ops.knn(torch.from_numpy(x).to(_dev()), torch.from_numpy(ptr).to(_dev()), 8)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 4, 8), (43, 256, 1024), (300, 1024, 512), (1000, 768, 256), (129, 64, 256)])
+def test_gemm_matches_fp64(m, k, n):
+    from text2pos_amd import ops
+    g = torch.Generator().manual_seed(m * 7 + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(k, n, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    got = ops.gemm(a.to(_dev()), w.to(_dev()), b.to(_dev()), relu=True).cpu()
+    want = torch.relu(a.double() @ w.double() + b.double())
+    assert (got.double() - want).abs().max().item() < 2e-5
+
+
+def test_rownorm():
+    from text2pos_amd import ops
+    x = torch.randn(77, 256)
+    x[3] = 0
+    got = ops.rownorm(x.to(_dev())).cpu()
+    assert torch.allclose(got, torch.nn.functional.normalize(x, dim=-1), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# text branch
+# ---------------------------------------------------------------------------------------------------------------
+def test_encode_text_golden(hip_model, golden_dir):
+    z = np.load(os.path.join(golden_dir, "text_encoder.npz"))
+    for case in ("b1", "b7_ragged_unk", "b64"):
+        texts = [str(s) for s in z[f"{case}.texts"]]
+        with torch.no_grad():
+            out = hip_model.encode_text(texts).cpu().numpy()
+            raw = hip_model.language_encoder(texts).cpu().numpy()
+        assert np.abs(raw - z[f"{case}.raw"]).max() < TOL, case
+        assert np.abs(out - z[f"{case}.out"]).max() < TOL, case
+
+
+def test_encode_text_vs_oracle_large_batch(hip_model, oracle_model):
+    from text2pos_amd import synthetic as S
+    texts = S.make_texts(9, 0, 333)
+    texts[5] = "road"                       # length-1 sequence
+    texts[6] = " ".join([texts[6]] * 3)     # long sequence
+    with torch.no_grad():
+        got = hip_model.encode_text(texts).cpu()
+    want = oracle_model.encode_text(texts)
+    assert (got - want).abs().max().item() < TOL
+
+
+def test_encode_text_rejects_empty(hip_model):
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            hip_model.encode_text(["", "north"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cell branch
+# ---------------------------------------------------------------------------------------------------------------
+def _to_dev(*arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(_dev()) for a in arrs]
+
+
+def _oracle_trace(oracle_model, xyz, rgb, center, mean_rgb, cell_ptr):
+    tr = []
+    out = oracle_model.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr, trace=tr)
+    return out, tr
+
+
+@pytest.mark.parametrize("self_loops", [True, False])
+def test_encode_cells_stagewise_vs_oracle(hip_model, oracle_model, vocab, self_loops):
+    import weights as W
+    from oracle import model as OM
+    from text2pos_amd import synthetic as S
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(31, 5)
+    om = oracle_model
+    if not self_loops:
+        om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(),
+                                    add_self_loops=False).eval()
+        W.fill_state_dict(om, 11)
+    want, tr = _oracle_trace(om, xyz, rgb, center, mean_rgb, cell_ptr)
+    hip_model.add_self_loops = self_loops
+    try:
+        with torch.no_grad():
+            got, gtr = hip_model.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr, want_trace=True)
+    finally:
+        hip_model.add_self_loops = True
+    n_obj = xyz.shape[0]
+    # per-cell oracle traces -> concatenate in object order
+    pn = [d for d in tr if "sa" in d]
+    for l, (nc, c) in enumerate(((128, 64), (64, 128), (32, 256))):
+        want_sa = torch.cat([d["sa"][l]["out"] for d in pn]).numpy()
+        got_sa = gtr["sa_out"][l].cpu().numpy()[:, :c]
+        assert got_sa.shape == want_sa.shape == (n_obj * nc, c)
+        assert np.abs(got_sa - want_sa).max() < TOL, f"SA{l + 1} output"
+    f0 = torch.cat([d["features0"] for d in pn]).numpy()
+    f2 = torch.cat([d["features2"] for d in pn]).numpy()
+    assert np.abs(gtr["features0"].cpu().numpy() - f0).max() < TOL
+    assert np.abs(gtr["features2"].cpu().numpy() - f2).max() < TOL
+    emb = [d for d in tr if "object_embeddings" in d][0]["object_embeddings"].numpy()
+    assert np.abs(gtr["obj_emb"].cpu().numpy() - emb).max() < TOL
+    assert np.abs(got.cpu().numpy() - want.numpy()).max() < TOL
+
+
+def test_encode_cells_golden(hip_model, golden_dir):
+    z = np.load(os.path.join(golden_dir, "cell_encoder.npz"))
+    with torch.no_grad():
+        got, tr = hip_model.encode_objects_packed(*_to_dev(z["xyz"], z["rgb"], z["center"], z["mean_rgb"]),
+                                                  z["cell_ptr"], want_trace=True)
+    assert np.abs(tr["features2"].cpu().numpy() - z["features2"]).max() < TOL
+    assert np.abs(tr["obj_emb"].cpu().numpy() - z["obj_emb"]).max() < TOL
+    assert np.abs(got.cpu().numpy() - z["out"]).max() < TOL
+
+
+def test_encode_objects_reference_signature(hip_model, oracle_model):
+    """List[List[Object3d]] + List[Batch] entry point (models/cell_retrieval.py:77) == packed entry point."""
+    from text2pos_amd import data as D, synthetic as S
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(41, 3)
+    objects, points = [], []
+    for c in range(3):
+        lo, hi = cell_ptr[c], cell_ptr[c + 1]
+        objects.append([D.Object3d(i, i, np.tile(center[i].astype(np.float64), (2, 1)),
+                                   np.tile(mean_rgb[i].astype(np.float64), (2, 1)), "box") for i in range(lo, hi)])
+        n = hi - lo
+        points.append(D.Batch(x=torch.from_numpy(rgb[lo:hi].reshape(n * 256, 3).copy()),
+                              pos=torch.from_numpy(xyz[lo:hi].reshape(n * 256, 3).copy()),
+                              batch=torch.arange(n).repeat_interleave(256)))
+    with torch.no_grad():
+        a = hip_model.encode_objects(objects, points).cpu()
+        b = hip_model.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr).cpu()
+    assert torch.equal(a, b)
+    want = oracle_model.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)
+    assert (a - want).abs().max().item() < TOL
+
+
+def test_encode_cells_chunking_is_invisible(hip_model):
+    """Results must not depend on the internal chunk size (whole cells per chunk, self-loop aliasing stays per cell)."""
+    from text2pos_amd import synthetic as S
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(51, 12)
+    args = _to_dev(xyz, rgb, center, mean_rgb)
+    with torch.no_grad():
+        one = hip_model.encode_objects_packed(*args, cell_ptr).cpu()
+        many = hip_model.encode_objects_packed(*args, cell_ptr, chunk_objects=40).cpu()
+        again = hip_model.encode_objects_packed(*args, cell_ptr).cpu()
+    assert torch.equal(one, again), "non-deterministic"
+    assert torch.equal(one, many)
+
+
+def test_train_mode_and_grad_fail_loudly(hip_model):
+    hip_model.train()
+    try:
+        with pytest.raises(NotImplementedError):
+            hip_model.encode_text(["north"])
+    finally:
+        hip_model.eval()
+    with pytest.raises(NotImplementedError):
+        hip_model.encode_text(["north"])      # grad enabled, parameters require grad
+    with pytest.raises(Exception):
+        hip_model.forward()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# retrieval
+# ---------------------------------------------------------------------------------------------------------------
+def test_retrieval_golden(golden_dir):
+    import text2pos_amd as t2p
+    z = np.load(os.path.join(golden_dir, "retrieval.npz"))
+    idx, score = t2p.retrieve_topk(z["cells"], z["queries"], 10)
+    assert np.array_equal(idx.cpu().numpy(), z["top10"])
+    want = (z["cells"].astype(np.float64) @ z["queries"].astype(np.float64).T).T
+    assert np.abs(score.cpu().numpy() - np.take_along_axis(want, z["top10"], 1)).max() < 1e-12
+
+
+@pytest.mark.parametrize("nq,nc,k", [(1, 1, 1), (3, 5, 10), (130, 33, 5), (257, 1000, 10), (1000, 12000, 10), (17, 4099, 16)])
+def test_retrieval_vs_oracle(nq, nc, k):
+    import text2pos_amd as t2p
+    from oracle.model import retrieve_topk_f64
+    rng = np.random.default_rng(nq * 31 + nc)
+    c = rng.standard_normal((nc, 256)).astype(np.float32)
+    q = rng.standard_normal((nq, 256)).astype(np.float32)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    if nc > 40:
+        c[7] = c[3]; c[39] = c[3]              # exact duplicates -> ties -> ascending index
+    idx, score = t2p.retrieve_topk(c, q, k)
+    idx, score = idx.cpu().numpy(), score.cpu().numpy()
+    kk = min(k, nc)
+    widx, wscore = retrieve_topk_f64(c, q, kk)
+    assert np.array_equal(idx[:, :kk], widx)
+    assert np.abs(score[:, :kk] - wscore).max() < 1e-12
+    if nc < k:
+        assert (idx[:, nc:] == -1).all() and np.isneginf(score[:, nc:]).all()
+
+
+def test_retrieval_near_ties_need_float64():
+    """Cells whose scores differ by ~1e-9: indistinguishable in fp32, ordered correctly only by a float64 ranking."""
+    import text2pos_amd as t2p
+    from oracle.model import retrieve_topk_f64
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((8, 256)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    base = rng.standard_normal((256,)).astype(np.float32)
+    base /= np.linalg.norm(base)
+    c = np.tile(base, (64, 1))
+    c[:, 0] += (rng.permutation(64) * 2.0 ** -22).astype(np.float32) * np.float32(1e-2)   # tiny distinct perturbations
+    c = np.concatenate([c, rng.standard_normal((200, 256)).astype(np.float32) * 0.01], 0).astype(np.float32)
+    idx, _ = t2p.retrieve_topk(c, q, 16)
+    widx, _ = retrieve_topk_f64(c, q, 16)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+
+
+def test_retrieval_properties_full_size():
+    """Size-independent properties at BASELINE config 2 size (12k cells, 1k queries)."""
+    import text2pos_amd as t2p
+    g = torch.Generator().manual_seed(1)
+    c = torch.nn.functional.normalize(torch.randn(12000, 256, generator=g), dim=-1).to(_dev())
+    q = torch.nn.functional.normalize(torch.randn(1000, 256, generator=g), dim=-1).to(_dev())
+    idx, score = t2p.retrieve_topk(c, q, 10)
+    assert (score[:, :-1] >= score[:, 1:]).all()                      # sorted, high -> low
+    assert (idx >= 0).all() and (idx < 12000).all()
+    assert all(len(set(r.tolist())) == 10 for r in idx.cpu())          # no repeats
+    full = (q.double() @ c.double().T)
+    assert torch.equal(full.topk(10, dim=1).values, score) or (full.topk(10, dim=1).values - score).abs().max() < 1e-12
+    # idempotence: retrieving among the retrieved returns the same order
+    sub = c[idx[0]]
+    idx2, _ = t2p.retrieve_topk(sub, q[:1], 10)
+    assert torch.equal(idx2.cpu()[0], torch.arange(10))
+    # shifting the database by an offset shifts the indices (multi-GPU shard invariant)
+    idx3, _ = t2p.retrieve_topk(c, q, 10, index_offset=5000)
+    assert torch.equal(idx3, idx + 5000)
+    # self-retrieval: a cell queried by its own embedding ranks first with score ~1
+    idx4, s4 = t2p.retrieve_topk(c, c[:50].contiguous(), 1)
+    assert torch.equal(idx4.cpu()[:, 0], torch.arange(50)) and (s4 - 1).abs().max() < 1e-6

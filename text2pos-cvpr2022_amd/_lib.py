@@ -1,0 +1,93 @@
+"""ctypes binding of libt2p_hip.so (C ABI: include/t2p.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails a call, this raises.
+torch is imported first so that the library binds to the HIP runtime (libamdhip64.so.7) torch already loaded --
+one runtime per process, which is what makes torch's device pointers and streams valid inside the kernels.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libt2p_hip.so")
+ABI_VERSION = 1
+
+c_float_p = C.POINTER(C.c_float)
+c_void = C.c_void_p
+
+
+class CellWeights(C.Structure):
+    _names = (["sa_w1", "sa_b1", "sa_w2", "sa_b2"], ["ga_w1", "ga_b1", "ga_w2", "ga_b2", "lin1_w", "lin1_b", "lin2_w",
+              "lin2_b", "pn_w", "pn_b", "col_w1", "col_b1", "col_w2", "col_b2", "pos_w1", "pos_b1", "pos_w2", "pos_b2",
+              "merge_w", "merge_b", "g_wp", "g_bp", "g_wq", "g_w2", "g_b2", "lin_w1", "lin_b1", "lin_w2", "lin_b2"])
+    _fields_ = [(n, c_void * 3) for n in _names[0]] + [(n, c_void) for n in _names[1]]
+
+
+class CellConfig(C.Structure):
+    _fields_ = [("n_pts", C.c_int32), ("embed_dim", C.c_int32), ("pointnet_features", C.c_int32),
+                ("use_class", C.c_int32), ("use_color", C.c_int32), ("use_position", C.c_int32),
+                ("self_loops", C.c_int32), ("knn_k", C.c_int32), ("variation", C.c_int32),
+                ("radius", C.c_float * 3), ("chunk_objects", C.c_int32)]
+
+
+class CellTrace(C.Structure):
+    _fields_ = [("fps_idx", c_void * 3), ("nbr", c_void * 3), ("cnt", c_void * 3), ("sa_out", c_void * 3),
+                ("features0", c_void), ("features2", c_void), ("obj_emb", c_void), ("knn_idx", c_void)]
+
+
+class TextWeights(C.Structure):
+    _fields_ = [("embedding", c_void), ("w_ih", c_void), ("w_hh", c_void), ("bias", c_void)]
+
+
+# every symbol include/t2p.h declares: (restype, argtypes)
+SYMBOLS = {
+    "t2p_abi_version": (C.c_int, []),
+    "t2p_last_error": (C.c_char_p, []),
+    "t2p_encode_cells_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.POINTER(CellConfig)]),
+    "t2p_encode_cells": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int64,
+                                   C.POINTER(CellWeights), C.POINTER(CellConfig), c_void, C.POINTER(CellTrace), c_void,
+                                   C.c_size_t, c_void]),
+    "t2p_encode_text_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "t2p_encode_text": (C.c_int, [c_void, c_void, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(TextWeights),
+                                  c_void, c_void, c_void, C.c_size_t, c_void]),
+    "t2p_sim_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "t2p_sim_topk": (C.c_int, [c_void, c_void, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, c_void, c_void,
+                               c_void, C.c_size_t, c_void]),
+    "t2p_sample_group": (C.c_int, [c_void, C.c_int64, C.c_int32, c_float_p, C.POINTER(c_void), C.POINTER(c_void),
+                                   C.POINTER(c_void), c_void]),
+    "t2p_knn": (C.c_int, [c_void, C.c_int32, c_void, C.c_int32, C.c_int32, C.c_int32, c_void, c_void]),
+    "t2p_gemm": (C.c_int, [c_void, C.c_int32, c_void, c_void, c_void, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                           C.c_int32, C.c_int32, c_void]),
+    "t2p_rownorm": (C.c_int, [c_void, C.c_int64, C.c_int32, c_void, c_void]),
+}
+
+_lib = None
+
+
+class T2PError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libt2p_hip.so (once).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise T2PError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python __graft_entry__.py build, or python text2pos-cvpr2022_amd/build.py)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the export is missing
+            fn.restype, fn.argtypes = res, args
+        if handle.t2p_abi_version() != ABI_VERSION:
+            raise T2PError(f"libt2p_hip.so ABI {handle.t2p_abi_version()} != binding ABI {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().t2p_last_error().decode("utf-8", "replace")
+        raise T2PError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,111 @@
+"""Drop-in for the reference's coarse model: same constructor, `encode_text`, `encode_objects`, `embed_dim`,
+`device` / `get_device()` and state_dict layout as models/cell_retrieval.py::CellRetrievalNetwork, with the forward
+arithmetic executed by libt2p_hip.so on an MI355X.
+
+Callers that drop in unchanged: training/coarse.py:111,124 (eval_epoch) and evaluation/pipeline.py:73-75,111-113.
+Forward-only (the reference evaluates under torch.no_grad(), training/coarse.py:68); training-mode BatchNorm and
+autograd are not built and raise instead of silently falling back to another implementation.
+"""
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from .data import pack_cells
+from .modules import LanguageEncoder, get_mlp
+from .object_encoder import ObjectEncoder
+
+
+class DynamicEdgeConv(nn.Module):
+    """Holds `nn` under the key torch_geometric.nn.DynamicEdgeConv uses (`graph1.nn.*`)."""
+
+    def __init__(self, nn_, k, aggr="max"):
+        super().__init__()
+        self.nn, self.k, self.aggr = nn_, k, aggr
+
+
+class CellRetrievalNetwork(nn.Module):
+    def __init__(self, known_classes: List[str], known_colors: List[str], known_words: List[str], args,
+                 add_self_loops: bool = True):
+        """add_self_loops=True reproduces torch_geometric's PointConv default, which the reference relies on
+        (models/pointcloud/pointnet2.py:23); False gives the plain ball-query neighbourhoods."""
+        super().__init__()
+        self.embed_dim = args.embed_dim
+        self.use_features = args.use_features
+        self.variation = args.variation
+        self.args = args
+        self.add_self_loops = add_self_loops
+        d = self.embed_dim
+        assert args.variation in (0, 1)
+        self.graph1 = DynamicEdgeConv(get_mlp([2 * d, d, d], add_batchnorm=True), k=8,
+                                      aggr="max" if args.variation == 0 else "mean")
+        self.lin = get_mlp([d, d, d])
+        self.object_encoder = ObjectEncoder(d, known_classes, known_colors, args)
+        self.language_encoder = LanguageEncoder(known_words, d, bi_dir=True)
+        self._pack = None
+
+    # ---- text branch -----------------------------------------------------------------------------------------
+    def encode_text(self, descriptions):
+        """List[str] -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:69-75)."""
+        self._check_forward_only()
+        return self.language_encoder(descriptions, normalize=True)
+
+    # ---- cell branch -----------------------------------------------------------------------------------------
+    def _cell_pack(self):
+        ver = (packing.params_version(self), str(self.device))
+        if self._pack is None or self._pack[0] != ver:
+            tensors = packing.pack_cell_weights(self, self.device)
+            self._pack = (ver, tensors, ops.make_cell_weights(tensors))
+        return self._pack[2]
+
+    def _cell_config(self, n_pts, chunk_objects=0):
+        a = self.args
+        if getattr(a, "class_embed", False) or getattr(a, "color_embed", False):
+            raise NotImplementedError("--class_embed / --color_embed ablations are not built on the HIP path")
+        radii = self.object_encoder.pointnet.radii
+        return ops.make_cell_config(n_pts=n_pts, embed_dim=self.embed_dim, pointnet_features=a.pointnet_features,
+                                    use_features=tuple(a.use_features), self_loops=self.add_self_loops,
+                                    knn_k=self.graph1.k, variation=self.variation, radius=radii,
+                                    chunk_objects=chunk_objects)
+
+    def _check_forward_only(self):
+        if self.training:
+            raise NotImplementedError("training-mode forward (batch-statistics BatchNorm) is not built; call .eval()")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the HIP path is forward-only; call it under torch.no_grad()")
+
+    def encode_objects_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, cell_ptr_dev=None, want_trace=False,
+                              chunk_objects=0):
+        """Device-resident packed inputs: xyz/rgb [Nobj, P, 3], center/mean_rgb [Nobj, 3] (fp32, on self.device),
+        cell_ptr int32 [B+1] on the host.  Returns [B, D] L2-normalised."""
+        self._check_forward_only()
+        cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int32)
+        if cell_ptr_dev is None:
+            cell_ptr_dev = torch.from_numpy(cp).to(self.device)
+        cfg = self._cell_config(xyz.shape[1], chunk_objects)
+        return ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
+
+    def encode_objects(self, objects, object_points):
+        """objects: List[List[Object3d]], object_points: List[Batch] (one PyG-style batch per cell)
+        -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:77-107)."""
+        self._check_forward_only()
+        n_pts = int(getattr(self.args, "pointnet_numpoints", 256))
+        zero_color = "color" not in self.args.use_features  # models/object_encoder.py:86-90
+        xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, n_pts, zero_color)
+        dev = self.device
+        to = lambda t: t.to(dev, non_blocking=True)
+        return self.encode_objects_packed(to(xyz), to(rgb), to(center), to(mean_rgb), cell_ptr)
+
+    encode_cells = encode_objects  # the name BASELINE.json uses for the same method
+
+    def forward(self):
+        raise Exception("Not implemented.")  # as the reference (models/cell_retrieval.py:109-110)
+
+    @property
+    def device(self):
+        return next(self.lin.parameters()).device
+
+    def get_device(self):
+        return self.device

@@ -1,0 +1,448 @@
+// extern "C" entry points of libt2p_hip.so (see include/t2p.h) and the launch orchestration of the cell branch.
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/t2p.h"
+#include "t2p_common.h"
+
+namespace t2p {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int num_cus() {
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cached = prop.multiProcessorCount;
+        if (cached <= 0) cached = 256;
+    }
+    return cached;
+}
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Bump {
+    char* base;
+    size_t off, cap;
+    template <typename T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = (T*)(base ? base + off : nullptr);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+// Level geometry for n_pts points: dense/centroid counts, feature widths, hidden widths.
+struct Geo {
+    int nd[3], nc[3];
+    static constexpr int H[3] = {32, 128, 256};
+    static constexpr int C[3] = {64, 128, 256};
+    static constexpr int LD[3] = {72, 136, 264};  // SA output row = [C | xyz | 0 x 5]
+    explicit Geo(int n_pts) {
+        nd[0] = n_pts;
+        for (int l = 0; l < 3; l++) {
+            nc[l] = (nd[l] + 1) / 2;
+            if (l < 2) nd[l + 1] = nc[l];
+        }
+    }
+};
+constexpr int Geo::H[3];
+constexpr int Geo::C[3];
+constexpr int Geo::LD[3];
+
+struct CellWs {
+    GroupTables gt;
+    float *A[3], *B[3], *F[3];
+    float *gh, *f0, *f1, *f2, *cat, *emb, *embn, *P, *Q, *x1, *pool, *l1, *l2;
+    int32_t *knn, *seg_ptr, *first;
+};
+
+// Carve the per-chunk workspace (n objects, nb cells).  With base == nullptr this only measures.
+size_t carve(Bump& b, int64_t n, int64_t nb, const t2p_cell_config& cfg, CellWs* ws) {
+    Geo g(cfg.n_pts);
+    const int D = cfg.embed_dim;
+    const int nfeat = (cfg.use_class ? 1 : 0) + (cfg.use_color ? 1 : 0) + (cfg.use_position ? 1 : 0);
+    CellWs w;
+    for (int l = 0; l < 3; l++) {
+        w.gt.n_dense[l] = g.nd[l];
+        w.gt.n_cent[l] = g.nc[l];
+        w.gt.fps_idx[l] = b.take<uint8_t>(n * g.nc[l]);
+        w.gt.nbr[l] = b.take<uint8_t>(n * g.nc[l] * 32);
+        w.gt.cnt[l] = b.take<uint8_t>(n * g.nc[l]);
+        w.A[l] = b.take<float>(n * g.nd[l] * Geo::H[l]);
+        w.B[l] = b.take<float>(n * g.nc[l] * Geo::H[l]);
+        w.F[l] = b.take<float>(n * g.nc[l] * Geo::LD[l]);
+    }
+    w.gh = b.take<float>(n * g.nc[2] * 512);
+    w.f0 = b.take<float>(n * 1024);
+    w.f1 = b.take<float>(n * 512);
+    w.f2 = b.take<float>(n * 256);
+    w.cat = b.take<float>(n * (size_t)(nfeat > 0 ? nfeat : 1) * D);
+    w.emb = b.take<float>(n * D);
+    w.embn = b.take<float>(n * D);
+    w.P = b.take<float>(n * D);
+    w.Q = b.take<float>(n * D);
+    w.x1 = b.take<float>(n * D);
+    w.knn = b.take<int32_t>(n * (size_t)cfg.knn_k);
+    w.first = b.take<int32_t>(n);
+    w.seg_ptr = b.take<int32_t>(nb + 1);
+    w.pool = b.take<float>(nb * D);
+    w.l1 = b.take<float>(nb * D);
+    w.l2 = b.take<float>(nb * D);
+    if (ws) *ws = w;
+    return align_up(b.off, 256);
+}
+
+int default_chunk(const t2p_cell_config& cfg) { return cfg.chunk_objects > 0 ? cfg.chunk_objects : 8192; }
+
+int check_cfg(const t2p_cell_config* cfg) {
+    T2P_CHECK_ARG(cfg != nullptr, "encode_cells: cfg is NULL");
+    if (cfg->n_pts != 256) {
+        set_error("encode_cells: n_pts=%d not built (256; the GA max-pool tile assumes 32 points per object)", cfg->n_pts);
+        return T2P_E_UNSUPPORTED;
+    }
+    if (cfg->embed_dim != 256) {
+        set_error("encode_cells: embed_dim=%d not built (256)", cfg->embed_dim);
+        return T2P_E_UNSUPPORTED;
+    }
+    if (cfg->variation != 0) {
+        set_error("encode_cells: variation=%d not built (0 = max aggregation)", cfg->variation);
+        return T2P_E_UNSUPPORTED;
+    }
+    T2P_CHECK_ARG(cfg->pointnet_features >= 0 && cfg->pointnet_features <= 2, "encode_cells: pointnet_features=%d",
+                  cfg->pointnet_features);
+    T2P_CHECK_ARG(cfg->use_class || cfg->use_color || cfg->use_position, "encode_cells: use_features is empty");
+    T2P_CHECK_ARG(cfg->knn_k >= 1 && cfg->knn_k <= 32, "encode_cells: knn_k=%d outside [1,32]", cfg->knn_k);
+    return 0;
+}
+
+template <typename T>
+int copy_trace(T* dst, const T* src, size_t n, hipStream_t st) {
+    if (dst == nullptr || n == 0) return 0;
+    hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        set_error("encode_cells: trace copy failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+int encode_chunk(const float* xyz, const float* rgb, const float* center, const float* mean_rgb,
+                 const int32_t* cell_ptr_dev /* at first cell of chunk */, int32_t o_lo, int64_t n, int64_t nb,
+                 int max_cell, const t2p_cell_weights& W, const t2p_cell_config& cfg, float* out,
+                 const t2p_cell_trace* tr, int64_t trace_obj0, CellWs& ws, hipStream_t st) {
+    Geo g(cfg.n_pts);
+    const int D = cfg.embed_dim;
+    T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st));
+    T2P_TRY(launch_sample_group(xyz, n, cfg.n_pts, cfg.radius, ws.gt, st));
+
+    // ---- three set-abstraction levels -----------------------------------------------------------------------
+    for (int l = 0; l < 3; l++) {
+        const int H = Geo::H[l], C = Geo::C[l];
+        const int cf = l == 0 ? 3 : Geo::C[l - 1];  // feature columns in front of the xyz columns
+        const float* pos_src = l == 0 ? xyz : ws.F[l - 1];
+        const int ld_pos = l == 0 ? 3 : Geo::LD[l - 1];
+        const int pos_col0 = l == 0 ? 0 : Geo::C[l - 1];
+        // layer-1 point table A_j = W1 [x_j | pos_j] + b1
+        if (l == 0) {
+            T2P_TRY(launch_sa1_point_table(rgb, xyz, n * g.nd[0], W.sa_w1[0], W.sa_b1[0], H, ws.A[0], st));
+        } else {
+            WsParams p{};
+            p.A = ws.F[l - 1];
+            p.lda = Geo::LD[l - 1];
+            p.W = W.sa_w1[l];
+            p.ldw = H;
+            p.bias = W.sa_b1[l];
+            p.out = ws.A[l];
+            p.ldo = H;
+            p.relu = 0;
+            p.M = n * g.nd[l];
+            T2P_TRY(launch_ws(WS_DENSE_STORE, Geo::LD[l - 1], H, p, st));
+        }
+        // centroid table B_i = W1p pos_i
+        T2P_TRY(launch_pos_table(pos_src, ld_pos, pos_col0, ws.gt.fps_idx[l], n, g.nd[l], g.nc[l],
+                                 W.sa_w1[l] + (size_t)cf * H, H, ws.B[l], st));
+        // per-edge ReLU(A_j - B_i) -> layer 2 -> max over the group
+        WsParams p{};
+        p.A = ws.A[l];
+        p.lda = H;
+        p.Bc = ws.B[l];
+        p.W = W.sa_w2[l];
+        p.ldw = C;
+        p.bias = W.sa_b2[l];
+        p.out = ws.F[l];
+        p.ldo = Geo::LD[l];
+        p.relu = 1;
+        p.n_groups = n;
+        p.nbr = ws.gt.nbr[l];
+        p.cnt = ws.gt.cnt[l];
+        p.fps_idx = ws.gt.fps_idx[l];
+        p.obj_cell_first = ws.first;
+        p.pos_src = pos_src;
+        p.ld_pos = ld_pos;
+        p.pos_col0 = pos_col0;
+        p.n_dense = g.nd[l];
+        p.n_cent = g.nc[l];
+        p.self_loops = cfg.self_loops;
+        T2P_TRY(launch_ws(WS_EDGE_SA, H, C, p, st));
+    }
+    // ---- global abstraction: [x | pos] -> 512 -> 1024, max over the object's 32 points ------------------------
+    {
+        WsParams p{};
+        p.A = ws.F[2];
+        p.lda = Geo::LD[2];
+        p.W = W.ga_w1;
+        p.ldw = 512;
+        p.bias = W.ga_b1;
+        p.out = ws.gh;
+        p.ldo = 512;
+        p.relu = 1;
+        p.M = n * g.nc[2];
+        T2P_TRY(launch_ws(WS_DENSE_STORE, Geo::LD[2], 512, p, st));
+        WsParams q{};
+        q.A = ws.gh;
+        q.lda = 512;
+        q.W = W.ga_w2;
+        q.ldw = 1024;
+        q.bias = W.ga_b2;
+        q.out = ws.f0;
+        q.ldo = 1024;
+        q.relu = 1;
+        q.n_groups = n;
+        T2P_TRY(launch_ws(WS_DENSE_GROUPMAX, 512, 1024, q, st));
+    }
+    // ---- PointNet2 heads + ObjectEncoder ------------------------------------------------------------------------
+    T2P_TRY(launch_gemm(ws.f0, 1024, W.lin1_w, W.lin1_b, ws.f1, 512, 0, n, 1024, 512, 1, st));
+    T2P_TRY(launch_gemm(ws.f1, 512, W.lin2_w, W.lin2_b, ws.f2, 256, 0, n, 512, 256, 1, st));
+    const int nfeat = (cfg.use_class ? 1 : 0) + (cfg.use_color ? 1 : 0) + (cfg.use_position ? 1 : 0);
+    const int ldcat = nfeat * D;
+    int slot = 0;
+    if (cfg.use_class) {
+        const float* fin = cfg.pointnet_features == 0 ? ws.f0 : (cfg.pointnet_features == 1 ? ws.f1 : ws.f2);
+        const int kin = cfg.pointnet_features == 0 ? 1024 : (cfg.pointnet_features == 1 ? 512 : 256);
+        // mlp_pointnet into P (scratch), then F.normalize into the concat slot
+        T2P_TRY(launch_gemm(fin, kin, W.pn_w, W.pn_b, ws.P, D, 0, n, kin, D, 1, st));
+        T2P_TRY(launch_rownorm(ws.P, D, n, D, ws.cat, ldcat, slot * D, st));
+        slot++;
+    }
+    if (cfg.use_color) {
+        T2P_TRY(launch_mlp3_norm(mean_rgb, n, W.col_w1, W.col_b1, W.col_w2, W.col_b2, D, ws.cat, ldcat, slot * D, st));
+        slot++;
+    }
+    if (cfg.use_position) {
+        T2P_TRY(launch_mlp3_norm(center, n, W.pos_w1, W.pos_b1, W.pos_w2, W.pos_b2, D, ws.cat, ldcat, slot * D, st));
+        slot++;
+    }
+    const float* emb = ws.cat;  // single feature: embeddings[0] is returned un-merged (object_encoder.py:137-140)
+    if (nfeat > 1) {
+        T2P_TRY(launch_gemm(ws.cat, ldcat, W.merge_w, W.merge_b, ws.emb, D, 0, n, ldcat, D, 1, st));
+        emb = ws.emb;
+    }
+    // ---- cell head: normalize, DynamicEdgeConv(k, max), global max pool, lin, normalize -------------------------
+    T2P_TRY(launch_rownorm(emb, D, n, D, ws.embn, D, 0, st));
+    T2P_TRY(launch_gemm(ws.embn, D, W.g_wp, W.g_bp, ws.P, D, 0, n, D, D, 0, st));
+    T2P_TRY(launch_gemm(ws.embn, D, W.g_wq, nullptr, ws.Q, D, 0, n, D, D, 0, st));
+    T2P_TRY(launch_knn(ws.embn, D, ws.seg_ptr, (int)nb, max_cell, cfg.knn_k, ws.knn, st));
+    {
+        WsParams p{};
+        p.A = ws.Q;
+        p.lda = D;
+        p.Bc = ws.P;
+        p.W = W.g_w2;
+        p.ldw = D;
+        p.bias = W.g_b2;
+        p.out = ws.x1;
+        p.ldo = D;
+        p.relu = 1;
+        p.n_groups = (n + 31) / 32;
+        p.knn_idx = ws.knn;
+        p.knn_k = cfg.knn_k;
+        p.n_dst = n;
+        T2P_TRY(launch_ws(WS_EDGE_KNN, D, D, p, st));
+    }
+    T2P_TRY(launch_segmax(ws.x1, D, ws.seg_ptr, (int)nb, ws.pool, 0, st));
+    T2P_TRY(launch_gemm(ws.pool, D, W.lin_w1, W.lin_b1, ws.l1, D, 0, nb, D, D, 1, st));
+    T2P_TRY(launch_gemm(ws.l1, D, W.lin_w2, W.lin_b2, ws.l2, D, 0, nb, D, D, 1, st));
+    T2P_TRY(launch_rownorm(ws.l2, D, nb, D, out, D, 0, st));
+
+    if (tr) {
+        for (int l = 0; l < 3; l++) {
+            T2P_TRY(copy_trace(tr->fps_idx[l] ? tr->fps_idx[l] + trace_obj0 * g.nc[l] : nullptr, ws.gt.fps_idx[l],
+                               (size_t)n * g.nc[l], st));
+            T2P_TRY(copy_trace(tr->nbr[l] ? tr->nbr[l] + trace_obj0 * g.nc[l] * 32 : nullptr, ws.gt.nbr[l],
+                               (size_t)n * g.nc[l] * 32, st));
+            T2P_TRY(copy_trace(tr->cnt[l] ? tr->cnt[l] + trace_obj0 * g.nc[l] : nullptr, ws.gt.cnt[l],
+                               (size_t)n * g.nc[l], st));
+            T2P_TRY(copy_trace(tr->sa_out[l] ? tr->sa_out[l] + trace_obj0 * g.nc[l] * Geo::LD[l] : nullptr, ws.F[l],
+                               (size_t)n * g.nc[l] * Geo::LD[l], st));
+        }
+        T2P_TRY(copy_trace(tr->features0 ? tr->features0 + trace_obj0 * 1024 : nullptr, ws.f0, (size_t)n * 1024, st));
+        T2P_TRY(copy_trace(tr->features2 ? tr->features2 + trace_obj0 * 256 : nullptr, ws.f2, (size_t)n * 256, st));
+        T2P_TRY(copy_trace(tr->obj_emb ? tr->obj_emb + trace_obj0 * D : nullptr, emb, (size_t)n * D, st));
+        // knn indices are chunk-local object rows; tests use a single chunk or add the chunk offset themselves
+        T2P_TRY(copy_trace(tr->knn_idx ? tr->knn_idx + trace_obj0 * cfg.knn_k : nullptr, ws.knn,
+                           (size_t)n * cfg.knn_k, st));
+    }
+    return 0;
+}
+
+// Whole cells per chunk, at most `chunk` objects (a single larger cell still forms its own chunk).
+int64_t next_chunk_end(const int32_t* cp, int64_t c0, int64_t n_cells, int chunk) {
+    int64_t c1 = c0 + 1;
+    while (c1 < n_cells && (cp[c1 + 1] - cp[c0]) <= chunk) c1++;
+    return c1;
+}
+
+}  // namespace
+}  // namespace t2p
+
+using namespace t2p;
+
+extern "C" {
+
+int t2p_abi_version(void) { return T2P_ABI_VERSION; }
+const char* t2p_last_error(void) { return g_err; }
+
+size_t t2p_encode_cells_workspace_bytes(int64_t n_obj, int64_t n_cells, const t2p_cell_config* cfg) {
+    if (cfg == nullptr || n_obj <= 0) return 256;
+    // a chunk holds at most max(chunk_objects, largest cell) objects; the caller may not know the largest cell here,
+    // so size for min(n_obj, chunk) and let t2p_encode_cells re-check against the actual partition.
+    int64_t n = default_chunk(*cfg);
+    if (n > n_obj) n = n_obj;
+    int64_t nb = n_cells < n ? n_cells : n;
+    Bump b{nullptr, 0, 0};
+    return carve(b, n, nb > 0 ? nb : 1, *cfg, nullptr) + 256;
+}
+
+int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, const float* mean_rgb,
+                     const int32_t* cell_ptr_host, const int32_t* cell_ptr, int64_t n_obj, int64_t n_cells,
+                     const t2p_cell_weights* w, const t2p_cell_config* cfg, float* out, const t2p_cell_trace* trace,
+                     void* workspace, size_t workspace_bytes, t2p_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    T2P_TRY(check_cfg(cfg));
+    T2P_CHECK_ARG(w != nullptr && cell_ptr_host != nullptr && cell_ptr != nullptr && out != nullptr,
+                  "encode_cells: NULL argument");
+    T2P_CHECK_ARG(n_cells >= 0 && n_obj >= 0, "encode_cells: negative size");
+    if (n_cells == 0) return 0;
+    T2P_CHECK_ARG(cell_ptr_host[0] == 0 && cell_ptr_host[n_cells] == n_obj,
+                  "encode_cells: cell_ptr must start at 0 and end at n_obj=%lld (got %d..%d)", (long long)n_obj,
+                  cell_ptr_host[0], cell_ptr_host[n_cells]);
+    for (int64_t c = 0; c < n_cells; c++)
+        T2P_CHECK_ARG(cell_ptr_host[c + 1] > cell_ptr_host[c],
+                      "encode_cells: cell %lld is empty (the reference asserts >= 1 object per cell, "
+                      "dataloading/kitti360pose/utils.py:108)", (long long)c);
+    T2P_CHECK_ARG((((uintptr_t)xyz | (uintptr_t)rgb | (uintptr_t)workspace) & 15) == 0,
+                  "encode_cells: xyz, rgb and workspace must be 16-byte aligned");
+    const int chunk = default_chunk(*cfg);
+    for (int64_t c0 = 0; c0 < n_cells;) {
+        const int64_t c1 = next_chunk_end(cell_ptr_host, c0, n_cells, chunk);
+        const int32_t o_lo = cell_ptr_host[c0], o_hi = cell_ptr_host[c1];
+        const int64_t n = o_hi - o_lo, nb = c1 - c0;
+        int max_cell = 0;
+        for (int64_t c = c0; c < c1; c++) {
+            const int m = cell_ptr_host[c + 1] - cell_ptr_host[c];
+            max_cell = m > max_cell ? m : max_cell;
+        }
+        Bump b{(char*)workspace, 0, workspace_bytes};
+        CellWs ws;
+        const size_t need = carve(b, n, nb, *cfg, &ws);
+        if (need > workspace_bytes) {
+            set_error("encode_cells: workspace %zu B < %zu B needed for a chunk of %lld objects / %lld cells",
+                      workspace_bytes, need, (long long)n, (long long)nb);
+            return T2P_E_WORKSPACE;
+        }
+        const int64_t P3 = (int64_t)cfg->n_pts * 3;
+        T2P_TRY(encode_chunk(xyz + o_lo * P3, rgb + o_lo * P3, center + (int64_t)o_lo * 3, mean_rgb + (int64_t)o_lo * 3,
+                             cell_ptr + c0, o_lo, n, nb, max_cell, *w, *cfg, out + c0 * cfg->embed_dim, trace, o_lo, ws,
+                             st));
+        c0 = c1;
+    }
+    return 0;
+}
+
+size_t t2p_encode_text_workspace_bytes(int64_t batch, int32_t vocab, int32_t embed_dim) {
+    const size_t D = embed_dim;
+    return align_up((size_t)2 * vocab * 4 * D * sizeof(float), 256) + align_up((size_t)2 * batch * D * sizeof(float), 256) +
+           align_up((size_t)batch * D * sizeof(float), 256) + 256;
+}
+
+int t2p_encode_text(const int32_t* tokens, const int32_t* lengths, int64_t batch, int32_t max_len, int32_t vocab,
+                    int32_t embed_dim, const t2p_text_weights* w, float* out_raw, float* out, void* workspace,
+                    size_t workspace_bytes, t2p_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    T2P_CHECK_ARG(w != nullptr && tokens != nullptr && lengths != nullptr && out != nullptr, "encode_text: NULL argument");
+    T2P_CHECK_ARG(batch >= 0 && batch < (1 << 30) && max_len >= 1 && vocab >= 1, "encode_text: bad sizes");
+    if (batch == 0) return 0;
+    const size_t need = t2p_encode_text_workspace_bytes(batch, vocab, embed_dim);
+    if (workspace == nullptr || workspace_bytes < need) {
+        set_error("encode_text: workspace %zu B < required %zu B", workspace_bytes, need);
+        return T2P_E_WORKSPACE;
+    }
+    const int D = embed_dim;
+    Bump b{(char*)workspace, 0, workspace_bytes};
+    float* table = b.take<float>((size_t)2 * vocab * 4 * D);
+    float* hdir = b.take<float>((size_t)2 * batch * D);
+    float* raw = out_raw ? out_raw : b.take<float>((size_t)batch * D);
+    // gate table [dir][V][4D] = embedding [V][D] x W_ih^T [D][4D] + (b_ih + b_hh)
+    for (int dir = 0; dir < 2; dir++)
+        T2P_TRY(launch_gemm(w->embedding, D, w->w_ih + (size_t)dir * D * 4 * D, w->bias + (size_t)dir * 4 * D,
+                            table + (size_t)dir * vocab * 4 * D, 4 * D, 0, vocab, D, 4 * D, 0, st));
+    T2P_TRY(launch_bilstm_impl(table, w->w_hh, tokens, lengths, (int)batch, max_len, vocab, D, hdir, raw, st));
+    T2P_TRY(launch_rownorm(raw, D, batch, D, out, D, 0, st));
+    return 0;
+}
+
+size_t t2p_sim_topk_workspace_bytes(int64_t nq, int64_t nc, int32_t k) { return sim_topk_workspace_bytes(nq, nc, k); }
+
+int t2p_sim_topk(const float* queries, const float* cells, int64_t nq, int64_t nc, int32_t dim, int32_t k,
+                 int64_t index_offset, int64_t* out_idx, double* out_score, void* workspace, size_t workspace_bytes,
+                 t2p_stream_t stream) {
+    T2P_CHECK_ARG(queries != nullptr && cells != nullptr && out_idx != nullptr && out_score != nullptr,
+                  "sim_topk: NULL argument");
+    T2P_CHECK_ARG(nq >= 0 && nc >= 0, "sim_topk: negative size");
+    return launch_sim_topk(queries, cells, nq, nc, dim, k, index_offset, out_idx, out_score, workspace, workspace_bytes,
+                           (hipStream_t)stream);
+}
+
+int t2p_sample_group(const float* xyz, int64_t n_obj, int32_t n_pts, const float* radius_host,
+                     uint8_t* const* fps_idx, uint8_t* const* nbr, uint8_t* const* cnt, t2p_stream_t stream) {
+    T2P_CHECK_ARG(xyz && radius_host && fps_idx && nbr && cnt, "sample_group: NULL argument");
+    Geo g(n_pts);
+    GroupTables gt;
+    for (int l = 0; l < 3; l++) {
+        gt.fps_idx[l] = fps_idx[l];
+        gt.nbr[l] = nbr[l];
+        gt.cnt[l] = cnt[l];
+        gt.n_dense[l] = g.nd[l];
+        gt.n_cent[l] = g.nc[l];
+    }
+    return launch_sample_group(xyz, n_obj, n_pts, radius_host, gt, (hipStream_t)stream);
+}
+
+int t2p_knn(const float* x, int32_t dim, const int32_t* seg_ptr, int32_t n_seg, int32_t max_seg_rows, int32_t k,
+            int32_t* out_idx, t2p_stream_t stream) {
+    return launch_knn(x, dim, seg_ptr, n_seg, max_seg_rows, k, out_idx, (hipStream_t)stream);
+}
+
+int t2p_gemm(const float* a, int32_t lda, const float* w, const float* bias, float* c, int32_t ldc, int32_t c0,
+             int64_t m, int32_t k, int32_t n, int32_t relu, t2p_stream_t stream) {
+    return launch_gemm(a, lda, w, bias, c, ldc, c0, m, k, n, relu, (hipStream_t)stream);
+}
+
+int t2p_rownorm(const float* x, int64_t n_rows, int32_t dim, float* out, t2p_stream_t stream) {
+    return launch_rownorm(x, dim, n_rows, dim, out, dim, 0, (hipStream_t)stream);
+}
+
+}  // extern "C"

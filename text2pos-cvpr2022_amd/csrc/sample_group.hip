@@ -1,0 +1,158 @@
+// Fused farthest-point sampling + ball query for the three PointNet++ set-abstraction levels of one object.
+//
+// Replaces (reference call sites): gnn.fps  models/pointcloud/pointnet2.py:26  and gnn.radius
+// models/pointcloud/pointnet2.py:28-30 (max_num_neighbors = 32) for sa1/sa2/sa3 (ratio 0.5, r = 0.2/0.3/0.4).
+//
+// Both operators depend on the xyz coordinates only, and level l+1 works on the FPS subset of level l, so all
+// three levels are computed by ONE wavefront per object with the coordinates staged once in LDS
+// (256 x 3 fp32 = 3 KiB).  Output is the compact uint8 group table (GroupTables in t2p_common.h): 7.4 KiB per
+// object instead of ~90 KiB of int64 COO edges.
+//
+// Pinned semantics (SURVEY.md 0.6 / oracle/primitives.c): FPS starts at local point 0, arg-max ties -> lowest
+// index; ball query keeps the first <= 32 in-range dense points in ascending index, strict d2 < r*r;
+// d2 = (dx*dx + dy*dy) + dz*dz in fp32 with no FMA contraction.
+#include "t2p_common.h"
+
+namespace t2p {
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kMaxPts = 256;
+constexpr int kMaxNbr = 32;
+
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    float s = xx + yy;
+    return s + zz;
+}
+
+// wave-wide arg-max of (d, idx): larger d wins, equal d -> smaller idx.  Result uniform across the wave.
+__device__ __forceinline__ void wave_argmax(float& d, int& idx) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float od = __shfl_xor(d, off, 64);
+        int oi = __shfl_xor(idx, off, 64);
+        bool take = (od > d) || (od == d && oi < idx);
+        d = take ? od : d;
+        idx = take ? oi : idx;
+    }
+}
+
+// One level: FPS of n_c samples among the n_d points in (px,py,pz) [LDS], then ball query.
+// sel (LDS, n_c bytes) receives the FPS indices; the sampled coordinates are written to (qx,qy,qz).
+__device__ void level(const float* px, const float* py, const float* pz, int n_d, int n_c, float r2,
+                      uint8_t* sel, float* qx, float* qy, float* qz, uint8_t* nbr_lds, uint8_t* cnt_lds) {
+    const int lane = threadIdx.x;
+    float x[4], y[4], z[4], mind[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int i = lane + 64 * j;
+        bool v = i < n_d;
+        x[j] = v ? px[i] : 0.f;
+        y[j] = v ? py[i] : 0.f;
+        z[j] = v ? pz[i] : 0.f;
+        mind[j] = INFINITY;
+    }
+    int cur = 0;
+    if (lane == 0) sel[0] = 0;
+    for (int s = 1; s < n_c; s++) {
+        float cx = px[cur], cy = py[cur], cz = pz[cur];
+        float bd = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int i = lane + 64 * j;
+            if (i < n_d) {
+                float d = dist2(x[j], y[j], z[j], cx, cy, cz);
+                mind[j] = d < mind[j] ? d : mind[j];
+                if (mind[j] > bd) { bd = mind[j]; bi = i; }
+            }
+        }
+        wave_argmax(bd, bi);
+        cur = bi;
+        if (lane == 0) sel[s] = (uint8_t)cur;
+    }
+    __syncthreads();
+    for (int c = lane; c < n_c; c += 64) {
+        int i = sel[c];
+        qx[c] = px[i];
+        qy[c] = py[i];
+        qz[c] = pz[i];
+    }
+    __syncthreads();
+    // ball query: centroids one after the other, the wave scans the dense points 64 at a time in ascending order
+    for (int c = 0; c < n_c; c++) {
+        float cx = qx[c], cy = qy[c], cz = qz[c];
+        int count = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int i = lane + 64 * j;
+            bool hit = (i < n_d) && (dist2(x[j], y[j], z[j], cx, cy, cz) < r2);
+            unsigned long long m = __ballot(hit);
+            int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && pos < kMaxNbr) nbr_lds[c * kMaxNbr + pos] = (uint8_t)i;
+            count += __popcll(m);
+        }
+        if (lane == 0) cnt_lds[c] = (uint8_t)(count < kMaxNbr ? count : kMaxNbr);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
+                                                     float r0, float r1, float r2, GroupTables gt) {
+    __shared__ float p0[3][kMaxPts];
+    __shared__ float p1[3][kMaxPts / 2];
+    __shared__ float p2[3][kMaxPts / 4];
+    __shared__ float p3[3][kMaxPts / 8];
+    __shared__ __attribute__((aligned(16))) uint8_t nbr_lds[(kMaxPts / 2) * kMaxNbr];
+    __shared__ __attribute__((aligned(16))) uint8_t cnt_lds[kMaxPts / 2];
+    __shared__ __attribute__((aligned(16))) uint8_t sel_lds[kMaxPts / 2];
+    const int lane = threadIdx.x;
+    for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
+        const float* src = xyz + o * (int64_t)n_pts * 3;
+        for (int i = lane; i < n_pts * 3; i += 64) {
+            float v = src[i];
+            p0[i % 3][i / 3] = v;
+        }
+        __syncthreads();
+        float* pin[4][3] = {{p0[0], p0[1], p0[2]}, {p1[0], p1[1], p1[2]}, {p2[0], p2[1], p2[2]}, {p3[0], p3[1], p3[2]}};
+        const float rr[3] = {r0 * r0, r1 * r1, r2 * r2};
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            const int n_d = gt.n_dense[l], n_c = gt.n_cent[l];
+            // unused neighbour slots are zero-filled so that the table is deterministic
+            for (int i = lane; i < n_c * kMaxNbr / 4; i += 64) ((uint32_t*)nbr_lds)[i] = 0u;
+            __syncthreads();
+            level(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
+                  pin[l + 1][2], nbr_lds, cnt_lds);
+            uint8_t* g_nbr = gt.nbr[l] + o * (int64_t)n_c * kMaxNbr;
+            uint8_t* g_cnt = gt.cnt[l] + o * (int64_t)n_c;
+            uint8_t* g_sel = gt.fps_idx[l] + o * (int64_t)n_c;
+            for (int i = lane; i < n_c * kMaxNbr; i += 64) g_nbr[i] = nbr_lds[i];
+            for (int i = lane; i < n_c; i += 64) {
+                g_cnt[i] = cnt_lds[i];
+                g_sel[i] = sel_lds[i];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float radius[3], GroupTables gt,
+                        hipStream_t st) {
+    T2P_CHECK_ARG(n_pts >= 8 && n_pts <= kMaxPts, "sample_group: n_pts=%d outside [8,%d]", n_pts, kMaxPts);
+    if (n_obj == 0) return 0;
+    int64_t grid = n_obj < (int64_t)num_cus() * 64 ? n_obj : (int64_t)num_cus() * 64;
+    hipLaunchKernelGGL(k_sample_group, dim3((unsigned)grid), dim3(64), 0, st, xyz, n_obj, n_pts, radius[0],
+                       radius[1], radius[2], gt);
+    T2P_CHECK_LAUNCH("sample_group");
+    return 0;
+}
+
+}  // namespace t2p

@@ -1,0 +1,259 @@
+// Small HBM/latency-bound helper kernels of the cell branch: K<=6 layer-1 tables, row L2-normalisation,
+// per-cell pooling and the per-cell kNN graph.
+//
+// Reference call sites: F.normalize models/object_encoder.py:110-135, models/cell_retrieval.py:73,94,105;
+// gnn.global_max_pool / global_mean_pool models/cell_retrieval.py:98,102; knn inside gnn.DynamicEdgeConv
+// models/cell_retrieval.py:46-48,97.
+#include "t2p_common.h"
+
+namespace t2p {
+namespace {
+
+__global__ void k_sa1_point_table(const float* __restrict__ rgb, const float* __restrict__ xyz, int64_t n_rows,
+                                  const float* __restrict__ w, const float* __restrict__ bias, int H,
+                                  float* __restrict__ out) {
+    int64_t total = n_rows * H;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t row = e / H;
+        int h = (int)(e - row * H);
+        const float* c = rgb + row * 3;
+        const float* p = xyz + row * 3;
+        float acc = bias[h];
+        acc = fmaf(c[0], w[0 * H + h], acc);
+        acc = fmaf(c[1], w[1 * H + h], acc);
+        acc = fmaf(c[2], w[2 * H + h], acc);
+        acc = fmaf(p[0], w[3 * H + h], acc);
+        acc = fmaf(p[1], w[4 * H + h], acc);
+        acc = fmaf(p[2], w[5 * H + h], acc);
+        out[e] = acc;
+    }
+}
+
+__global__ void k_pos_table(const float* __restrict__ src, int ld_src, int col0, const uint8_t* __restrict__ idx,
+                            int64_t n_obj, int n_dense, int n_cent, const float* __restrict__ wp, int H,
+                            float* __restrict__ out) {
+    int64_t total = n_obj * n_cent * H;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t row = e / H;
+        int h = (int)(e - row * H);
+        int64_t o = row / n_cent;
+        int c = (int)(row - o * n_cent);
+        int loc = idx ? (int)idx[row] : c;
+        const float* p = src + (o * n_dense + loc) * (int64_t)ld_src + col0;
+        float acc = p[0] * wp[h];
+        acc = fmaf(p[1], wp[H + h], acc);
+        acc = fmaf(p[2], wp[2 * H + h], acc);
+        out[e] = acc;
+    }
+}
+
+// F.normalize(x, dim=-1): x / max(||x||_2, 1e-12); one wavefront per row.
+__global__ __launch_bounds__(256) void k_rownorm(const float* __restrict__ in, int ld_in, int64_t n_rows, int dim,
+                                                 float* __restrict__ out, int ld_out, int col0) {
+    const int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* x = in + row * ld_in;
+    float ss = 0.f;
+    for (int i = lane; i < dim; i += 64) ss = fmaf(x[i], x[i], ss);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    float nrm = sqrtf(ss);
+    float den = nrm > 1e-12f ? nrm : 1e-12f;
+    float* y = out + row * ld_out + col0;
+    for (int i = lane; i < dim; i += 64) y[i] = x[i] / den;
+}
+
+__global__ void k_segpool(const float* __restrict__ in, int dim, const int32_t* __restrict__ seg_ptr, int n_seg,
+                          float* __restrict__ out, int mean) {
+    int s = blockIdx.x;
+    int lo = seg_ptr[s], hi = seg_ptr[s + 1];
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        if (mean) {
+            float acc = 0.f;
+            for (int r = lo; r < hi; r++) acc += in[(int64_t)r * dim + c];
+            out[(int64_t)s * dim + c] = hi > lo ? acc / (float)(hi - lo) : 0.f;
+        } else {
+            float m = hi > lo ? -INFINITY : 0.f;
+            for (int r = lo; r < hi; r++) m = fmaxf(m, in[(int64_t)r * dim + c]);
+            out[(int64_t)s * dim + c] = m;
+        }
+    }
+}
+
+// kNN graph inside one segment (cell): all-pairs squared distances in LDS, then a k-pass ordered selection.
+// Distance pinned to the sequential fp32 form acc = acc + (a-b)*(a-b), no FMA (oracle/primitives.c).
+__global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int dim, const int32_t* __restrict__ seg_ptr,
+                                             int k, int32_t* __restrict__ out_idx) {
+#pragma clang fp contract(off)
+    extern __shared__ float dmat[];
+    int s = blockIdx.x;
+    int lo = seg_ptr[s], hi = seg_ptr[s + 1];
+    int n = hi - lo;
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        int i = e / n, j = e - i * n;
+        if (j < i) continue;  // symmetric: (a-b)^2 == (b-a)^2 exactly
+        const float* a = x + (int64_t)(lo + j) * dim;
+        const float* b = x + (int64_t)(lo + i) * dim;
+        float acc = 0.f;
+        for (int t = 0; t < dim; t++) {
+            float df = a[t] - b[t];
+            float sq = df * df;
+            acc = acc + sq;
+        }
+        dmat[i * n + j] = acc;
+        dmat[j * n + i] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float last_d = -1.f;
+        int last_j = -1;
+        for (int q = 0; q < k; q++) {
+            float bd = INFINITY;
+            int bj = -1;
+            for (int j = 0; j < n; j++) {
+                float d = dmat[i * n + j];
+                bool after = (d > last_d) || (d == last_d && j > last_j);
+                if (after && (bj < 0 || d < bd)) { bd = d; bj = j; }
+            }
+            out_idx[(int64_t)(lo + i) * k + q] = bj >= 0 ? lo + bj : -1;
+            if (bj >= 0) { last_d = bd; last_j = bj; }
+            else { last_d = INFINITY; last_j = 0x7fffffff; }
+        }
+    }
+}
+
+// colour / position encoders of ObjectEncoder (models/object_encoder.py:40-41,124-135): 3 -> 64 -> D, each layer
+// Linear+BN+ReLU, then F.normalize.  One wavefront per object: lane = hidden unit, then D/64 outputs per lane.
+__global__ __launch_bounds__(256) void k_mlp3_norm(const float* __restrict__ in3, int64_t n_rows,
+                                                   const float* __restrict__ w1, const float* __restrict__ b1,
+                                                   const float* __restrict__ w2, const float* __restrict__ b2, int D,
+                                                   float* __restrict__ out, int ld_out, int col0) {
+    __shared__ float hid[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    const bool ok = row < n_rows;
+    float hval = 0.f;
+    if (ok) {
+        const float* x = in3 + row * 3;
+        float a = b1[lane];
+        a = fmaf(x[0], w1[lane], a);
+        a = fmaf(x[1], w1[64 + lane], a);
+        a = fmaf(x[2], w1[128 + lane], a);
+        hval = fmaxf(a, 0.f);
+    }
+    hid[wv][lane] = hval;
+    __syncthreads();
+    if (!ok) return;
+    float o[8];
+    float ss = 0.f;
+    const int per = D / 64;
+    for (int j = 0; j < per; j++) {
+        const int c = j * 64 + lane;
+        float a = b2[c];
+        for (int k = 0; k < 64; k++) a = fmaf(hid[wv][k], w2[k * D + c], a);
+        a = fmaxf(a, 0.f);
+        o[j] = a;
+        ss = fmaf(a, a, ss);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float nrm = sqrtf(ss);
+    const float den = nrm > 1e-12f ? nrm : 1e-12f;
+    for (int j = 0; j < per; j++) out[row * ld_out + col0 + j * 64 + lane] = o[j] / den;
+}
+
+__global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, int32_t o_lo,
+                             int32_t* __restrict__ seg_ptr_local, int32_t* __restrict__ first) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= n_cells; c += gridDim.x * blockDim.x) {
+        const int32_t lo = cell_ptr[c] - o_lo;
+        seg_ptr_local[c] = lo;
+        if (c < n_cells) {
+            const int32_t hi = cell_ptr[c + 1] - o_lo;
+            for (int32_t o = lo; o < hi; o++) first[o] = lo;
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    int64_t cap = (int64_t)num_cus() * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+int launch_sa1_point_table(const float* rgb, const float* xyz, int64_t n_rows, const float* w, const float* bias,
+                           int H, float* out, hipStream_t st) {
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(k_sa1_point_table, dim3(grid_for(n_rows * H, 256)), dim3(256), 0, st, rgb, xyz, n_rows, w,
+                       bias, H, out);
+    T2P_CHECK_LAUNCH("sa1_point_table");
+    return 0;
+}
+
+int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx, int64_t n_obj, int n_dense,
+                     int n_cent, const float* wp, int H, float* out, hipStream_t st) {
+    if (n_obj == 0) return 0;
+    hipLaunchKernelGGL(k_pos_table, dim3(grid_for(n_obj * n_cent * H, 256)), dim3(256), 0, st, src, ld_src, col0, idx,
+                       n_obj, n_dense, n_cent, wp, H, out);
+    T2P_CHECK_LAUNCH("pos_table");
+    return 0;
+}
+
+int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* out, int ld_out, int col0,
+                   hipStream_t st) {
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(k_rownorm, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, in, ld_in, n_rows, dim, out,
+                       ld_out, col0);
+    T2P_CHECK_LAUNCH("rownorm");
+    return 0;
+}
+
+int launch_segmax(const float* in, int dim, const int32_t* seg_ptr, int n_seg, float* out, int mean, hipStream_t st) {
+    if (n_seg == 0) return 0;
+    hipLaunchKernelGGL(k_segpool, dim3(n_seg), dim3(256), 0, st, in, dim, seg_ptr, n_seg, out, mean);
+    T2P_CHECK_LAUNCH("segpool");
+    return 0;
+}
+
+int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const float* b1, const float* w2,
+                     const float* b2, int D, float* out, int ld_out, int col0, hipStream_t st) {
+    T2P_CHECK_ARG(D % 64 == 0 && D <= 512, "mlp3_norm: D=%d must be a multiple of 64, <= 512", D);
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(k_mlp3_norm, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, in3, n_rows, w1, b1, w2, b2, D,
+                       out, ld_out, col0);
+    T2P_CHECK_LAUNCH("mlp3_norm");
+    return 0;
+}
+
+int launch_cell_index(const int32_t* cell_ptr, int n_cells, int32_t o_lo, int32_t* seg_ptr_local, int32_t* first,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(k_cell_index, dim3((unsigned)((n_cells + 1 + 255) / 256)), dim3(256), 0, st, cell_ptr, n_cells,
+                       o_lo, seg_ptr_local, first);
+    T2P_CHECK_LAUNCH("cell_index");
+    return 0;
+}
+
+int launch_knn(const float* x, int dim, const int32_t* seg_ptr, int n_seg, int max_seg_rows, int k, int32_t* out_idx,
+               hipStream_t st) {
+    // all-pairs distance matrix of the largest segment lives in dynamic LDS (<= 192 rows -> 144 KiB)
+    if (n_seg == 0) return 0;
+    const int kMaxRows = 192;
+    T2P_CHECK_ARG(max_seg_rows >= 0 && max_seg_rows <= kMaxRows, "knn: a cell with %d objects exceeds the %d-row limit",
+                  max_seg_rows, kMaxRows);
+    size_t lds = (size_t)(max_seg_rows > 0 ? max_seg_rows : 1) * max_seg_rows * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_knn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(kMaxRows * kMaxRows * sizeof(float)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_knn, dim3(n_seg), dim3(256), lds, st, x, dim, seg_ptr, k, out_idx);
+    T2P_CHECK_LAUNCH("knn");
+    return 0;
+}
+
+}  // namespace t2p

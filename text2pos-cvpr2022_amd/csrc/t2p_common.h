@@ -1,0 +1,129 @@
+// Internal helpers shared by the gfx950 kernels of libt2p_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace t2p {
+
+void set_error(const char* fmt, ...);
+
+// All launch wrappers return 0 on success, a hipError_t (>0) on a HIP failure or a negative
+// T2P_E_* code on an argument error; the message is kept for t2p_last_error().
+#define T2P_E_ARG (-1)
+#define T2P_E_WORKSPACE (-2)
+#define T2P_E_UNSUPPORTED (-3)
+
+#define T2P_CHECK_ARG(cond, ...)                  \
+    do {                                          \
+        if (!(cond)) {                            \
+            ::t2p::set_error(__VA_ARGS__);        \
+            return T2P_E_ARG;                     \
+        }                                         \
+    } while (0)
+
+#define T2P_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            ::t2p::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                     \
+        }                                                                        \
+    } while (0)
+
+#define T2P_TRY(expr)             \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+int num_cus();  // cached multiProcessorCount of the current device
+
+// ---- sample_group.hip -------------------------------------------------------------------------------------
+// Compact per-object group tables produced by the fused FPS + ball-query kernel.
+// Level l (0..2): n_dense[l] dense points -> n_cent[l] = ceil(n_dense[l]/2) centroids; indices are LOCAL to the
+// object and refer to the level's dense ordering (level 0: input order; level l>0: FPS order of level l-1).
+struct GroupTables {
+    uint8_t* fps_idx[3];  // [n_obj, n_cent[l]]
+    uint8_t* nbr[3];      // [n_obj, n_cent[l], 32]
+    uint8_t* cnt[3];      // [n_obj, n_cent[l]]
+    int n_dense[3];
+    int n_cent[3];
+};
+int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float radius[3], GroupTables gt,
+                        hipStream_t st);
+
+// ---- tables.hip / small kernels ------------------------------------------------------------------------------
+// out[row, h] = bias[h] + sum_c rgb[row,c]*w[c][h] + xyz[row,c]*w[3+c][h]      (SA1 layer-1 point table, K = 6)
+int launch_sa1_point_table(const float* rgb, const float* xyz, int64_t n_rows, const float* w /*[6][H]*/,
+                           const float* bias, int H, float* out, hipStream_t st);
+// out[(o*n_cent + c), h] = sum_d pos(o, idx[o,c])[d] * wp[d][h] ; pos rows are read from `src` with leading
+// dimension ld_src at column offset col0 (row = o*n_dense + idx).  idx == nullptr -> identity (c).
+int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx, int64_t n_obj, int n_dense,
+                     int n_cent, const float* wp /*[3][H]*/, int H, float* out, hipStream_t st);
+// gather level-l centroid positions: out[(o*n_cent + c), 0..2]
+int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* out, int ld_out, int col0,
+                   hipStream_t st);
+int launch_segmax(const float* in, int dim, const int32_t* seg_ptr, int n_seg, float* out, int mean,
+                  hipStream_t st);
+int launch_knn(const float* x, int dim, const int32_t* seg_ptr, int n_seg, int max_seg_rows, int k,
+               int32_t* out_idx, hipStream_t st);
+// 3 -> 64 -> D MLP (BN folded, ReLU after both layers) + F.normalize, written into out[row*ld_out + col0 ...]
+int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const float* b1, const float* w2,
+                     const float* b2, int D, float* out, int ld_out, int col0, hipStream_t st);
+// chunk-local cell index arrays: seg_ptr_local[c] = cell_ptr[c] - o_lo (c = 0..n_cells), first[o] = start of o's cell
+int launch_cell_index(const int32_t* cell_ptr, int n_cells, int32_t o_lo, int32_t* seg_ptr_local, int32_t* first,
+                      hipStream_t st);
+
+// ---- tg_gemm.hip: generic tiled fp32-MFMA GEMM ------------------------------------------------------------
+// C[M, N] (ldc, column offset c0) = act(A[M, K] (lda) * W[K, N] (row-major, ldw = N) + bias[N])
+int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int c0, int64_t M,
+                int K, int N, int relu, hipStream_t st);
+
+// ---- ws_gemm.hip: weight-stationary streaming fp32-MFMA kernels ---------------------------------------------
+enum WsMode { WS_DENSE_STORE = 0, WS_DENSE_GROUPMAX = 1, WS_EDGE_SA = 2, WS_EDGE_KNN = 3 };
+struct WsParams {
+    // operand tables
+    const float* A;    // source rows [n_src, lda]   (dense: the GEMM's A; edge: layer-1 point table)
+    int lda;
+    const float* Bc;   // edge modes: per-destination term [n_dst, H]
+    const float* W;    // [K][ldw] k-major weights (BN folded)
+    int ldw;
+    const float* bias; // [N]
+    float* out;        // dense_store: [M, ldo]; groupmax: [n_groups, ldo]; edge: [n_dst, ldo]
+    int ldo;
+    int relu;
+    int64_t n_groups;  // dense: ceil(M / rows_per_group); edge SA: objects; edge kNN: ceil(n_dst/32)
+    int64_t M;         // dense: total rows
+    // edge SA
+    const uint8_t* nbr;     // [n_obj, n_cent, 32]
+    const uint8_t* cnt;     // [n_obj, n_cent]
+    const uint8_t* fps_idx; // [n_obj, n_cent]  (to append the centroid positions to the output rows)
+    const int32_t* obj_cell_first;  // [n_obj] index of the first object of the object's cell (self-loop aliasing)
+    const float* pos_src;   // rows holding the dense positions of this level
+    int ld_pos, pos_col0;
+    int n_dense, n_cent;
+    int self_loops;         // 1 = PyG PointConv(add_self_loops=True) index-aliased loops, 0 = none
+    // edge kNN
+    const int32_t* knn_idx; // [n_dst, knn_k] (-1 = absent)
+    int knn_k;
+    int64_t n_dst;
+};
+int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st);
+
+// ---- lstm.hip ---------------------------------------------------------------------------------------------
+int launch_bilstm_impl(const float* gate_table /*[2][V][4D]*/, const float* whh /*[2][D][4D] k-major*/,
+                       const int32_t* tokens /*[B, T]*/, const int32_t* lengths, int B, int T, int V, int D,
+                       float* hdir_ws /*[2][B][D]*/, float* out /*[B, D] mean of the two final hidden states*/,
+                       hipStream_t st);
+
+// ---- sim_topk.hip -----------------------------------------------------------------------------------------
+size_t sim_topk_workspace_bytes(int64_t nq, int64_t nc, int k);
+int launch_sim_topk(const float* Q, const float* C, int64_t nq, int64_t nc, int dim, int k, int64_t c_index_offset,
+                    int64_t* out_idx, double* out_score, void* ws, size_t ws_bytes, hipStream_t st);
+
+}  // namespace t2p

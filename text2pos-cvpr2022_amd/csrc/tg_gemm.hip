@@ -1,0 +1,115 @@
+// Generic LDS-tiled fp32-MFMA GEMM with fused bias / ReLU epilogue, for the small dense layers of the path:
+//   lin1, lin2                    models/pointcloud/pointnet2.py:89-90
+//   mlp_pointnet, color/pos MLPs, mlp_merge   models/object_encoder.py:98,124-138
+//   DynamicEdgeConv layer-1 tables (P, Q) and the cell `lin` MLP   models/cell_retrieval.py:46-49,97-99
+//   LSTM input projection of the vocabulary (gate table)            models/modules.py:77,89
+// C[M,N] = act(A[M,K] W[K,N] + bias).  128x128x16 tile, 4 waves x (2x2) v_mfma_f32_32x32x2_f32 tiles,
+// register-prefetched global loads (issue next chunk before the MFMAs of the current one).
+#include "t2p_common.h"
+
+namespace t2p {
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDA_S = BM + 2;  // As[k][m], +2 keeps the transposing ds_write_b32 conflict-free
+constexpr int LDB_S = BN + 4;  // Ws[k][n]
+
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                              const float* __restrict__ bias, float* __restrict__ C, int ldc, int c0,
+                                              int64_t M, int K, int N, int relu) {
+    __shared__ float As[BK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Ws[BK * LDB_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l31 = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // global -> register staging assignments
+    const int a_row = tid >> 1, a_k = (tid & 1) * 8;  // 8 consecutive k of one row
+    const int w_k = tid >> 4, w_n = (tid & 15) * 8;   // 8 consecutive n of one k
+    const bool a_row_ok = (m0 + a_row) < M;
+    const float* a_ptr = A + (m0 + a_row) * (int64_t)lda + a_k;
+    f32x4 ra[2], rw[2];
+
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int k = k0 + a_k + 4 * i;
+            ra[i] = (a_row_ok && k < K) ? *(const f32x4*)(a_ptr + k0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int kk = k0 + w_k, n = n0 + w_n + 4 * i;
+            rw[i] = (kk < K && n < N) ? *(const f32x4*)(W + (int64_t)kk * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) As[(a_k + 4 * i + e) * LDA_S + a_row] = ra[i][e];
+            *(f32x4*)(Ws + w_k * LDB_S + w_n + 4 * i) = rw[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    load_chunk(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        store_chunk();
+        __syncthreads();
+        if (k0 + BK < K) load_chunk(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = As[(kk + h) * LDA_S + wr * 64 + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; j++) b[j] = Ws[(kk + h) * LDB_S + wc * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int col = n0 + wc * 64 + j * 32 + l31;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int64_t row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < M) {
+                    float v = acc[i][j][e] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    C[row * (int64_t)ldc + c0 + col] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int c0, int64_t M,
+                int K, int N, int relu, hipStream_t st) {
+    T2P_CHECK_ARG(K % 4 == 0 && N % 8 == 0 && lda % 4 == 0, "gemm: K=%d must be a multiple of 4, N=%d of 8, lda=%d of 4",
+                  K, N, lda);
+    T2P_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: A and W must be 16-byte aligned");
+    if (M == 0) return 0;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, c0, M, K, N, relu);
+    T2P_CHECK_LAUNCH("gemm");
+    return 0;
+}
+
+}  // namespace t2p

@@ -1,0 +1,144 @@
+"""Host-side input types of the path (mirrors of the reference's data model) and their packing into the flat
+structure-of-arrays layout the kernels read.
+
+Reference: Object3d / Cell  datapreparation/kitti360pose/imports.py:8-41,221-247;
+batch_object_points  dataloading/kitti360pose/utils.py:89-110 (per object Data(x=rgb, pos=xyz) -> transform ->
+Batch.from_data_list); transforms T.FixedPoints / T.NormalizeScale used at training/coarse.py:189-199 and
+evaluation/pipeline.py:290-293.  torch_geometric is not required: any object with `.x`, `.pos`, `.batch` works.
+"""
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+COLORS = np.array([[47.2579917, 49.75368454, 42.4153065], [136.32696657, 136.95241796, 126.02741229],
+                   [87.49822126, 91.69058836, 80.14558512], [213.91030679, 216.25033052, 207.24611073],
+                   [110.39218852, 112.91977458, 103.68638249], [27.47505158, 28.43996795, 25.16840296],
+                   [66.65951839, 70.22342483, 60.20395996], [171.00852191, 170.05737735, 155.00130334]]) / 255.0
+COLOR_NAMES = ["dark-green", "gray", "gray-green", "bright-gray", "gray", "black", "green", "beige"]
+CLASS_NAMES = ["building", "pole", "traffic light", "traffic sign", "garage", "stop", "smallpole", "lamp", "trash bin",
+               "vending machine", "box", "road", "sidewalk", "parking", "wall", "fence", "guard rail", "bridge", "tunnel",
+               "vegetation", "terrain", "pad"]
+
+
+class Object3d:
+    def __init__(self, id: int, instance_id: int, xyz: np.ndarray, rgb: np.ndarray, label: str):
+        self.id, self.instance_id, self.xyz, self.rgb, self.label = id, instance_id, xyz, rgb, label
+
+    def get_color_rgb(self):
+        return np.mean(self.rgb, axis=0)
+
+    def get_center(self):
+        return np.mean(self.xyz, axis=0)
+
+    def get_color_text(self):
+        return COLOR_NAMES[int(np.argmin(np.linalg.norm(np.mean(self.rgb, axis=0) - COLORS, axis=1)))]
+
+    def __repr__(self):
+        return f"Object3d: {self.label}"
+
+
+class Cell:
+    def __init__(self, idx, scene_name, objects: List[Object3d], cell_size, bbox_w):
+        self.scene_name, self.objects, self.cell_size, self.bbox_w = scene_name, objects, cell_size, np.asarray(bbox_w)
+        self.id = f"{scene_name[-9:-5]}_{idx:05.0f}" if isinstance(idx, (int, float)) else str(idx)
+
+    def get_center(self):
+        return 0.5 * (self.bbox_w[0:3] + self.bbox_w[3:6])
+
+
+class Data:
+    def __init__(self, x=None, pos=None, batch=None):
+        self.x, self.pos, self.batch = x, pos, batch
+
+    @property
+    def num_nodes(self):
+        return self.pos.shape[0]
+
+    def to(self, device):
+        self.x, self.pos = self.x.to(device), self.pos.to(device)
+        if self.batch is not None:
+            self.batch = self.batch.to(device)
+        return self
+
+
+class Batch(Data):
+    @staticmethod
+    def from_data_list(data_list: Sequence[Data]):
+        sizes = [d.pos.shape[0] for d in data_list]
+        batch = torch.repeat_interleave(torch.arange(len(data_list)), torch.tensor(sizes))
+        return Batch(x=torch.cat([d.x for d in data_list]), pos=torch.cat([d.pos for d in data_list]), batch=batch)
+
+
+class FixedPoints:
+    """Resample to `num` points with replacement (the reference uses T.FixedPoints(num) with default replace=True)."""
+
+    def __init__(self, num, generator: np.random.Generator = None):
+        self.num = num
+        self.gen = generator if generator is not None else np.random.default_rng()
+
+    def __call__(self, data):
+        choice = torch.from_numpy(self.gen.choice(data.pos.shape[0], self.num, replace=True))
+        data.x, data.pos = data.x[choice], data.pos[choice]
+        return data
+
+
+class NormalizeScale:
+    def __call__(self, data):
+        data.pos = data.pos - data.pos.mean(dim=-2, keepdim=True)
+        data.pos = data.pos * ((1 / data.pos.abs().max()) * 0.999999)
+        return data
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, data):
+        for t in self.transforms:
+            data = t(data)
+        return data
+
+
+def batch_object_points(objects: List[Object3d], transform):
+    data_list = [transform(Data(x=torch.tensor(o.rgb, dtype=torch.float), pos=torch.tensor(o.xyz, dtype=torch.float)))
+                 for o in objects]
+    assert len(data_list) >= 1
+    return Batch.from_data_list(data_list)
+
+
+def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_color: bool = False):
+    """Flatten the (objects, object_points) pair of CellRetrievalNetwork.encode_objects into host arrays:
+    xyz, rgb [Nobj, n_pts, 3], center, mean_rgb [Nobj, 3] (fp32, pinned when CUDA is present), cell_ptr int32 [B+1]."""
+    if len(objects) != len(object_points):
+        raise RuntimeError(f"encode_objects: {len(objects)} object lists but {len(object_points)} point batches")
+    counts = [len(o) for o in objects]
+    cell_ptr = np.zeros(len(objects) + 1, dtype=np.int32)
+    cell_ptr[1:] = np.cumsum(counts)
+    n_obj = int(cell_ptr[-1])
+    pin = torch.cuda.is_available()
+    xyz = torch.empty((n_obj, n_pts, 3), dtype=torch.float32, pin_memory=pin)
+    rgb = torch.empty((n_obj, n_pts, 3), dtype=torch.float32, pin_memory=pin)
+    center = torch.empty((n_obj, 3), dtype=torch.float32, pin_memory=pin)
+    mean_rgb = torch.empty((n_obj, 3), dtype=torch.float32, pin_memory=pin)
+    for i, (objs, pts) in enumerate(zip(objects, object_points)):
+        lo, hi = int(cell_ptr[i]), int(cell_ptr[i + 1])
+        n = hi - lo
+        if n < 1:
+            raise RuntimeError(f"encode_objects: cell {i} has no objects")
+        if pts.pos.shape[0] != n * n_pts:
+            raise RuntimeError(f"encode_objects: cell {i} has {n} objects but {pts.pos.shape[0]} points; every object "
+                               f"must be resampled to {n_pts} points (T.FixedPoints({n_pts}))")
+        if pts.batch is not None:
+            expect = torch.arange(n).repeat_interleave(n_pts)
+            if not torch.equal(pts.batch.cpu().long(), expect):
+                raise RuntimeError(f"encode_objects: cell {i}: batch vector is not {n} contiguous groups of {n_pts}")
+        xyz[lo:hi] = pts.pos.detach().cpu().float().reshape(n, n_pts, 3)
+        if zero_color:
+            rgb[lo:hi] = 0.0
+        else:
+            rgb[lo:hi] = pts.x.detach().cpu().float().reshape(n, n_pts, 3)
+        # same conversion as the reference: torch.tensor(list of float64 means, dtype=torch.float)
+        center[lo:hi] = torch.tensor(np.stack([o.get_center() for o in objs]), dtype=torch.float)
+        mean_rgb[lo:hi] = torch.tensor(np.stack([o.get_color_rgb() for o in objs]), dtype=torch.float)
+    return xyz, rgb, center, mean_rgb, cell_ptr

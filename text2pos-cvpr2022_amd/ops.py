@@ -1,0 +1,243 @@
+"""Tensor-level wrappers over the C ABI (include/t2p.h): argument validation, workspace handling, stream plumbing.
+
+PyTorch is used for device memory, streams and torch.distributed only; all arithmetic happens in libt2p_hip.so.
+Shape / dtype / device / contiguity violations raise RuntimeError before anything is launched.
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_workspaces: Dict[tuple, torch.Tensor] = {}
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need(t: torch.Tensor, name: str, dtype, ndim=None, device=None):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: must live on the GPU (got device {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name}: expected {ndim} dimensions, got shape {tuple(t.shape)}")
+    if device is not None and t.device != device:
+        raise RuntimeError(f"{name}: on {t.device}, expected {device}")
+    return t
+
+
+def workspace(device, nbytes: int, tag: str) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, tag), obtained from torch's caching allocator."""
+    key = (str(device), tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _workspaces[key] = None
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def sample_group(xyz: torch.Tensor, radius=(0.2, 0.3, 0.4)):
+    """Fused FPS + ball query of the three SA levels.  xyz [n_obj, n_pts, 3] fp32.
+    Returns dict(fps_idx=[3 x uint8 [n_obj, n_c]], nbr=[3 x uint8 [n_obj, n_c, 32]], cnt=[3 x uint8 [n_obj, n_c]])."""
+    _need(xyz, "xyz", torch.float32, 3)
+    n_obj, n_pts, three = xyz.shape
+    if three != 3:
+        raise RuntimeError(f"xyz: last dimension must be 3, got {three}")
+    nd, out = n_pts, dict(fps_idx=[], nbr=[], cnt=[])
+    for _ in range(3):
+        nc = (nd + 1) // 2
+        out["fps_idx"].append(torch.empty((n_obj, nc), dtype=torch.uint8, device=xyz.device))
+        out["nbr"].append(torch.empty((n_obj, nc, 32), dtype=torch.uint8, device=xyz.device))
+        out["cnt"].append(torch.empty((n_obj, nc), dtype=torch.uint8, device=xyz.device))
+        nd = nc
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    r = (C.c_float * 3)(*[float(v) for v in radius])
+    L.check(L.lib().t2p_sample_group(_ptr(xyz), n_obj, n_pts, r, arr(out["fps_idx"]), arr(out["nbr"]), arr(out["cnt"]),
+                                     _stream(xyz.device)), "t2p_sample_group")
+    return out
+
+
+def knn(x: torch.Tensor, seg_ptr: torch.Tensor, k: int, max_seg_rows: Optional[int] = None) -> torch.Tensor:
+    _need(x, "x", torch.float32, 2)
+    _need(seg_ptr, "seg_ptr", torch.int32, 1, x.device)
+    if max_seg_rows is None:
+        sp = seg_ptr.cpu()
+        max_seg_rows = int((sp[1:] - sp[:-1]).max().item()) if sp.numel() > 1 else 0
+    out = torch.empty((x.shape[0], k), dtype=torch.int32, device=x.device)
+    L.check(L.lib().t2p_knn(_ptr(x), x.shape[1], _ptr(seg_ptr), seg_ptr.numel() - 1, int(max_seg_rows), k, _ptr(out),
+                            _stream(x.device)), "t2p_knn")
+    return out
+
+
+def gemm(a: torch.Tensor, w_kmajor: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False):
+    """act(a @ w_kmajor + bias);  a [M, K], w_kmajor [K, N]."""
+    _need(a, "a", torch.float32, 2)
+    _need(w_kmajor, "w", torch.float32, 2, a.device)
+    if bias is not None:
+        _need(bias, "bias", torch.float32, 1, a.device)
+    m, k = a.shape
+    if w_kmajor.shape[0] != k:
+        raise RuntimeError(f"gemm: a is [{m},{k}] but w is {tuple(w_kmajor.shape)}")
+    n = w_kmajor.shape[1]
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    L.check(L.lib().t2p_gemm(_ptr(a), k, _ptr(w_kmajor), _ptr(bias), _ptr(out), n, 0, m, k, n, int(relu),
+                             _stream(a.device)), "t2p_gemm")
+    return out
+
+
+def rownorm(x: torch.Tensor) -> torch.Tensor:
+    _need(x, "x", torch.float32, 2)
+    out = torch.empty_like(x)
+    L.check(L.lib().t2p_rownorm(_ptr(x), x.shape[0], x.shape[1], _ptr(out), _stream(x.device)), "t2p_rownorm")
+    return out
+
+
+def sim_topk(queries: torch.Tensor, cells: torch.Tensor, k: int, index_offset: int = 0):
+    """Float64 cosine scores + ordered top-k (ties -> lower index).  Returns (idx int64 [nq,k], score f64 [nq,k])."""
+    _need(queries, "queries", torch.float32, 2)
+    _need(cells, "cells", torch.float32, 2, queries.device)
+    nq, dim = queries.shape
+    nc = cells.shape[0]
+    if cells.shape[1] != dim:
+        raise RuntimeError(f"sim_topk: queries have dim {dim}, cells {cells.shape[1]}")
+    dev = queries.device
+    idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    score = torch.empty((nq, k), dtype=torch.float64, device=dev)
+    nbytes = L.lib().t2p_sim_topk_workspace_bytes(nq, nc, k)
+    ws = workspace(dev, nbytes, "sim_topk")
+    L.check(L.lib().t2p_sim_topk(_ptr(queries), _ptr(cells), nq, nc, dim, k, int(index_offset), _ptr(idx), _ptr(score),
+                                 _ptr(ws), ws.numel(), _stream(dev)), "t2p_sim_topk")
+    return idx, score
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features=("class", "color", "position"),
+                     self_loops=True, knn_k=8, variation=0, radius=(0.2, 0.3, 0.4), chunk_objects=0) -> L.CellConfig:
+    cfg = L.CellConfig()
+    cfg.n_pts, cfg.embed_dim, cfg.pointnet_features = int(n_pts), int(embed_dim), int(pointnet_features)
+    cfg.use_class = int("class" in use_features)
+    cfg.use_color = int("color" in use_features)
+    cfg.use_position = int("position" in use_features)
+    cfg.self_loops, cfg.knn_k, cfg.variation = int(bool(self_loops)), int(knn_k), int(variation)
+    cfg.radius = (C.c_float * 3)(*[float(r) for r in radius])
+    cfg.chunk_objects = int(chunk_objects)
+    return cfg
+
+
+def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
+    """packed: name -> tensor (or list of 3 tensors for the sa_* members), fp32 contiguous on the GPU."""
+    w = L.CellWeights()
+    for name in L.CellWeights._names[0]:
+        ts = packed[name]
+        for t in ts:
+            _need(t, name, torch.float32)
+        setattr(w, name, (C.c_void_p * 3)(*[t.data_ptr() for t in ts]))
+    for name in L.CellWeights._names[1]:
+        t = packed.get(name)
+        if t is not None:
+            _need(t, name, torch.float32)
+        setattr(w, name, 0 if t is None else t.data_ptr())
+    return w
+
+
+def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr_dev, weights: L.CellWeights,
+                 cfg: L.CellConfig, want_trace: bool = False):
+    """Cell branch on packed, device-resident inputs.  Returns out [n_cells, D] (and a dict of stage outputs)."""
+    _need(xyz, "xyz", torch.float32, 3)
+    dev = xyz.device
+    _need(rgb, "rgb", torch.float32, 3, dev)
+    _need(center, "center", torch.float32, 2, dev)
+    _need(mean_rgb, "mean_rgb", torch.float32, 2, dev)
+    _need(cell_ptr_dev, "cell_ptr", torch.int32, 1, dev)
+    n_obj, n_pts = xyz.shape[0], xyz.shape[1]
+    if tuple(rgb.shape) != tuple(xyz.shape) or xyz.shape[2] != 3:
+        raise RuntimeError(f"encode_cells: xyz {tuple(xyz.shape)} / rgb {tuple(rgb.shape)} must both be [n_obj, n_pts, 3]")
+    if tuple(center.shape) != (n_obj, 3) or tuple(mean_rgb.shape) != (n_obj, 3):
+        raise RuntimeError("encode_cells: center / mean_rgb must be [n_obj, 3]")
+    if n_pts != cfg.n_pts:
+        raise RuntimeError(f"encode_cells: objects have {n_pts} points, config says {cfg.n_pts}")
+    cp = np.ascontiguousarray(cell_ptr_host, dtype=np.int32)
+    n_cells = cp.shape[0] - 1
+    if cell_ptr_dev.numel() != n_cells + 1:
+        raise RuntimeError("encode_cells: host and device cell_ptr differ in length")
+    D = cfg.embed_dim
+    out = torch.empty((n_cells, D), dtype=torch.float32, device=dev)
+    trace, tr = None, None
+    if want_trace:
+        tr = L.CellTrace()
+        trace = dict(fps_idx=[], nbr=[], cnt=[], sa_out=[])
+        nd = n_pts
+        for l, c in enumerate((64, 128, 256)):
+            nc = (nd + 1) // 2
+            trace["fps_idx"].append(torch.empty((n_obj, nc), dtype=torch.uint8, device=dev))
+            trace["nbr"].append(torch.empty((n_obj, nc, 32), dtype=torch.uint8, device=dev))
+            trace["cnt"].append(torch.empty((n_obj, nc), dtype=torch.uint8, device=dev))
+            trace["sa_out"].append(torch.empty((n_obj * nc, c + 8), dtype=torch.float32, device=dev))
+            nd = nc
+        trace["features0"] = torch.empty((n_obj, 1024), dtype=torch.float32, device=dev)
+        trace["features2"] = torch.empty((n_obj, 256), dtype=torch.float32, device=dev)
+        trace["obj_emb"] = torch.empty((n_obj, D), dtype=torch.float32, device=dev)
+        trace["knn_idx"] = torch.empty((n_obj, cfg.knn_k), dtype=torch.int32, device=dev)
+        for name in ("fps_idx", "nbr", "cnt", "sa_out"):
+            setattr(tr, name, (C.c_void_p * 3)(*[t.data_ptr() for t in trace[name]]))
+        for name in ("features0", "features2", "obj_emb", "knn_idx"):
+            setattr(tr, name, trace[name].data_ptr())
+    nbytes = L.lib().t2p_encode_cells_workspace_bytes(n_obj, n_cells, C.byref(cfg))
+    # a single cell larger than the chunk forms its own (bigger) chunk: size for it
+    biggest = int((cp[1:] - cp[:-1]).max()) if n_cells > 0 else 0
+    chunk = cfg.chunk_objects if cfg.chunk_objects > 0 else 8192
+    if biggest > chunk:
+        big_cfg = L.CellConfig.from_buffer_copy(cfg)
+        big_cfg.chunk_objects = biggest
+        nbytes = max(nbytes, L.lib().t2p_encode_cells_workspace_bytes(n_obj, n_cells, C.byref(big_cfg)))
+    ws = workspace(dev, nbytes, "encode_cells")
+    rc = L.lib().t2p_encode_cells(_ptr(xyz), _ptr(rgb), _ptr(center), _ptr(mean_rgb),
+                                  cp.ctypes.data_as(C.c_void_p), _ptr(cell_ptr_dev), n_obj, n_cells, C.byref(weights),
+                                  C.byref(cfg), _ptr(out), C.byref(tr) if tr is not None else None, _ptr(ws),
+                                  ws.numel(), _stream(dev))
+    L.check(rc, "t2p_encode_cells")
+    return (out, trace) if want_trace else out
+
+
+def make_text_weights(embedding, w_ih, w_hh, bias) -> L.TextWeights:
+    w = L.TextWeights()
+    for n, t in (("embedding", embedding), ("w_ih", w_ih), ("w_hh", w_hh), ("bias", bias)):
+        _need(t, n, torch.float32)
+        setattr(w, n, t.data_ptr())
+    return w
+
+
+def encode_text(tokens: torch.Tensor, lengths: torch.Tensor, weights: L.TextWeights, vocab: int, embed_dim: int,
+                want_raw: bool = False):
+    """tokens [B, T] int32 right-padded with 0, lengths [B] int32 -> L2-normalised [B, D] (and the raw encoder output)."""
+    _need(tokens, "tokens", torch.int32, 2)
+    dev = tokens.device
+    _need(lengths, "lengths", torch.int32, 1, dev)
+    b, t = tokens.shape
+    if lengths.numel() != b:
+        raise RuntimeError("encode_text: lengths must have one entry per row of tokens")
+    out = torch.empty((b, embed_dim), dtype=torch.float32, device=dev)
+    raw = torch.empty((b, embed_dim), dtype=torch.float32, device=dev) if want_raw else None
+    nbytes = L.lib().t2p_encode_text_workspace_bytes(b, vocab, embed_dim)
+    ws = workspace(dev, nbytes, "encode_text")
+    L.check(L.lib().t2p_encode_text(_ptr(tokens), _ptr(lengths), b, t, vocab, embed_dim, C.byref(weights), _ptr(raw),
+                                    _ptr(out), _ptr(ws), ws.numel(), _stream(dev)), "t2p_encode_text")
+    return (out, raw) if want_raw else out

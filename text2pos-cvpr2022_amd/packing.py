@@ -1,0 +1,96 @@
+"""Host-side weight preparation for the HIP kernels: eval-mode BatchNorm folding, transposition to k-major
+([in][out]) and zero-padding of the K dimension, all in float64 before the single rounding to fp32.
+
+Parameter containers keep the reference's state_dict layout (models/modules.py:21-29: each MLP layer is
+Sequential(Linear, BatchNorm1d, ReLU) -> keys `<mlp>.<layer>.0.{weight,bias}` and
+`<mlp>.<layer>.1.{weight,bias,running_mean,running_var,num_batches_tracked}`).
+"""
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+
+def fold_linear_bn(layer: nn.Sequential) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(W [out,in], b [out]) in float64 of Linear followed by eval-mode BatchNorm1d (if present)."""
+    lin = layer[0]
+    w = lin.weight.detach().double()
+    b = lin.bias.detach().double() if lin.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64,
+                                                                               device=w.device)
+    if len(layer) > 1 and isinstance(layer[1], nn.BatchNorm1d):
+        bn = layer[1]
+        s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        w = w * s[:, None]
+        b = (b - bn.running_mean.detach().double()) * s + bn.bias.detach().double()
+    return w, b
+
+
+def kmajor(w: torch.Tensor, k_pad: int = None) -> torch.Tensor:
+    """[out,in] float64 -> contiguous fp32 [in (zero-padded to k_pad)][out]."""
+    wt = w.t().contiguous()
+    if k_pad is not None and k_pad > wt.shape[0]:
+        wt = torch.cat([wt, torch.zeros(k_pad - wt.shape[0], wt.shape[1], dtype=wt.dtype, device=wt.device)], 0)
+    return wt.float().contiguous()
+
+
+def f32(b: torch.Tensor) -> torch.Tensor:
+    return b.float().contiguous()
+
+
+def pack_cell_weights(model, device) -> Dict[str, object]:
+    """model: CellRetrievalNetwork (this package).  Returns name -> fp32 device tensor(s) for ops.make_cell_weights."""
+    oe, pn = model.object_encoder, model.object_encoder.pointnet
+    p: Dict[str, object] = {}
+    sa_w1, sa_b1, sa_w2, sa_b2 = [], [], [], []
+    for sa, kpad in ((pn.sa1, 6), (pn.sa2, 72), (pn.sa3, 136)):
+        nn_ = sa.point_conv.local_nn
+        w1, b1 = fold_linear_bn(nn_[0])
+        w2, b2 = fold_linear_bn(nn_[1])
+        sa_w1.append(kmajor(w1, kpad).to(device))
+        sa_b1.append(f32(b1).to(device))
+        sa_w2.append(kmajor(w2).to(device))
+        sa_b2.append(f32(b2).to(device))
+    p.update(sa_w1=sa_w1, sa_b1=sa_b1, sa_w2=sa_w2, sa_b2=sa_b2)
+    w1, b1 = fold_linear_bn(pn.ga.mlp[0])
+    w2, b2 = fold_linear_bn(pn.ga.mlp[1])
+    p.update(ga_w1=kmajor(w1, 264).to(device), ga_b1=f32(b1).to(device), ga_w2=kmajor(w2).to(device),
+             ga_b2=f32(b2).to(device))
+    for name, lin in (("lin1", pn.lin1), ("lin2", pn.lin2)):
+        p[name + "_w"] = kmajor(lin.weight.detach().double()).to(device)
+        p[name + "_b"] = f32(lin.bias.detach().double()).to(device)
+    w, b = fold_linear_bn(oe.mlp_pointnet[0])
+    p.update(pn_w=kmajor(w).to(device), pn_b=f32(b).to(device))
+    for pre, enc in (("col", oe.color_encoder), ("pos", oe.pos_encoder)):
+        w1, b1 = fold_linear_bn(enc[0])
+        w2, b2 = fold_linear_bn(enc[1])
+        p[pre + "_w1"], p[pre + "_b1"] = kmajor(w1).to(device), f32(b1).to(device)
+        p[pre + "_w2"], p[pre + "_b2"] = kmajor(w2).to(device), f32(b2).to(device)
+    w, b = fold_linear_bn(oe.mlp_merge[0])
+    p.update(merge_w=kmajor(w).to(device), merge_b=f32(b).to(device))
+    # DynamicEdgeConv nn on [x_i | x_j - x_i]:  W1a x_i + W1b (x_j - x_i) = (W1a - W1b) x_i + W1b x_j
+    d = model.embed_dim
+    w1, b1 = fold_linear_bn(model.graph1.nn[0])
+    w2, b2 = fold_linear_bn(model.graph1.nn[1])
+    p.update(g_wp=kmajor(w1[:, :d] - w1[:, d:]).to(device), g_bp=f32(b1).to(device), g_wq=kmajor(w1[:, d:]).to(device),
+             g_w2=kmajor(w2).to(device), g_b2=f32(b2).to(device))
+    w1, b1 = fold_linear_bn(model.lin[0])
+    w2, b2 = fold_linear_bn(model.lin[1])
+    p.update(lin_w1=kmajor(w1).to(device), lin_b1=f32(b1).to(device), lin_w2=kmajor(w2).to(device),
+             lin_b2=f32(b2).to(device))
+    return p
+
+
+def pack_text_weights(lang, device) -> Dict[str, torch.Tensor]:
+    """lang: LanguageEncoder (this package).  nn.LSTM parameter layout: weight_ih_l0 [4D, D] (gates i,f,g,o)."""
+    lstm = lang.lstm
+    w_ih = torch.stack([lstm.weight_ih_l0.detach().double().t(), lstm.weight_ih_l0_reverse.detach().double().t()])
+    w_hh = torch.stack([lstm.weight_hh_l0.detach().double().t(), lstm.weight_hh_l0_reverse.detach().double().t()])
+    bias = torch.stack([lstm.bias_ih_l0.detach().double() + lstm.bias_hh_l0.detach().double(),
+                        lstm.bias_ih_l0_reverse.detach().double() + lstm.bias_hh_l0_reverse.detach().double()])
+    return dict(embedding=f32(lang.word_embedding.weight.detach()).to(device), w_ih=f32(w_ih).to(device),
+                w_hh=f32(w_hh).to(device), bias=f32(bias).to(device))
+
+
+def params_version(module: nn.Module) -> Tuple:
+    """Cheap change detector for cached packs: (data_ptr, _version) of every parameter and buffer."""
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
