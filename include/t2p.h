@@ -164,6 +164,14 @@ int t2p_sim_topk(const float* queries, const float* cells, int64_t nq, int64_t n
                  t2p_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Opt-in kernel timing for bench.py: when enabled, every kernel launch of the calls above is bracketed by hipEvents
+ * recorded on the launch stream (the only process-global state of the library; not thread-safe, off by default).
+ * t2p_profile_report waits for the recorded launches and writes "<kernel> <launches> <total_ms>\n" lines into buf.
+ * ---------------------------------------------------------------------------------------------------------- */
+void t2p_profile_enable(int on);
+int t2p_profile_report(char* buf, size_t buf_bytes);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Stage-level exports (used by the stage-wise parity tests).
  * ---------------------------------------------------------------------------------------------------------- */
 /* Fused gnn.fps + gnn.radius of the three SA levels (pointnet2.py:26-30); outputs as in t2p_cell_trace.

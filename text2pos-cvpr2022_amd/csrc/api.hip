@@ -28,6 +28,30 @@ int num_cus() {
     return cached;
 }
 
+// ---- opt-in kernel timing ---------------------------------------------------------------------------------------
+struct ProfRec {
+    const char* name;
+    hipEvent_t a, b;
+};
+static bool g_prof_on = false;
+static ProfRec g_prof[8192];
+static int g_prof_n = 0;
+
+ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), st(s) {
+    if (!g_prof_on || g_prof_n >= 8192) return;
+    slot = g_prof_n++;
+    g_prof[slot].name = name;
+    if (hipEventCreate(&g_prof[slot].a) != hipSuccess || hipEventCreate(&g_prof[slot].b) != hipSuccess) {
+        slot = -1;
+        g_prof_n--;
+        return;
+    }
+    (void)hipEventRecord(g_prof[slot].a, st);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+}
+
 namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -313,6 +337,35 @@ using namespace t2p;
 extern "C" {
 
 int t2p_abi_version(void) { return T2P_ABI_VERSION; }
+
+void t2p_profile_enable(int on) { g_prof_on = on != 0; }
+
+// Waits for the recorded launches, writes one line per kernel name: "<name> <launches> <total_ms>\n", clears.
+int t2p_profile_report(char* buf, size_t n) {
+    size_t off = 0;
+    if (n > 0) buf[0] = 0;
+    for (int i = 0; i < g_prof_n; i++) {
+        if (g_prof[i].name == nullptr) continue;
+        int cnt = 0;
+        double tot = 0.0;
+        for (int j = i; j < g_prof_n; j++) {
+            if (g_prof[j].name == nullptr || strcmp(g_prof[j].name, g_prof[i].name) != 0) continue;
+            float ms = 0.f;
+            if (hipEventSynchronize(g_prof[j].b) == hipSuccess && hipEventElapsedTime(&ms, g_prof[j].a, g_prof[j].b) == hipSuccess) {
+                tot += ms;
+                cnt++;
+            }
+            (void)hipEventDestroy(g_prof[j].a);
+            (void)hipEventDestroy(g_prof[j].b);
+            if (j != i) g_prof[j].name = nullptr;
+        }
+        int w = snprintf(buf + off, off < n ? n - off : 0, "%s %d %.6f\n", g_prof[i].name, cnt, tot);
+        if (w > 0) off += (size_t)w;
+        g_prof[i].name = nullptr;
+    }
+    g_prof_n = 0;
+    return 0;
+}
 const char* t2p_last_error(void) { return g_err; }
 
 size_t t2p_encode_cells_workspace_bytes(int64_t n_obj, int64_t n_cells, const t2p_cell_config* cfg) {

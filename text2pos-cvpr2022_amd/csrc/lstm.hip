@@ -150,6 +150,8 @@ int launch_bilstm_impl(const float* gate_table, const float* whh, const int32_t*
                        int T, int V, int D, float* hdir_ws, float* out, hipStream_t st) {
     if (B == 0) return 0;
     dim3 grid((unsigned)((B + 31) / 32), 2);
+    {
+    ProfScope ps_("bilstm", st);
     if (D == 256) {
         hipLaunchKernelGGL(k_bilstm<256>, grid, dim3(256), 0, st, gate_table, whh, tokens, lengths, B, T, V, hdir_ws);
     } else if (D == 128) {
@@ -157,6 +159,7 @@ int launch_bilstm_impl(const float* gate_table, const float* whh, const int32_t*
     } else {
         set_error("bilstm: embed_dim=%d not instantiated (128, 256)", D);
         return T2P_E_UNSUPPORTED;
+    }
     }
     T2P_CHECK_LAUNCH("bilstm");
     const int64_t n = (int64_t)B * D;

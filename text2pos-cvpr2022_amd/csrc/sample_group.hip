@@ -149,6 +149,7 @@ int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float 
     T2P_CHECK_ARG(n_pts >= 8 && n_pts <= kMaxPts, "sample_group: n_pts=%d outside [8,%d]", n_pts, kMaxPts);
     if (n_obj == 0) return 0;
     int64_t grid = n_obj < (int64_t)num_cus() * 64 ? n_obj : (int64_t)num_cus() * 64;
+    ProfScope ps_("sample_group", st);
     hipLaunchKernelGGL(k_sample_group, dim3((unsigned)grid), dim3(64), 0, st, xyz, n_obj, n_pts, radius[0],
                        radius[1], radius[2], gt);
     T2P_CHECK_LAUNCH("sample_group");

@@ -213,11 +213,15 @@ int launch_sim_topk(const float* Q, const float* Cm, int64_t nq, int64_t nc, int
     int cps = (int)((nc + sp - 1) / sp);
     cps = ((cps + CB - 1) / CB) * CB;
     dim3 grid((unsigned)((nq + QB - 1) / QB), (unsigned)sp);
+    {
+    ProfScope ps_("sim_partial", st);
     if (dim == 256)
         hipLaunchKernelGGL(k_sim_partial<256>, grid, dim3(256), 0, st, Q, Cm, nq, nc, cps, ps, pi, sp);
     else
         hipLaunchKernelGGL(k_sim_partial<128>, grid, dim3(256), 0, st, Q, Cm, nq, nc, cps, ps, pi, sp);
+    }
     T2P_CHECK_LAUNCH("sim_partial");
+    ProfScope ps2_("topk_merge", st);
     hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, ps, pi, nq, sp * 4 * KCAP, k,
                        c_index_offset, out_idx, out_score);
     T2P_CHECK_LAUNCH("topk_merge");

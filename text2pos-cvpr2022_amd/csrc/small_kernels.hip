@@ -188,6 +188,7 @@ inline unsigned grid_for(int64_t total, int block) {
 int launch_sa1_point_table(const float* rgb, const float* xyz, int64_t n_rows, const float* w, const float* bias,
                            int H, float* out, hipStream_t st) {
     if (n_rows == 0) return 0;
+    ProfScope ps_("sa1_point_table", st);
     hipLaunchKernelGGL(k_sa1_point_table, dim3(grid_for(n_rows * H, 256)), dim3(256), 0, st, rgb, xyz, n_rows, w,
                        bias, H, out);
     T2P_CHECK_LAUNCH("sa1_point_table");
@@ -197,6 +198,7 @@ int launch_sa1_point_table(const float* rgb, const float* xyz, int64_t n_rows, c
 int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx, int64_t n_obj, int n_dense,
                      int n_cent, const float* wp, int H, float* out, hipStream_t st) {
     if (n_obj == 0) return 0;
+    ProfScope ps_("pos_table", st);
     hipLaunchKernelGGL(k_pos_table, dim3(grid_for(n_obj * n_cent * H, 256)), dim3(256), 0, st, src, ld_src, col0, idx,
                        n_obj, n_dense, n_cent, wp, H, out);
     T2P_CHECK_LAUNCH("pos_table");
@@ -206,6 +208,7 @@ int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx,
 int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* out, int ld_out, int col0,
                    hipStream_t st) {
     if (n_rows == 0) return 0;
+    ProfScope ps_("rownorm", st);
     hipLaunchKernelGGL(k_rownorm, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, in, ld_in, n_rows, dim, out,
                        ld_out, col0);
     T2P_CHECK_LAUNCH("rownorm");
@@ -214,6 +217,7 @@ int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* o
 
 int launch_segmax(const float* in, int dim, const int32_t* seg_ptr, int n_seg, float* out, int mean, hipStream_t st) {
     if (n_seg == 0) return 0;
+    ProfScope ps_("segpool", st);
     hipLaunchKernelGGL(k_segpool, dim3(n_seg), dim3(256), 0, st, in, dim, seg_ptr, n_seg, out, mean);
     T2P_CHECK_LAUNCH("segpool");
     return 0;
@@ -223,6 +227,7 @@ int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const fl
                      const float* b2, int D, float* out, int ld_out, int col0, hipStream_t st) {
     T2P_CHECK_ARG(D % 64 == 0 && D <= 512, "mlp3_norm: D=%d must be a multiple of 64, <= 512", D);
     if (n_rows == 0) return 0;
+    ProfScope ps_("mlp3_norm", st);
     hipLaunchKernelGGL(k_mlp3_norm, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, in3, n_rows, w1, b1, w2, b2, D,
                        out, ld_out, col0);
     T2P_CHECK_LAUNCH("mlp3_norm");
@@ -231,6 +236,7 @@ int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const fl
 
 int launch_cell_index(const int32_t* cell_ptr, int n_cells, int32_t o_lo, int32_t* seg_ptr_local, int32_t* first,
                       hipStream_t st) {
+    ProfScope ps_("cell_index", st);
     hipLaunchKernelGGL(k_cell_index, dim3((unsigned)((n_cells + 1 + 255) / 256)), dim3(256), 0, st, cell_ptr, n_cells,
                        o_lo, seg_ptr_local, first);
     T2P_CHECK_LAUNCH("cell_index");
@@ -251,6 +257,7 @@ int launch_knn(const float* x, int dim, const int32_t* seg_ptr, int n_seg, int m
                             (int)(kMaxRows * kMaxRows * sizeof(float)));
         attr_set = true;
     }
+    ProfScope ps_("knn", st);
     hipLaunchKernelGGL(k_knn, dim3(n_seg), dim3(256), lds, st, x, dim, seg_ptr, k, out_idx);
     T2P_CHECK_LAUNCH("knn");
     return 0;

@@ -43,6 +43,14 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 int num_cus();  // cached multiProcessorCount of the current device
 
+// Opt-in per-kernel timing (t2p_profile_enable): brackets a launch with hipEvents on the launch stream.
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t st);
+    ~ProfScope();
+    int slot;
+    hipStream_t st;
+};
+
 // ---- sample_group.hip -------------------------------------------------------------------------------------
 // Compact per-object group tables produced by the fused FPS + ball-query kernel.
 // Level l (0..2): n_dense[l] dense points -> n_cent[l] = ceil(n_dense[l]/2) centroids; indices are LOCAL to the

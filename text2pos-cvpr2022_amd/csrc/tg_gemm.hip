@@ -107,6 +107,7 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
     T2P_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: A and W must be 16-byte aligned");
     if (M == 0) return 0;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+    ProfScope ps_("tg_gemm", st);
     hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, c0, M, K, N, relu);
     T2P_CHECK_LAUNCH("gemm");
     return 0;

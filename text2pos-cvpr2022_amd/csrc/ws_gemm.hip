@@ -320,6 +320,10 @@ int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
     if (streams > p.n_groups) streams = p.n_groups;
     if (streams >= 8) streams -= streams % 8;  // keep the XCD-aware mapping valid
     const unsigned grid = (unsigned)(streams * n_slices);
+    static const char* kMode[] = {"dense", "groupmax", "edge_sa", "edge_knn"};
+    static char name[64];
+    if (name[0] == 0) snprintf(name, sizeof(name), "ws_%s_k%d_n%d", kMode[MODE], K, NW * n_slices);
+    ProfScope ps_(name, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::lds_bytes(), st, p, n_slices);
     T2P_CHECK_LAUNCH("ws_gemm");
     return 0;

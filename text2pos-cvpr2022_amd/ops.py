@@ -241,3 +241,20 @@ def encode_text(tokens: torch.Tensor, lengths: torch.Tensor, weights: L.TextWeig
     L.check(L.lib().t2p_encode_text(_ptr(tokens), _ptr(lengths), b, t, vocab, embed_dim, C.byref(weights), _ptr(raw),
                                     _ptr(out), _ptr(ws), ws.numel(), _stream(dev)), "t2p_encode_text")
     return (out, raw) if want_raw else out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def profile_enable(on: bool):
+    """Bracket every kernel launch with hipEvents on its launch stream (bench.py's live per-kernel timing)."""
+    L.lib().t2p_profile_enable(int(bool(on)))
+
+
+def profile_report() -> Dict[str, tuple]:
+    """{kernel name: (launches, total_ms)} of the launches recorded since the last report; waits for them."""
+    buf = C.create_string_buffer(1 << 16)
+    L.check(L.lib().t2p_profile_report(buf, len(buf)), "t2p_profile_report")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
