@@ -1,0 +1,230 @@
+"""CPU tests of the host logic and of the C-ABI library's loadability (no compute calls without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import text2pos_amd as t2p
+from text2pos_amd import _lib, data as D, distributed as TD, modules, ops, packing, synthetic as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "t2p.h")).read()
+    declared = set(re.findall(r"\b(t2p_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 14
+    handle = _lib.lib()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/t2p.h but not exported"
+    assert declared == set(_lib.SYMBOLS), "ctypes binding and header disagree"
+    assert handle.t2p_abi_version() == _lib.ABI_VERSION
+
+
+def test_workspace_size_queries_need_no_gpu():
+    cfg = ops.make_cell_config()
+    a = _lib.lib().t2p_encode_cells_workspace_bytes(100, 10, cfg)
+    b = _lib.lib().t2p_encode_cells_workspace_bytes(20000, 1000, cfg)
+    assert 0 < a < b < 16 << 30
+    assert _lib.lib().t2p_encode_text_workspace_bytes(64, 43, 256) > 2 * 43 * 1024 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libt2p_hip.so")
+    with pytest.raises(_lib.T2PError, match="build the HIP extension"):
+        _lib.lib()
+
+
+def test_no_cpu_path():
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.gemm(torch.zeros(4, 4), torch.zeros(4, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.sim_topk(torch.zeros(2, 256), torch.zeros(3, 256), 1)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "text2pos-cvpr2022_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "/root/reference" not in src, f
+
+
+# ---- tokeniser / text weights -----------------------------------------------------------------------------------
+def test_tokenizer_matches_reference_rules():
+    from oracle.model import tokenize as otok
+    words = S.known_words()
+    vocab = {w: i + 1 for i, w in enumerate(words)}
+    texts = ["The pose is north of a gray road.", "Pose, WEST. of a unknownword wall", "a"]
+    padded, lens = modules.tokenize(texts, vocab)
+    want = otok(texts, vocab)
+    assert lens.tolist() == [len(w) for w in want] == [8, 6, 1]
+    for i, w in enumerate(want):
+        assert padded[i, : len(w)].tolist() == w and (padded[i, len(w):] == 0).all()
+    assert padded[1, 4] == 0                                     # unknown word -> 0
+    with pytest.raises(RuntimeError):
+        modules.tokenize(["", "a"], vocab)
+
+
+def test_text_weight_packing_layout():
+    enc = t2p.LanguageEncoder(S.known_words(), 256, bi_dir=True)
+    p = packing.pack_text_weights(enc, "cpu")
+    assert p["w_ih"].shape == (2, 256, 1024) and p["w_hh"].shape == (2, 256, 1024) and p["bias"].shape == (2, 1024)
+    assert torch.equal(p["w_hh"][1], enc.lstm.weight_hh_l0_reverse.detach().t())
+    assert torch.allclose(p["bias"][0], (enc.lstm.bias_ih_l0 + enc.lstm.bias_hh_l0).detach())
+    assert p["embedding"].shape == (len(S.known_words()) + 1, 256) and (p["embedding"][0] == 0).all()
+
+
+# ---- BatchNorm folding / cell weight packing ------------------------------------------------------------------------
+def _model():
+    import weights as W
+    m = t2p.CellRetrievalNetwork(S.LABELS + ["pad"], S.COLOR_NAMES, S.known_words(), S.default_args()).eval()
+    W.fill_state_dict(m, 3)
+    return m
+
+
+def test_bn_fold_equals_eval_mode_block():
+    m = _model()
+    blk = m.object_encoder.pointnet.sa2.point_conv.local_nn[0]
+    w, b = packing.fold_linear_bn(blk)
+    x = torch.randn(50, 67)
+    with torch.no_grad():
+        want = blk(x)
+    got = torch.relu(x.double() @ w.t() + b).float()
+    assert torch.allclose(got, want, atol=1e-5)
+
+
+def test_cell_weight_pack_shapes_and_edge_split():
+    m = _model()
+    p = packing.pack_cell_weights(m, "cpu")
+    assert [tuple(t.shape) for t in p["sa_w1"]] == [(6, 32), (72, 128), (136, 256)]
+    assert [tuple(t.shape) for t in p["sa_w2"]] == [(32, 64), (128, 128), (256, 256)]
+    assert tuple(p["ga_w1"].shape) == (264, 512) and tuple(p["ga_w2"].shape) == (512, 1024)
+    assert (p["sa_w1"][1][67:] == 0).all() and (p["ga_w1"][259:] == 0).all()      # zero K padding
+    assert tuple(p["merge_w"].shape) == (768, 256) and tuple(p["lin1_w"].shape) == (1024, 512)
+    # layer 1 of an SA block on [x_j | pos_j - pos_i] == A_j - B_i with the packed tables
+    blk = m.object_encoder.pointnet.sa2.point_conv.local_nn[0]
+    xj, pj, pi = torch.randn(9, 64), torch.randn(9, 3), torch.randn(9, 3)
+    with torch.no_grad():
+        want = blk(torch.cat([xj, pj - pi], 1))
+    w1, b1 = p["sa_w1"][1], p["sa_b1"][1]
+    a = torch.cat([xj, pj, torch.zeros(9, 5)], 1) @ w1 + b1
+    bt = pi @ w1[64:67]
+    assert torch.allclose(torch.relu(a - bt), want, atol=1e-5)
+    # DynamicEdgeConv layer 1 on [x_i | x_j - x_i] == P_i + Q_j
+    g1 = m.graph1.nn[0]
+    xi, xj = torch.randn(7, 256), torch.randn(7, 256)
+    with torch.no_grad():
+        want = g1(torch.cat([xi, xj - xi], 1))
+    got = torch.relu(xi @ p["g_wp"] + p["g_bp"] + xj @ p["g_wq"])
+    assert torch.allclose(got, want, atol=1e-5)
+
+
+def test_state_dict_layout_matches_reference_keys(oracle_model):
+    m = _model()
+    sd = m.state_dict()
+    expect = {
+        "language_encoder.word_embedding.weight": (43, 256),
+        "language_encoder.lstm.weight_ih_l0": (1024, 256),
+        "language_encoder.lstm.weight_hh_l0_reverse": (1024, 256),
+        "language_encoder.lstm.bias_hh_l0": (1024,),
+        "object_encoder.pointnet.sa1.point_conv.local_nn.0.0.weight": (32, 6),
+        "object_encoder.pointnet.sa2.point_conv.local_nn.0.0.weight": (128, 67),
+        "object_encoder.pointnet.sa3.point_conv.local_nn.1.0.weight": (256, 256),
+        "object_encoder.pointnet.sa3.point_conv.local_nn.1.1.running_var": (256,),
+        "object_encoder.pointnet.ga.mlp.0.0.weight": (512, 259),
+        "object_encoder.pointnet.ga.mlp.1.0.weight": (1024, 512),
+        "object_encoder.pointnet.lin1.weight": (512, 1024),
+        "object_encoder.pointnet.lin2.weight": (256, 512),
+        "object_encoder.pointnet.class_classifier.weight": (22, 256),
+        "object_encoder.pointnet.color_classifier.weight": (8, 256),
+        "object_encoder.mlp_pointnet.0.0.weight": (256, 256),
+        "object_encoder.mlp_merge.0.0.weight": (256, 768),
+        "object_encoder.pos_encoder.0.0.weight": (64, 3),
+        "object_encoder.color_encoder.1.0.weight": (256, 64),
+        "object_encoder.class_embedding.weight": (23, 256),
+        "object_encoder.color_embedding.weight": (8, 256),
+        "graph1.nn.0.0.weight": (256, 512),
+        "graph1.nn.1.1.num_batches_tracked": (),
+        "lin.1.0.weight": (256, 256),
+    }
+    for k, shape in expect.items():
+        assert k in sd and tuple(sd[k].shape) == shape, k
+    assert set(sd) == set(oracle_model.state_dict())
+
+
+def test_forward_raises_like_the_reference_and_train_mode_is_refused():
+    m = _model()
+    with pytest.raises(Exception, match="Not implemented"):
+        m.forward()
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m.encode_text(["north"])
+
+
+# ---- input packing -------------------------------------------------------------------------------------------------
+def _cell(n, n_pts=256, seed=0):
+    xyz, rgb, center, mean_rgb, _ = S.make_cells(seed, n, fixed_n=1)
+    objs = [D.Object3d(i, i, np.tile(center[i].astype(np.float64), (3, 1)), np.tile(mean_rgb[i].astype(np.float64), (3, 1)),
+                       "box") for i in range(n)]
+    pts = D.Batch(x=torch.from_numpy(rgb.reshape(-1, 3)), pos=torch.from_numpy(xyz.reshape(-1, 3)),
+                  batch=torch.arange(n).repeat_interleave(n_pts))
+    return objs, pts, (xyz, rgb, center, mean_rgb)
+
+
+def test_pack_cells_roundtrip_and_validation():
+    o1, p1, raw1 = _cell(3, seed=1)
+    o2, p2, raw2 = _cell(2, seed=2)
+    xyz, rgb, center, mean_rgb, ptr = D.pack_cells([o1, o2], [p1, p2], 256)
+    assert ptr.tolist() == [0, 3, 5] and xyz.shape == (5, 256, 3)
+    assert np.array_equal(xyz[:3].numpy(), raw1[0]) and np.array_equal(rgb[3:].numpy(), raw2[1])
+    assert np.allclose(center[:3].numpy(), raw1[2]) and np.allclose(mean_rgb[3:].numpy(), raw2[3])
+    z = D.pack_cells([o1], [p1], 256, zero_color=True)
+    assert (z[1] == 0).all()
+    with pytest.raises(RuntimeError, match="resampled"):
+        D.pack_cells([o1[:2]], [p1], 256)
+    bad = D.Batch(x=p1.x, pos=p1.pos, batch=p1.batch.flip(0))
+    with pytest.raises(RuntimeError, match="contiguous groups"):
+        D.pack_cells([o1], [bad], 256)
+    with pytest.raises(RuntimeError):
+        D.pack_cells([o1, o2], [p1], 256)
+
+
+def test_batch_object_points_mirrors_reference_pipeline():
+    rng = np.random.default_rng(0)
+    objs = [D.Object3d(i, i, rng.random((40 + i, 3)) * 5, rng.random((40 + i, 3)), "box") for i in range(4)]
+    tf = D.Compose([D.FixedPoints(256, np.random.default_rng(1)), D.NormalizeScale()])
+    b = D.batch_object_points(objs, tf)
+    assert b.pos.shape == (4 * 256, 3) and b.x.shape == (4 * 256, 3) and b.batch.tolist() == sum([[i] * 256 for i in range(4)], [])
+    for i in range(4):
+        p = b.pos[i * 256:(i + 1) * 256]
+        assert abs(float(p.abs().max()) - 0.999999) < 1e-6 and float(p.mean(0).abs().max()) < 1e-6
+        assert len(np.unique(p.numpy(), axis=0)) <= 40 + i            # sampled with replacement
+
+
+# ---- synthetic generator / sharding ------------------------------------------------------------------------------------
+def test_synthetic_is_a_pure_function_of_seed_and_index():
+    full = S.make_cells(9, 10)
+    part = S.make_cells(9, 10, 4, 7)
+    lo, hi = full[4][4], full[4][7]
+    for a, b in zip(full[:4], part[:4]):
+        assert np.array_equal(a[lo:hi], b)
+    assert np.array_equal(part[4], full[4][4:8] - lo)
+    sizes = S.cell_sizes(9, 5000)
+    assert sizes.min() == 6 and sizes.max() == 26 and abs(sizes.mean() - 16) < 0.3
+    assert S.make_texts(9, 5, 6) == S.make_texts(9, 0, 8)[5:6]
+    assert all(48 <= len(t.replace(".", "").split()) <= 54 for t in S.make_texts(9, 0, 50))
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 12000, 100003):
+        for w in (1, 2, 3, 8):
+            r = [TD.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1

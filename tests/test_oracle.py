@@ -1,0 +1,155 @@
+"""CPU tests of the oracle itself: pinned against the golden fixtures produced by executing the reference
+(tests/golden/make_golden.py) and against hand-checkable known-answer cases for the restated PyG primitives."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from oracle import lib, model as OM, pyg_restated as gnn
+
+
+def _fp(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# ---- golden fixtures (reference execution) ------------------------------------------------------------------------
+def test_text_encoder_matches_reference_fixture(oracle_model, golden_dir):
+    z = np.load(os.path.join(golden_dir, "text_encoder.npz"))
+    for case in ("b1", "b7_ragged_unk", "b64"):
+        texts = [str(s) for s in z[f"{case}.texts"]]
+        with torch.no_grad():
+            raw = oracle_model.language_encoder(texts).numpy()
+        out = oracle_model.encode_text(texts).numpy()
+        assert np.abs(raw - z[f"{case}.raw"]).max() < 1e-6, case
+        assert np.abs(out - z[f"{case}.out"]).max() < 1e-6, case
+        assert np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-6)
+
+
+def test_cell_encoder_matches_reference_glue_fixture(oracle_model, golden_dir):
+    z = np.load(os.path.join(golden_dir, "cell_encoder.npz"))
+    tr = []
+    out = oracle_model.encode_objects_packed(z["xyz"], z["rgb"], z["center"], z["mean_rgb"], z["cell_ptr"], trace=tr)
+    f2 = torch.cat([d["features2"] for d in tr if "sa" in d]).numpy()
+    emb = [d for d in tr if "object_embeddings" in d][0]["object_embeddings"].numpy()
+    assert np.abs(f2 - z["features2"]).max() < 1e-5
+    assert np.abs(emb - z["obj_emb"]).max() < 1e-5
+    assert np.abs(out.numpy() - z["out"]).max() < 1e-5
+
+
+def test_retrieval_matches_reference_statements_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "retrieval.npz"))
+    idx, score = OM.retrieve_topk_f64(z["cells"], z["queries"], 10)
+    assert np.array_equal(idx, z["top10"])
+    assert (np.diff(score, axis=1) <= 0).all()
+    # the C restatement (sequential fma) agrees with NumPy's BLAS on indices and to 1e-13 on scores
+    c64, q64 = z["cells"].astype(np.float64), z["queries"].astype(np.float64)
+    ci = np.zeros((16, 10), np.int64)
+    cs = np.zeros((16, 10), np.float64)
+    lib().t2p_oracle_topk_f64(_fp(q64, C.c_double), _fp(c64, C.c_double), C.c_int64(16), C.c_int64(300), C.c_int32(256),
+                              C.c_int32(10), _fp(ci, C.c_int64), _fp(cs, C.c_double))
+    assert np.array_equal(ci, idx) and np.abs(cs - score).max() < 1e-13
+
+
+# ---- known-answer tests for the restated primitives (pure-Python loops as the independent check) ---------------------
+def _py_fps(p, m):
+    d2 = lambda a, b: float(np.float32(np.float32((a[0] - b[0]) * (a[0] - b[0])) + np.float32((a[1] - b[1]) * (a[1] - b[1])))
+                            + np.float32((a[2] - b[2]) * (a[2] - b[2])))
+    out, dist = [0], [d2(q, p[0]) for q in p]
+    for _ in range(1, m):
+        best = max(range(len(p)), key=lambda i: (dist[i], -i))
+        out.append(best)
+        dist = [min(dist[i], d2(p[i], p[best])) for i in range(len(p))]
+    return out
+
+
+def test_fps_collinear_known_answer():
+    p = np.zeros((8, 3), np.float32)
+    p[:, 0] = np.arange(8)
+    idx = gnn.fps(torch.from_numpy(p), None, 0.5).tolist()
+    assert idx == [0, 7, 3, 5] == _py_fps(p, 4)   # ties (3 vs 4, 5 vs 1/2/...) resolve to the lowest index
+
+
+def test_fps_random_vs_python_and_batching():
+    rng = np.random.default_rng(0)
+    p = rng.standard_normal((2, 37, 3)).astype(np.float32)
+    p[1, 5] = p[1, 4]                               # duplicate point
+    batch = torch.arange(2).repeat_interleave(37)
+    idx = gnn.fps(torch.from_numpy(p.reshape(-1, 3)), batch, 0.5)
+    assert idx.numel() == 2 * 19                    # ceil(0.5 * 37) per sub-graph
+    assert idx[:19].tolist() == _py_fps(p[0], 19)
+    assert (idx[19:] - 37).tolist() == _py_fps(p[1], 19)
+
+
+def test_radius_boundary_truncation_duplicates():
+    x = np.zeros((40, 3), np.float32)
+    x[1:, 0] = 0.1                                   # 39 duplicates at distance 0.1
+    x[39, 0] = np.float32(0.2)                       # exactly on the sphere r = 0.2 -> excluded (strict <)
+    y = np.zeros((1, 3), np.float32)
+    e = gnn.radius(torch.from_numpy(x), torch.from_numpy(y), 0.2)
+    assert e.shape == (2, 32)                        # capped at max_num_neighbors = 32
+    assert e[1].tolist() == list(range(32))          # first 32 in ascending index
+    e2 = gnn.radius(torch.from_numpy(x[32:]), torch.from_numpy(y), 0.2)
+    assert e2[1].tolist() == list(range(7))          # point 39 (d == r) is not a neighbour
+    # C restatement agrees
+    nbr = np.zeros((1, 1, 32), np.int32)
+    cnt = np.zeros((1, 1), np.int32)
+    cent = np.zeros((1, 1), np.int32)
+    lib().t2p_oracle_ball_query(_fp(x, C.c_float), _fp(cent, C.c_int32), C.c_int64(1), C.c_int32(40), C.c_int32(1),
+                                C.c_float(0.2), C.c_int32(32), _fp(nbr, C.c_int32), _fp(cnt, C.c_int32))
+    assert cnt[0, 0] == 32 and nbr[0, 0].tolist() == list(range(32))
+
+
+def test_radius_respects_batches():
+    x = torch.zeros(6, 3)
+    bx = torch.tensor([0, 0, 0, 1, 1, 1])
+    e = gnn.radius(x, x[[0, 3]], 0.5, bx, torch.tensor([0, 1]))
+    assert e.tolist() == [[0, 0, 0, 1, 1, 1], [0, 1, 2, 3, 4, 5]]
+
+
+def test_pointconv_self_loop_aliasing_is_index_based():
+    """PyG PointConv(add_self_loops=True) in the bipartite call: edge (j == i) removed, then (i, i) appended for
+    i < N_centroid -- centroid i is linked to DENSE point i, also across objects of the same cell batch."""
+    pos = torch.arange(8, dtype=torch.float32)[:, None].repeat(1, 3)          # 2 objects x 4 points
+    xfeat = torch.eye(8)[:, :3]
+    cent = pos[[0, 3, 4, 7]]                                                   # centroids 0,1 (obj 0), 2,3 (obj 1)
+    conv = gnn.PointConv(local_nn=None, add_self_loops=True)
+    edge = torch.tensor([[0, 3, 4, 7], [0, 1, 2, 3]])                          # each centroid <- its own source point
+    out = conv(xfeat, (pos, cent), edge)
+    # message = [x_j | pos_j - pos_i]; max over {own source point, dense point i}
+    for i, own in enumerate([0, 3, 4, 7]):
+        cand = torch.stack([torch.cat([xfeat[j], pos[j] - cent[i]]) for j in {own, i}])
+        assert torch.equal(out[i], cand.max(0).values)
+    plain = gnn.PointConv(local_nn=None, add_self_loops=False)(xfeat, (pos, cent), edge)
+    assert torch.equal(plain[3], torch.cat([xfeat[7], torch.zeros(3)]))
+
+
+def test_knn_ties_and_small_segments():
+    x = torch.zeros(5, 4)
+    x[3, 0] = 1.0
+    e = gnn.knn(x, x, 3, torch.tensor([0, 0, 0, 1, 1]), torch.tensor([0, 0, 0, 1, 1]))
+    rows = {i: e[1][e[0] == i].tolist() for i in range(5)}
+    assert rows[0] == [0, 1, 2] and rows[1] == [0, 1, 2]      # all-zero distances -> ascending index
+    assert rows[3] == [3, 4] and rows[4] == [4, 3]            # segment of 2 < k: self first, then the other
+
+
+def test_dynamic_edge_conv_matches_explicit_loop():
+    torch.manual_seed(0)
+    x = torch.nn.functional.normalize(torch.randn(11, 16), dim=-1)
+    batch = torch.tensor([0] * 4 + [1] * 7)
+    net = torch.nn.Linear(32, 8)
+    got = gnn.DynamicEdgeConv(net, k=3, aggr="max")(x, batch)
+    for i in range(11):
+        seg = [j for j in range(11) if batch[j] == batch[i]]
+        order = sorted(seg, key=lambda j: (float(((x[j] - x[i]) ** 2).sum()), j))[:3]
+        want = torch.stack([net(torch.cat([x[i], x[j] - x[i]])) for j in order]).max(0).values
+        assert torch.allclose(got[i], want, atol=1e-6)
+
+
+def test_oracle_model_unit_norm_and_determinism(oracle_model):
+    import text2pos_amd  # noqa: F401
+    from text2pos_amd import synthetic as S
+    xyz, rgb, c, m, ptr = S.make_cells(77, 2)
+    a = oracle_model.encode_objects_packed(xyz, rgb, c, m, ptr)
+    b = oracle_model.encode_objects_packed(xyz, rgb, c, m, ptr)
+    assert torch.equal(a, b) and torch.allclose(a.norm(dim=1), torch.ones(2), atol=1e-6)
