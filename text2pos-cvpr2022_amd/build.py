@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libt2p_hip.so")
-SOURCES = ["api.hip", "sample_group.hip", "small_kernels.hip", "tg_gemm.hip", "ws_gemm.hip", "lstm.hip", "sim_topk.hip"]
+SOURCES = ["api.hip", "sample_group.hip", "small_kernels.hip", "tg_gemm.hip", "ws_gemm.hip", "ws_sa.hip", "lstm.hip", "sim_topk.hip"]
 HEADERS = [os.path.join(CSRC, "t2p_common.h"), os.path.join(HERE, "..", "include", "t2p.h")]
 # -ffp-contract=off: the index-producing kernels (FPS, ball query, kNN) pin their fp32 distance arithmetic to the
 # oracle's un-contracted form; fused multiply-adds are written explicitly (fmaf / MFMA) where they are wanted.
@@ -32,6 +32,17 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """A/B build: same sources with extra -D flags into libt2p_hip_<name>.so (select it with T2P_LIB=<path>)."""
+    global OBJ, LIB
+    saved = (OBJ, LIB)
+    OBJ, LIB = os.path.join(CSRC, "_obj_" + name), os.path.join(HERE, f"libt2p_hip_{name}.so")
+    try:
+        return build_hip(force=False, verbose=verbose, extra_flags=tuple("-D" + d for d in defines))
+    finally:
+        OBJ, LIB = saved
 
 
 def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
@@ -62,4 +73,8 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> str
 
 
 if __name__ == "__main__":
-    print(build_hip(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:  # python build.py --variant NAME DEF1 DEF2 ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build_hip(force="--force" in sys.argv, verbose=True))

@@ -90,7 +90,7 @@ struct CellWs {
     GroupTables gt;
     float *A[3], *B[3], *F[3];
     float *gh, *f0, *f1, *f2, *cat, *emb, *embn, *P, *Q, *x1, *pool, *l1, *l2;
-    int32_t *knn, *seg_ptr, *first;
+    int32_t *knn, *seg_ptr, *first, *prefix, *bounds;
 };
 
 // Carve the per-chunk workspace (n objects, nb cells).  With base == nullptr this only measures.
@@ -105,6 +105,8 @@ size_t carve(Bump& b, int64_t n, int64_t nb, const t2p_cell_config& cfg, CellWs*
         w.gt.fps_idx[l] = b.take<uint8_t>(n * g.nc[l]);
         w.gt.nbr[l] = b.take<uint8_t>(n * g.nc[l] * 32);
         w.gt.cnt[l] = b.take<uint8_t>(n * g.nc[l]);
+        w.gt.rows[l] = b.take<uint16_t>(n * g.nc[l] * 33);
+        w.gt.n_rows[l] = b.take<uint16_t>(n);
         w.A[l] = b.take<float>(n * g.nd[l] * Geo::H[l]);
         w.B[l] = b.take<float>(n * g.nc[l] * Geo::H[l]);
         w.F[l] = b.take<float>(n * g.nc[l] * Geo::LD[l]);
@@ -121,6 +123,8 @@ size_t carve(Bump& b, int64_t n, int64_t nb, const t2p_cell_config& cfg, CellWs*
     w.x1 = b.take<float>(n * D);
     w.knn = b.take<int32_t>(n * (size_t)cfg.knn_k);
     w.first = b.take<int32_t>(n);
+    w.prefix = b.take<int32_t>(n + 1);
+    w.bounds = b.take<int32_t>(1024 + 1);
     w.seg_ptr = b.take<int32_t>(nb + 1);
     w.pool = b.take<float>(nb * D);
     w.l1 = b.take<float>(nb * D);
@@ -129,7 +133,7 @@ size_t carve(Bump& b, int64_t n, int64_t nb, const t2p_cell_config& cfg, CellWs*
     return align_up(b.off, 256);
 }
 
-int default_chunk(const t2p_cell_config& cfg) { return cfg.chunk_objects > 0 ? cfg.chunk_objects : 8192; }
+int default_chunk(const t2p_cell_config& cfg) { return cfg.chunk_objects > 0 ? cfg.chunk_objects : 32768; }
 
 int check_cfg(const t2p_cell_config* cfg) {
     T2P_CHECK_ARG(cfg != nullptr, "encode_cells: cfg is NULL");
@@ -170,6 +174,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     Geo g(cfg.n_pts);
     const int D = cfg.embed_dim;
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st));
+    ws.gt.self_loops = cfg.self_loops;
     T2P_TRY(launch_sample_group(xyz, n, cfg.n_pts, cfg.radius, ws.gt, st));
 
     // ---- three set-abstraction levels -----------------------------------------------------------------------
@@ -197,30 +202,28 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         }
         // centroid table B_i = W1p pos_i
         T2P_TRY(launch_pos_table(pos_src, ld_pos, pos_col0, ws.gt.fps_idx[l], n, g.nd[l], g.nc[l],
-                                 W.sa_w1[l] + (size_t)cf * H, H, ws.B[l], st));
-        // per-edge ReLU(A_j - B_i) -> layer 2 -> max over the group
-        WsParams p{};
+                                 W.sa_w1[l] + (size_t)cf * H, H, ws.B[l], ws.F[l], Geo::LD[l], C, st));
+        // per-edge ReLU(A_j - B_i) -> layer 2 -> max per centroid
+        SaParams p{};
         p.A = ws.A[l];
-        p.lda = H;
         p.Bc = ws.B[l];
         p.W = W.sa_w2[l];
-        p.ldw = C;
         p.bias = W.sa_b2[l];
         p.out = ws.F[l];
         p.ldo = Geo::LD[l];
-        p.relu = 1;
-        p.n_groups = n;
-        p.nbr = ws.gt.nbr[l];
-        p.cnt = ws.gt.cnt[l];
+        p.rows = ws.gt.rows[l];
+        p.n_rows = ws.gt.n_rows[l];
+        p.first = ws.first;
         p.fps_idx = ws.gt.fps_idx[l];
-        p.obj_cell_first = ws.first;
         p.pos_src = pos_src;
         p.ld_pos = ld_pos;
         p.pos_col0 = pos_col0;
         p.n_dense = g.nd[l];
         p.n_cent = g.nc[l];
-        p.self_loops = cfg.self_loops;
-        T2P_TRY(launch_ws(WS_EDGE_SA, H, C, p, st));
+        p.n_obj = n;
+        p.prefix_ws = ws.prefix;
+        p.bounds_ws = ws.bounds;
+        T2P_TRY(launch_ws_sa(H, C, p, st));
     }
     // ---- global abstraction: [x | pos] -> 512 -> 1024, max over the object's 32 points ------------------------
     {
@@ -474,10 +477,13 @@ int t2p_sample_group(const float* xyz, int64_t n_obj, int32_t n_pts, const float
     T2P_CHECK_ARG(xyz && radius_host && fps_idx && nbr && cnt, "sample_group: NULL argument");
     Geo g(n_pts);
     GroupTables gt;
+    gt.self_loops = 0;
     for (int l = 0; l < 3; l++) {
         gt.fps_idx[l] = fps_idx[l];
         gt.nbr[l] = nbr[l];
         gt.cnt[l] = cnt[l];
+        gt.rows[l] = nullptr;
+        gt.n_rows[l] = nullptr;
         gt.n_dense[l] = g.nd[l];
         gt.n_cent[l] = g.nc[l];
     }

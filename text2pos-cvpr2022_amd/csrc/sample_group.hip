@@ -45,7 +45,8 @@ __device__ __forceinline__ void wave_argmax(float& d, int& idx) {
 // One level: FPS of n_c samples among the n_d points in (px,py,pz) [LDS], then ball query.
 // sel (LDS, n_c bytes) receives the FPS indices; the sampled coordinates are written to (qx,qy,qz).
 __device__ void level(const float* px, const float* py, const float* pz, int n_d, int n_c, float r2,
-                      uint8_t* sel, float* qx, float* qy, float* qz, uint8_t* nbr_lds, uint8_t* cnt_lds) {
+                      uint8_t* sel, float* qx, float* qy, float* qz, uint8_t* nbr_lds, uint8_t* cnt_lds,
+                      uint16_t* rows_lds, int self_loops, int* n_rows_out) {
     const int lane = threadIdx.x;
     float x[4], y[4], z[4], mind[4];
 #pragma unroll
@@ -85,6 +86,9 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
     }
     __syncthreads();
     // ball query: centroids one after the other, the wave scans the dense points 64 at a time in ascending order
+    // The same hits are also emitted as the object's compact edge-row list (sorted by centroid), one u16 per row:
+    // low byte = source (dense index; for a self-loop row: the centroid index), high byte = centroid | 0x80 if self loop.
+    int base = 0;
     for (int c = 0; c < n_c; c++) {
         float cx = qx[c], cy = qy[c], cz = qz[c];
         int count = 0;
@@ -94,11 +98,20 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
             bool hit = (i < n_d) && (dist2(x[j], y[j], z[j], cx, cy, cz) < r2);
             unsigned long long m = __ballot(hit);
             int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-            if (hit && pos < kMaxNbr) nbr_lds[c * kMaxNbr + pos] = (uint8_t)i;
+            if (hit && pos < kMaxNbr) {
+                nbr_lds[c * kMaxNbr + pos] = (uint8_t)i;
+                rows_lds[base + pos] = (uint16_t)((c << 8) | i);
+            }
             count += __popcll(m);
         }
-        if (lane == 0) cnt_lds[c] = (uint8_t)(count < kMaxNbr ? count : kMaxNbr);
+        const int kept = count < kMaxNbr ? count : kMaxNbr;
+        if (lane == 0) {
+            cnt_lds[c] = (uint8_t)kept;
+            if (self_loops) rows_lds[base + kept] = (uint16_t)(((c | 0x80) << 8) | c);
+        }
+        base += kept + (self_loops ? 1 : 0);
     }
+    *n_rows_out = base;
     __syncthreads();
 }
 
@@ -111,6 +124,7 @@ __global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ x
     __shared__ __attribute__((aligned(16))) uint8_t nbr_lds[(kMaxPts / 2) * kMaxNbr];
     __shared__ __attribute__((aligned(16))) uint8_t cnt_lds[kMaxPts / 2];
     __shared__ __attribute__((aligned(16))) uint8_t sel_lds[kMaxPts / 2];
+    __shared__ __attribute__((aligned(16))) uint16_t rows_lds[(kMaxPts / 2) * (kMaxNbr + 1)];
     const int lane = threadIdx.x;
     for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
         const float* src = xyz + o * (int64_t)n_pts * 3;
@@ -127,8 +141,20 @@ __global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ x
             // unused neighbour slots are zero-filled so that the table is deterministic
             for (int i = lane; i < n_c * kMaxNbr / 4; i += 64) ((uint32_t*)nbr_lds)[i] = 0u;
             __syncthreads();
+            int n_rows = 0;
             level(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
-                  pin[l + 1][2], nbr_lds, cnt_lds);
+                  pin[l + 1][2], nbr_lds, cnt_lds, rows_lds, gt.self_loops, &n_rows);
+            if (gt.rows[l] != nullptr) {
+                const int maxr = n_c * (kMaxNbr + 1);
+                uint16_t* g_rows16 = gt.rows[l] + o * (int64_t)maxr;
+                if ((maxr & 1) == 0) {  // every object's list starts 4-byte aligned: copy two rows per store
+                    uint32_t* g_rows = (uint32_t*)g_rows16;
+                    for (int i = lane; i < (n_rows + 1) / 2; i += 64) g_rows[i] = ((const uint32_t*)rows_lds)[i];
+                } else {
+                    for (int i = lane; i < n_rows; i += 64) g_rows16[i] = rows_lds[i];
+                }
+                if (lane == 0) gt.n_rows[l][o] = (uint16_t)n_rows;
+            }
             uint8_t* g_nbr = gt.nbr[l] + o * (int64_t)n_c * kMaxNbr;
             uint8_t* g_cnt = gt.cnt[l] + o * (int64_t)n_c;
             uint8_t* g_sel = gt.fps_idx[l] + o * (int64_t)n_c;

@@ -31,7 +31,7 @@ __global__ void k_sa1_point_table(const float* __restrict__ rgb, const float* __
 
 __global__ void k_pos_table(const float* __restrict__ src, int ld_src, int col0, const uint8_t* __restrict__ idx,
                             int64_t n_obj, int n_dense, int n_cent, const float* __restrict__ wp, int H,
-                            float* __restrict__ out) {
+                            float* __restrict__ out, float* __restrict__ tail, int ld_tail, int tail_col0) {
     int64_t total = n_obj * n_cent * H;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t row = e / H;
@@ -44,6 +44,8 @@ __global__ void k_pos_table(const float* __restrict__ src, int ld_src, int col0,
         acc = fmaf(p[1], wp[H + h], acc);
         acc = fmaf(p[2], wp[2 * H + h], acc);
         out[e] = acc;
+        // the centroid's [xyz | 0 x 5] tail of the SA output row (the next layer's GEMM reads [features | xyz | pad])
+        if (tail != nullptr && h < 8) tail[row * ld_tail + tail_col0 + h] = h < 3 ? p[h] : 0.f;
     }
 }
 
@@ -196,11 +198,12 @@ int launch_sa1_point_table(const float* rgb, const float* xyz, int64_t n_rows, c
 }
 
 int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx, int64_t n_obj, int n_dense,
-                     int n_cent, const float* wp, int H, float* out, hipStream_t st) {
+                     int n_cent, const float* wp, int H, float* out, float* tail, int ld_tail, int tail_col0,
+                     hipStream_t st) {
     if (n_obj == 0) return 0;
     ProfScope ps_("pos_table", st);
     hipLaunchKernelGGL(k_pos_table, dim3(grid_for(n_obj * n_cent * H, 256)), dim3(256), 0, st, src, ld_src, col0, idx,
-                       n_obj, n_dense, n_cent, wp, H, out);
+                       n_obj, n_dense, n_cent, wp, H, out, tail, ld_tail, tail_col0);
     T2P_CHECK_LAUNCH("pos_table");
     return 0;
 }

@@ -59,6 +59,10 @@ struct GroupTables {
     uint8_t* fps_idx[3];  // [n_obj, n_cent[l]]
     uint8_t* nbr[3];      // [n_obj, n_cent[l], 32]
     uint8_t* cnt[3];      // [n_obj, n_cent[l]]
+    // compact edge-row lists consumed by the SA edge kernel (nullptr = not wanted):
+    uint16_t* rows[3];    // [n_obj, n_cent[l]*33]  (centroid | self-loop flag 0x80) << 8 | source index, sorted by centroid
+    uint16_t* n_rows[3];  // [n_obj] rows in the list (ball-query hits + one self loop per centroid when self_loops)
+    int self_loops;
     int n_dense[3];
     int n_cent[3];
 };
@@ -72,7 +76,8 @@ int launch_sa1_point_table(const float* rgb, const float* xyz, int64_t n_rows, c
 // out[(o*n_cent + c), h] = sum_d pos(o, idx[o,c])[d] * wp[d][h] ; pos rows are read from `src` with leading
 // dimension ld_src at column offset col0 (row = o*n_dense + idx).  idx == nullptr -> identity (c).
 int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx, int64_t n_obj, int n_dense,
-                     int n_cent, const float* wp /*[3][H]*/, int H, float* out, hipStream_t st);
+                     int n_cent, const float* wp /*[3][H]*/, int H, float* out, float* tail /*nullable*/, int ld_tail,
+                     int tail_col0, hipStream_t st);
 // gather level-l centroid positions: out[(o*n_cent + c), 0..2]
 int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* out, int ld_out, int col0,
                    hipStream_t st);
@@ -122,6 +127,28 @@ struct WsParams {
     int64_t n_dst;
 };
 int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st);
+
+// ---- ws_sa.hip: the set-abstraction edge kernel (flattened, fully pipelined batch stream) ----------------------------
+struct SaParams {
+    const float* A;   // layer-1 point table [n_obj*n_dense][H]
+    const float* Bc;  // centroid table [n_obj*n_cent][H]
+    const float* W;   // [H][C] k-major
+    const float* bias;
+    float* out;       // [n_obj*n_cent][ldo] rows = [features C | centroid xyz | 0 x 5]
+    int ldo;
+    const uint16_t* rows;    // GroupTables::rows[l]
+    const uint16_t* n_rows;  // GroupTables::n_rows[l]
+    const int32_t* first;    // [n_obj] first object of the object's cell (self-loop aliasing)
+    const uint8_t* fps_idx;  // [n_obj][n_cent]
+    const float* pos_src;    // rows holding the dense positions of this level
+    int ld_pos, pos_col0;
+    int n_dense, n_cent;
+    int64_t n_obj;
+    int32_t* prefix_ws;      // [n_obj+1] scratch (tile prefix sums)
+    int32_t* bounds_ws;      // [n_workgroups+1] scratch (balanced contiguous object ranges)
+    int ablate;              // debug only (T2P_ABLATE)
+};
+int launch_ws_sa(int H, int C, const SaParams& p, hipStream_t st);
 
 // ---- lstm.hip ---------------------------------------------------------------------------------------------
 int launch_bilstm_impl(const float* gate_table /*[2][V][4D]*/, const float* whh /*[2][D][4D] k-major*/,

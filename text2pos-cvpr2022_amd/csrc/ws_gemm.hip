@@ -17,8 +17,15 @@
 //   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  Lane half h = lane>>5 owns the contiguous K range
 //     [h*K/2, (h+1)*K/2), which turns the A-operand fetch into 16-byte LDS reads; the k summation order is
 //     therefore (0, K/2, 1, K/2+1, ...) -- fixed, deterministic.
+//   * Staging is software-pipelined over a double-buffered LDS tile: the global gathers of batch t+1 are issued
+//     before the MFMA block of batch t and land in registers behind it; the VALU part (+/- destination term, ReLU)
+//     and the ds_write follow the MFMA block; one barrier per batch.
 //   * Max-aggregation: all layer outputs are post-ReLU (>= 0), so the segmented max is an LDS integer atomic max
-//     on the float bit pattern, initialised to +0.
+//     on the float bit pattern, initialised to +0.  Rows are sorted by destination, so each lane first folds the
+//     runs of equal destination among its 16 accumulator rows in registers (typically 16 -> 2-3 atomics).
+#ifndef T2P_SCHED_BARRIER
+#define T2P_SCHED_BARRIER 0
+#endif
 #include "t2p_common.h"
 
 namespace t2p {
@@ -35,10 +42,13 @@ struct WsCfg {
     static constexpr int TR = WM * RT * 32;  // rows staged per barrier interval
     static constexpr int LDH = K + 4;        // padded hidden-row stride (floats)
     static constexpr bool EDGE = (MODE == WS_EDGE_SA || MODE == WS_EDGE_KNN);
-    static constexpr int HID_FLOATS = TR * LDH;
-    static constexpr int ACC_FLOATS = EDGE ? kAccFloats : (MODE == WS_DENSE_GROUPMAX ? NW : 0);
+    static constexpr int HID_FLOATS = TR * LDH;  // one of the two staging buffers
+    static constexpr int ACC_FLOATS = EDGE ? kAccFloats : 0;
+    static constexpr int F4_PER_ROW = K / 4;
+    static constexpr int TOTAL_F4 = TR * F4_PER_ROW;
+    static constexpr int ITERS = (TOTAL_F4 + 255) / 256;
     static constexpr size_t lds_bytes() {
-        size_t b = (size_t)(HID_FLOATS + ACC_FLOATS) * 4;
+        size_t b = (size_t)(2 * HID_FLOATS + ACC_FLOATS) * 4;
         if (EDGE) b += (size_t)kMaxRows * 4 + kMaxRows + 132 * 4;
         return b;
     }
@@ -50,9 +60,9 @@ template <int K, int NW, int WN, int RT, int MODE>
 __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
     using C = WsCfg<K, NW, WN, RT, MODE>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* hid = lds;
-    int* acc_lds = (int*)(lds + C::HID_FLOATS);
-    int* rows_src = (int*)(lds + C::HID_FLOATS + C::ACC_FLOATS);
+    float* hid = lds;  // two buffers of HID_FLOATS
+    int* acc_lds = (int*)(lds + 2 * C::HID_FLOATS);
+    int* rows_src = (int*)(lds + 2 * C::HID_FLOATS + C::ACC_FLOATS);
     uint8_t* rows_dst = (uint8_t*)(rows_src + kMaxRows);
     int* scan = (int*)(rows_dst + kMaxRows);
 
@@ -92,208 +102,297 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
 #pragma unroll
     for (int nt = 0; nt < C::NTW; nt++) bias[nt] = p.bias ? p.bias[ncol0 + nt * 32 + l31] : 0.f;
 
-    for (int64_t g = stream; g < p.n_groups; g += n_streams) {
-        int n_rows;
-        int64_t self_base = 0;
-        // ---- enumerate the group's rows -------------------------------------------------------------------
-        if constexpr (MODE == WS_EDGE_SA) {
-            const int nc = p.n_cent;
-            const int extra = p.self_loops ? 1 : 0;
-            int my = 0;
-            if (tid < nc) my = (int)p.cnt[g * nc + tid] + extra;
-            if (tid <= nc) scan[tid] = 0;
-            __syncthreads();
-            if (tid < nc) scan[tid + 1] = my;
-            __syncthreads();
-            if (wave == 0) {  // inclusive scan of <=128 counts by one wave, two entries per lane
-                int a0 = (2 * lane + 1 <= nc) ? scan[2 * lane + 1] : 0;
-                int a1 = (2 * lane + 2 <= nc) ? scan[2 * lane + 2] : 0;
-                int s = a0 + a1;
+    f32x4 sa[C::ITERS];                  // staged source rows (in flight behind the MFMA block)
+    f32x4 sb[C::EDGE ? C::ITERS : 1];    // staged destination terms (edge modes)
+
+    // Issue the global loads of one batch: rows [r0, r0+TR) of group g (n_rows valid rows in the group).
+    auto stage_load = [&](int64_t g, int r0, int n_rows) {
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    int t = __shfl_up(s, off, 64);
-                    if (lane >= off) s += t;
-                }
-                int excl = s - (a0 + a1);
-                if (2 * lane + 1 <= nc) scan[2 * lane + 1] = excl + a0;
-                if (2 * lane + 2 <= nc) scan[2 * lane + 2] = excl + a0 + a1;
-            }
-            __syncthreads();
-            n_rows = scan[nc];
-            if (p.self_loops) {
-                const int64_t first = p.obj_cell_first[g];
-                self_base = first * p.n_dense + (g - first) * (int64_t)nc;
-            }
-            if (tid < nc) {
-                int off = scan[tid];
-                const uint8_t* nb = p.nbr + (g * nc + tid) * 32;
-                const int c = my - extra;
-                for (int e = 0; e < c; e++) {
-                    rows_src[off + e] = (int)(g * p.n_dense + nb[e]);
-                    rows_dst[off + e] = (uint8_t)tid;
-                }
-                if (extra) {
-                    rows_src[off + c] = (int)(self_base + tid);
-                    rows_dst[off + c] = (uint8_t)tid;
+        for (int it = 0; it < C::ITERS; it++) {
+            const int q = it * 256 + tid;
+            const int lr = q / C::F4_PER_ROW, c4 = q % C::F4_PER_ROW;
+            const int r = r0 + lr;
+            sa[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (C::EDGE) sb[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (((C::TOTAL_F4 % 256) == 0 || q < C::TOTAL_F4) && r < n_rows) {
+                if constexpr (C::EDGE) {
+                    const int src = rows_src[r];
+                    const int dl = rows_dst[r];
+                    const int64_t dst = (MODE == WS_EDGE_SA) ? (g * p.n_cent + dl) : (g * 32 + dl);
+                    sa[it] = *(const f32x4*)(p.A + (int64_t)src * p.lda + c4 * 4);
+                    sb[it] = *(const f32x4*)(p.Bc + dst * K + c4 * 4);
+                } else if constexpr (MODE == WS_DENSE_GROUPMAX) {
+                    sa[it] = *(const f32x4*)(p.A + (g * 32 + r) * (int64_t)p.lda + c4 * 4);
+                } else {
+                    sa[it] = *(const f32x4*)(p.A + (g * C::TR + r) * (int64_t)p.lda + c4 * 4);
                 }
             }
-            for (int i = tid; i < kAccFloats; i += 256) acc_lds[i] = 0;
-        } else if constexpr (MODE == WS_EDGE_KNN) {
-            const int64_t d0 = g * 32;
-            const int nd = (int)((p.n_dst - d0) < 32 ? (p.n_dst - d0) : 32);
-            int my = 0;
-            if (tid < nd)
-                for (int e = 0; e < p.knn_k; e++) my += p.knn_idx[(d0 + tid) * p.knn_k + e] >= 0 ? 1 : 0;
-            if (tid <= 32) scan[tid] = 0;
-            __syncthreads();
-            if (tid < 32) scan[tid + 1] = my;
-            __syncthreads();
-            if (tid == 0) {
-                int s = 0;
-                for (int i = 1; i <= 32; i++) { s += scan[i]; scan[i] = s; }
-            }
-            __syncthreads();
-            n_rows = scan[32];
-            if (tid < nd) {
-                int off = scan[tid];
-                for (int e = 0; e < p.knn_k; e++) {
-                    int j = p.knn_idx[(d0 + tid) * p.knn_k + e];
-                    if (j >= 0) { rows_src[off] = j; rows_dst[off] = (uint8_t)tid; off++; }
-                }
-            }
-            for (int i = tid; i < kAccFloats; i += 256) acc_lds[i] = 0;
-        } else if constexpr (MODE == WS_DENSE_GROUPMAX) {
-            n_rows = 32;
-            for (int i = tid; i < NW; i += 256) acc_lds[i] = 0;
-        } else {
-            int64_t left = p.M - g * C::TR;
-            n_rows = (int)(left < C::TR ? left : C::TR);
         }
-        __syncthreads();
-
-        const int n_batches = (n_rows + C::TR - 1) / C::TR;
-        for (int bt = 0; bt < n_batches; bt++) {
-            const int r0 = bt * C::TR;
-            // ---- stage TR hidden rows into LDS (VALU: gather, +/- destination term, ReLU) ------------------
-            constexpr int F4_PER_ROW = K / 4;
-            constexpr int TOTAL_F4 = C::TR * F4_PER_ROW;
-            constexpr int ITERS = (TOTAL_F4 + 255) / 256;
+    };
+    // VALU part + LDS write of the staged batch.
+    auto stage_write = [&](int buf) {
+        float* dst = hid + buf * C::HID_FLOATS;
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) {
-                const int q = it * 256 + tid;
-                if ((TOTAL_F4 % 256) != 0 && q >= TOTAL_F4) break;
-                const int lr = q / F4_PER_ROW;  // local row in the staged batch
-                const int c4 = q % F4_PER_ROW;
-                const int r = r0 + lr;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (r < n_rows) {
-                    if constexpr (C::EDGE) {
-                        const int src = rows_src[r];
-                        const int dl = rows_dst[r];
-                        const int64_t dst = (MODE == WS_EDGE_SA) ? (g * p.n_cent + dl) : (g * 32 + dl);
-                        f32x4 a = *(const f32x4*)(p.A + (int64_t)src * p.lda + c4 * 4);
-                        f32x4 b = *(const f32x4*)(p.Bc + dst * K + c4 * 4);
-                        f32x4 t = (MODE == WS_EDGE_SA) ? (a - b) : (a + b);
+        for (int it = 0; it < C::ITERS; it++) {
+            const int q = it * 256 + tid;
+            if ((C::TOTAL_F4 % 256) != 0 && q >= C::TOTAL_F4) break;
+            const int lr = q / C::F4_PER_ROW, c4 = q % C::F4_PER_ROW;
+            f32x4 v = sa[it];
+            if constexpr (C::EDGE) {
+                const f32x4 t = (MODE == WS_EDGE_SA) ? (sa[it] - sb[it]) : (sa[it] + sb[it]);
 #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = fmaxf(t[e], 0.f);
-                    } else if constexpr (MODE == WS_DENSE_GROUPMAX) {
-                        v = *(const f32x4*)(p.A + (g * 32 + r) * (int64_t)p.lda + c4 * 4);
-                    } else {
-                        v = *(const f32x4*)(p.A + (g * C::TR + r) * (int64_t)p.lda + c4 * 4);
-                    }
-                }
-                *(f32x4*)(hid + lr * C::LDH + c4 * 4) = v;
+                for (int e = 0; e < 4; e++) v[e] = fmaxf(t[e], 0.f);
             }
-            __syncthreads();
-
-            // ---- MFMA: [RT x 32 rows] x [K] x [NTW x 32 cols] per wave ------------------------------------
-            f32x16 acc[RT][C::NTW];
+            *(f32x4*)(dst + lr * C::LDH + c4 * 4) = v;
+        }
+    };
+    // [RT x 32 rows] x [K] x [NTW x 32 cols] per wave.
+    auto mfma_block = [&](int buf, f32x16 (&acc)[RT][C::NTW]) {
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++)
+        for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                for (int nt = 0; nt < C::NTW; nt++)
+            for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
-                    for (int e = 0; e < 16; e++) acc[rt][nt][e] = 0.f;
-            const float* hrow = hid + ((wm * RT) * 32 + l31) * C::LDH + h * C::KS;
+                for (int e = 0; e < 16; e++) acc[rt][nt][e] = bias[nt];  // bias rides in the accumulator
+        const float* hrow = hid + buf * C::HID_FLOATS + ((wm * RT) * 32 + l31) * C::LDH + h * C::KS;
+        // A operands are fetched one chunk (QC k-quads) ahead of the MFMAs that consume them
+        constexpr int NQ = C::KS / 4;
+        constexpr int QC = (NQ % 4 == 0) ? 4 : ((NQ % 3 == 0) ? 3 : 1);
+        constexpr int NCH = NQ / QC;
+        f32x4 a_cur[RT][QC], a_nxt[RT][QC];
 #pragma unroll
-            for (int s4 = 0; s4 < C::KS / 4; s4++) {
-                f32x4 a[RT];
+        for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) a[rt] = *(const f32x4*)(hrow + rt * 32 * C::LDH + s4 * 4);
+            for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = *(const f32x4*)(hrow + rt * 32 * C::LDH + qi * 4);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            if (ch + 1 < NCH) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int qi = 0; qi < QC; qi++)
+                        a_nxt[rt][qi] = *(const f32x4*)(hrow + rt * 32 * C::LDH + ((ch + 1) * QC + qi) * 4);
+            }
+#if T2P_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this chunk's MFMAs
+#endif
+#pragma unroll
+            for (int qi = 0; qi < QC; qi++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                         for (int nt = 0; nt < C::NTW; nt++)
-                            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][j], w[nt][s4 * 4 + j],
-                                                                                acc[rt][nt], 0, 0, 0);
+                            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a_cur[rt][qi][j], w[nt][(ch * QC + qi) * 4 + j], acc[rt][nt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = a_nxt[rt][qi];
+        }
+    };
+    // Segmented max of one batch into the group's LDS accumulator (edge modes).
+    auto epilogue_edge = [&](int r0, int n_rows, f32x16 (&acc)[RT][C::NTW]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int trow0 = r0 + (wm * RT + rt) * 32;
+            if (trow0 >= n_rows) continue;
+            // destinations of this lane's 16 rows: quads of 4 consecutive rows at trow0 + 8*q + 4*h
+            int dq[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int r = trow0 + 8 * q + 4 * h + e;
+                    dq[q][e] = r < n_rows ? (int)rows_dst[r] : -1;
+                }
+            bool same[16], is_end[16];
+            int dd[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) dd[e] = dq[e >> 2][e & 3];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                same[e] = e > 0 && dd[e] == dd[e - 1];
+                is_end[e] = dd[e] >= 0 && (e == 15 || dd[e] != dd[e + 1]);
             }
+#pragma unroll
+            for (int nt = 0; nt < C::NTW; nt++) {
+                const int lcol = wn * C::NTW * 32 + nt * 32 + l31;
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    v[e] = acc[rt][nt][e];  // bias already inside; ReLU is implied by the signed-int max against +0
+                    if (e > 0) v[e] = same[e] ? fmaxf(v[e], v[e - 1]) : v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if (is_end[e]) atomicMax(&acc_lds[dd[e] * NW + lcol], __float_as_int(v[e]));
+            }
+        }
+    };
 
-            // ---- epilogue ------------------------------------------------------------------------------------
+    if constexpr (!C::EDGE) {
+        // ---- dense streams: every group is one batch; the pipeline runs across groups -----------------------------
+        int64_t g = stream;
+        auto rows_of = [&](int64_t gg) -> int {
+            if constexpr (MODE == WS_DENSE_GROUPMAX) return 32;
+            const int64_t left = p.M - gg * C::TR;
+            return (int)(left < C::TR ? left : C::TR);
+        };
+        if (g < p.n_groups) {
+            stage_load(g, 0, rows_of(g));
+            stage_write(0);
+        }
+        __syncthreads();
+        for (int i = 0; g < p.n_groups; g += n_streams, i++) {
+            const int64_t gn = g + n_streams;
+            const int n_rows = rows_of(g);
+            if (gn < p.n_groups) stage_load(gn, 0, rows_of(gn));
+            f32x16 acc[RT][C::NTW];
+            mfma_block(i & 1, acc);
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
-                const int trow0 = r0 + (wm * RT + rt) * 32;
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++) {
-                    const int lcol = wn * C::NTW * 32 + nt * 32 + l31;  // column inside the workgroup's slice
+                    const int lcol = wn * C::NTW * 32 + nt * 32 + l31;
                     if constexpr (MODE == WS_DENSE_STORE) {
+                        const int trow0 = (wm * RT + rt) * 32;
 #pragma unroll
                         for (int e = 0; e < 16; e++) {
                             const int r = trow0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            float v = acc[rt][nt][e] + bias[nt];
+                            float v = acc[rt][nt][e];
                             if (p.relu) v = fmaxf(v, 0.f);
                             if (r < n_rows) p.out[(g * C::TR + r) * (int64_t)p.ldo + slice * NW + lcol] = v;
                         }
-                    } else if constexpr (MODE == WS_DENSE_GROUPMAX) {
+                    } else {  // max over the 32 rows of the object: in registers, then across the two lane halves
                         float m = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 16; e++) m = fmaxf(m, acc[rt][nt][e] + bias[nt]);
+                        for (int e = 0; e < 16; e++) m = fmaxf(m, acc[rt][nt][e]);
                         m = fmaxf(m, __shfl_xor(m, 32, 64));
-                        if (h == 0) atomicMax(&acc_lds[lcol], __float_as_int(m));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 16; e++) {
-                            const int r = trow0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            if (r < n_rows) {
-                                float v = fmaxf(acc[rt][nt][e] + bias[nt], 0.f);
-                                atomicMax(&acc_lds[(int)rows_dst[r] * NW + lcol], __float_as_int(v));
-                            }
-                        }
+                        if (h == 0) p.out[g * (int64_t)p.ldo + slice * NW + lcol] = m;
                     }
+                }
+            }
+            if (gn < p.n_groups) stage_write((i + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        // ---- edge streams: a group = the destination rows of one object (SA) / 32 objects (kNN) -------------------
+        for (int64_t g = stream; g < p.n_groups; g += n_streams) {
+            int n_rows;
+            if constexpr (MODE == WS_EDGE_SA) {
+                const int nc = p.n_cent;
+                const int extra = p.self_loops ? 1 : 0;
+                int my = 0;
+                if (tid < nc) my = (int)p.cnt[g * nc + tid] + extra;
+                if (tid <= nc) scan[tid] = 0;
+                __syncthreads();
+                if (tid < nc) scan[tid + 1] = my;
+                __syncthreads();
+                if (wave == 0) {  // inclusive scan of <=128 counts by one wave, two entries per lane
+                    int a0 = (2 * lane + 1 <= nc) ? scan[2 * lane + 1] : 0;
+                    int a1 = (2 * lane + 2 <= nc) ? scan[2 * lane + 2] : 0;
+                    int s = a0 + a1;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        int t = __shfl_up(s, off, 64);
+                        if (lane >= off) s += t;
+                    }
+                    int excl = s - (a0 + a1);
+                    if (2 * lane + 1 <= nc) scan[2 * lane + 1] = excl + a0;
+                    if (2 * lane + 2 <= nc) scan[2 * lane + 2] = excl + a0 + a1;
+                }
+                __syncthreads();
+                n_rows = scan[nc];
+                int64_t self_base = 0;
+                if (p.self_loops) {
+                    const int64_t first = p.obj_cell_first[g];
+                    self_base = first * p.n_dense + (g - first) * (int64_t)nc;
+                }
+                if (tid < nc) {
+                    int off = scan[tid];
+                    const uint8_t* nb = p.nbr + (g * nc + tid) * 32;
+                    const int c = my - extra;
+                    for (int e = 0; e < c; e++) {
+                        rows_src[off + e] = (int)(g * p.n_dense + nb[e]);
+                        rows_dst[off + e] = (uint8_t)tid;
+                    }
+                    if (extra) {
+                        rows_src[off + c] = (int)(self_base + tid);
+                        rows_dst[off + c] = (uint8_t)tid;
+                    }
+                }
+            } else {
+                const int64_t d0 = g * 32;
+                const int nd = (int)((p.n_dst - d0) < 32 ? (p.n_dst - d0) : 32);
+                int my = 0;
+                if (tid < nd)
+                    for (int e = 0; e < p.knn_k; e++) my += p.knn_idx[(d0 + tid) * p.knn_k + e] >= 0 ? 1 : 0;
+                if (tid <= 32) scan[tid] = 0;
+                __syncthreads();
+                if (tid < 32) scan[tid + 1] = my;
+                __syncthreads();
+                if (tid == 0) {
+                    int s = 0;
+                    for (int i = 1; i <= 32; i++) { s += scan[i]; scan[i] = s; }
+                }
+                __syncthreads();
+                n_rows = scan[32];
+                if (tid < nd) {
+                    int off = scan[tid];
+                    for (int e = 0; e < p.knn_k; e++) {
+                        int j = p.knn_idx[(d0 + tid) * p.knn_k + e];
+                        if (j >= 0) { rows_src[off] = j; rows_dst[off] = (uint8_t)tid; off++; }
+                    }
+                }
+            }
+            for (int i = tid; i < kAccFloats; i += 256) acc_lds[i] = 0;
+            __syncthreads();
+
+            const int n_batches = (n_rows + C::TR - 1) / C::TR;
+            if (n_batches > 0) {
+                stage_load(g, 0, n_rows);
+                stage_write(0);
+            }
+            __syncthreads();
+            for (int bt = 0; bt < n_batches; bt++) {
+                const bool more = bt + 1 < n_batches;
+                if (more) stage_load(g, (bt + 1) * C::TR, n_rows);
+                f32x16 acc[RT][C::NTW];
+                mfma_block(bt & 1, acc);
+                epilogue_edge(bt * C::TR, n_rows, acc);
+                if (more) stage_write((bt + 1) & 1);
+                __syncthreads();
+            }
+
+            // ---- write the group's result -----------------------------------------------------------------------
+            if constexpr (MODE == WS_EDGE_SA) {
+                const int nc = p.n_cent;
+                for (int i = tid; i < nc * NW; i += 256) {
+                    const int c = i / NW, col = i % NW;
+                    p.out[(g * nc + c) * (int64_t)p.ldo + col] = __int_as_float(acc_lds[i]);
+                }
+                // append [pos_centroid, 0 x 5] so that the next layer's A rows are [features | pos | pad]
+                for (int i = tid; i < nc * 8; i += 256) {
+                    const int c = i >> 3, d = i & 7;
+                    float v = 0.f;
+                    if (d < 3) {
+                        const int loc = p.fps_idx[g * nc + c];
+                        v = p.pos_src[(g * p.n_dense + loc) * (int64_t)p.ld_pos + p.pos_col0 + d];
+                    }
+                    p.out[(g * nc + c) * (int64_t)p.ldo + NW + d] = v;
+                }
+            } else {
+                const int64_t d0 = g * 32;
+                const int nd = (int)((p.n_dst - d0) < 32 ? (p.n_dst - d0) : 32);
+                for (int i = tid; i < nd * NW; i += 256) {
+                    const int c = i / NW, col = i % NW;
+                    p.out[(d0 + c) * (int64_t)p.ldo + col] = __int_as_float(acc_lds[i]);
                 }
             }
             __syncthreads();
         }
-
-        // ---- write the group's result -------------------------------------------------------------------------
-        if constexpr (MODE == WS_EDGE_SA) {
-            const int nc = p.n_cent;
-            for (int i = tid; i < nc * NW; i += 256) {
-                const int c = i / NW, col = i % NW;
-                p.out[(g * nc + c) * (int64_t)p.ldo + col] = __int_as_float(acc_lds[i]);
-            }
-            // append [pos_centroid, 0 x 5] so that the next layer's A rows are [features | pos | pad]
-            for (int i = tid; i < nc * 8; i += 256) {
-                const int c = i >> 3, d = i & 7;
-                float v = 0.f;
-                if (d < 3) {
-                    const int loc = p.fps_idx[g * nc + c];
-                    v = p.pos_src[(g * p.n_dense + loc) * (int64_t)p.ld_pos + p.pos_col0 + d];
-                }
-                p.out[(g * nc + c) * (int64_t)p.ldo + NW + d] = v;
-            }
-        } else if constexpr (MODE == WS_EDGE_KNN) {
-            const int64_t d0 = g * 32;
-            const int nd = (int)((p.n_dst - d0) < 32 ? (p.n_dst - d0) : 32);
-            for (int i = tid; i < nd * NW; i += 256) {
-                const int c = i / NW, col = i % NW;
-                p.out[(d0 + c) * (int64_t)p.ldo + col] = __int_as_float(acc_lds[i]);
-            }
-        } else if constexpr (MODE == WS_DENSE_GROUPMAX) {
-            for (int i = tid; i < NW; i += 256) p.out[g * (int64_t)p.ldo + slice * NW + i] = __int_as_float(acc_lds[i]);
-        }
-        __syncthreads();
     }
 }
 

@@ -203,7 +203,7 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
     nbytes = L.lib().t2p_encode_cells_workspace_bytes(n_obj, n_cells, C.byref(cfg))
     # a single cell larger than the chunk forms its own (bigger) chunk: size for it
     biggest = int((cp[1:] - cp[:-1]).max()) if n_cells > 0 else 0
-    chunk = cfg.chunk_objects if cfg.chunk_objects > 0 else 8192
+    chunk = cfg.chunk_objects if cfg.chunk_objects > 0 else 32768
     if biggest > chunk:
         big_cfg = L.CellConfig.from_buffer_copy(cfg)
         big_cfg.chunk_objects = biggest
