@@ -89,6 +89,12 @@ typedef struct t2p_cell_weights {
     const float* lin_b1;
     const float* lin_w2;
     const float* lin_b2;
+    /* Optional "f16x3" split-precision images of the MFMA-heavy layer-2 weights (used when cfg->precision == 1):
+     * every weight is split w = hi + lo/2048 with hi, lo in fp16, stored in MFMA B-operand register order
+     * uint16 [2 planes hi,lo][N/32 column tiles][K/16 steps][2 lane halves][32 lanes][8]  holding
+     * w[k = half*K/2 + 8*step + e][n = 32*tile + lane]  (packing.py::pack_f16x3). */
+    const void* sa_w2_x3[3];
+    const void* ga_w2_x3;
 } t2p_cell_weights;
 
 typedef struct t2p_cell_config {
@@ -103,6 +109,8 @@ typedef struct t2p_cell_config {
     int32_t variation;         /* args.variation (cell_retrieval.py:45-54); only 0 (max aggregation) is built */
     float radius[3];           /* SA ball radii (pointnet2.py:57-59); 0.2, 0.3, 0.4 */
     int32_t chunk_objects;     /* objects processed per internal chunk (whole cells); 0 = default */
+    int32_t precision;         /* 0 = fp32 MFMA (exact fp32 fma chains); 1 = f16x3 split-precision MFMA with fp32
+                                  accumulation (hi.hi + hi.lo + lo.hi), same 1e-4 parity bar, 5.3x the MFMA rate */
 } t2p_cell_config;
 
 /* Optional stage outputs for parity tests (any member may be NULL).  Layouts:

@@ -21,14 +21,15 @@ class CellWeights(C.Structure):
     _names = (["sa_w1", "sa_b1", "sa_w2", "sa_b2"], ["ga_w1", "ga_b1", "ga_w2", "ga_b2", "lin1_w", "lin1_b", "lin2_w",
               "lin2_b", "pn_w", "pn_b", "col_w1", "col_b1", "col_w2", "col_b2", "pos_w1", "pos_b1", "pos_w2", "pos_b2",
               "merge_w", "merge_b", "g_wp", "g_bp", "g_wq", "g_w2", "g_b2", "lin_w1", "lin_b1", "lin_w2", "lin_b2"])
-    _fields_ = [(n, c_void * 3) for n in _names[0]] + [(n, c_void) for n in _names[1]]
+    _fields_ = ([(n, c_void * 3) for n in _names[0]] + [(n, c_void) for n in _names[1]] +
+                [("sa_w2_x3", c_void * 3), ("ga_w2_x3", c_void)])
 
 
 class CellConfig(C.Structure):
     _fields_ = [("n_pts", C.c_int32), ("embed_dim", C.c_int32), ("pointnet_features", C.c_int32),
                 ("use_class", C.c_int32), ("use_color", C.c_int32), ("use_position", C.c_int32),
                 ("self_loops", C.c_int32), ("knn_k", C.c_int32), ("variation", C.c_int32),
-                ("radius", C.c_float * 3), ("chunk_objects", C.c_int32)]
+                ("radius", C.c_float * 3), ("chunk_objects", C.c_int32), ("precision", C.c_int32)]
 
 
 class CellTrace(C.Structure):

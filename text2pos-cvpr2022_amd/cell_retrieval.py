@@ -28,7 +28,7 @@ class DynamicEdgeConv(nn.Module):
 
 class CellRetrievalNetwork(nn.Module):
     def __init__(self, known_classes: List[str], known_colors: List[str], known_words: List[str], args,
-                 add_self_loops: bool = True):
+                 add_self_loops: bool = True, precision: str = "f16x3"):
         """add_self_loops=True reproduces torch_geometric's PointConv default, which the reference relies on
         (models/pointcloud/pointnet2.py:23); False gives the plain ball-query neighbourhoods."""
         super().__init__()
@@ -37,6 +37,9 @@ class CellRetrievalNetwork(nn.Module):
         self.variation = args.variation
         self.args = args
         self.add_self_loops = add_self_loops
+        # "f16x3": the MFMA-heavy layer-2 GEMMs run as three fp16 MFMAs on hi/lo-split operands with fp32 accumulation
+        # (split error ~5e-7, below an fp32 fma chain's own rounding); "fp32": exact fp32 MFMA everywhere.
+        self.precision = precision
         d = self.embed_dim
         assert args.variation in (0, 1)
         self.graph1 = DynamicEdgeConv(get_mlp([2 * d, d, d], add_batchnorm=True), k=8,
@@ -68,7 +71,7 @@ class CellRetrievalNetwork(nn.Module):
         return ops.make_cell_config(n_pts=n_pts, embed_dim=self.embed_dim, pointnet_features=a.pointnet_features,
                                     use_features=tuple(a.use_features), self_loops=self.add_self_loops,
                                     knn_k=self.graph1.k, variation=self.variation, radius=radii,
-                                    chunk_objects=chunk_objects)
+                                    chunk_objects=chunk_objects, precision=self.precision)
 
     def _check_forward_only(self):
         if self.training:

@@ -153,6 +153,8 @@ int check_cfg(const t2p_cell_config* cfg) {
                   cfg->pointnet_features);
     T2P_CHECK_ARG(cfg->use_class || cfg->use_color || cfg->use_position, "encode_cells: use_features is empty");
     T2P_CHECK_ARG(cfg->knn_k >= 1 && cfg->knn_k <= 32, "encode_cells: knn_k=%d outside [1,32]", cfg->knn_k);
+    T2P_CHECK_ARG(cfg->precision == 0 || cfg->precision == 1, "encode_cells: precision=%d (0 = fp32, 1 = f16x3)",
+                  cfg->precision);
     return 0;
 }
 
@@ -208,6 +210,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.A = ws.A[l];
         p.Bc = ws.B[l];
         p.W = W.sa_w2[l];
+        p.W_x3 = cfg.precision == 1 ? W.sa_w2_x3[l] : nullptr;
         p.bias = W.sa_b2[l];
         p.out = ws.F[l];
         p.ldo = Geo::LD[l];
@@ -390,6 +393,9 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
     T2P_TRY(check_cfg(cfg));
     T2P_CHECK_ARG(w != nullptr && cell_ptr_host != nullptr && cell_ptr != nullptr && out != nullptr,
                   "encode_cells: NULL argument");
+    if (cfg->precision == 1)
+        T2P_CHECK_ARG(w->sa_w2_x3[0] && w->sa_w2_x3[1] && w->sa_w2_x3[2],
+                      "encode_cells: precision = f16x3 needs the packed sa_w2_x3 weight images");
     T2P_CHECK_ARG(n_cells >= 0 && n_obj >= 0, "encode_cells: negative size");
     if (n_cells == 0) return 0;
     T2P_CHECK_ARG(cell_ptr_host[0] == 0 && cell_ptr_host[n_cells] == n_obj,

@@ -132,7 +132,8 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st);
 struct SaParams {
     const float* A;   // layer-1 point table [n_obj*n_dense][H]
     const float* Bc;  // centroid table [n_obj*n_cent][H]
-    const float* W;   // [H][C] k-major
+    const float* W;   // [H][C] k-major (fp32 MFMA path)
+    const void* W_x3; // nullptr, or the host-packed f16x3 register image of W (selects the split-precision path)
     const float* bias;
     float* out;       // [n_obj*n_cent][ldo] rows = [features C | centroid xyz | 0 x 5]
     int ldo;
@@ -146,7 +147,6 @@ struct SaParams {
     int64_t n_obj;
     int32_t* prefix_ws;      // [n_obj+1] scratch (tile prefix sums)
     int32_t* bounds_ws;      // [n_workgroups+1] scratch (balanced contiguous object ranges)
-    int ablate;              // debug only (T2P_ABLATE)
 };
 int launch_ws_sa(int H, int C, const SaParams& p, hipStream_t st);
 

@@ -23,9 +23,6 @@
 //   * Max-aggregation: all layer outputs are post-ReLU (>= 0), so the segmented max is an LDS integer atomic max
 //     on the float bit pattern, initialised to +0.  Rows are sorted by destination, so each lane first folds the
 //     runs of equal destination among its 16 accumulator rows in registers (typically 16 -> 2-3 atomics).
-#ifndef T2P_SCHED_BARRIER
-#define T2P_SCHED_BARRIER 0
-#endif
 #include "t2p_common.h"
 
 namespace t2p {
@@ -173,9 +170,6 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
                     for (int qi = 0; qi < QC; qi++)
                         a_nxt[rt][qi] = *(const f32x4*)(hrow + rt * 32 * C::LDH + ((ch + 1) * QC + qi) * 4);
             }
-#if T2P_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this chunk's MFMAs
-#endif
 #pragma unroll
             for (int qi = 0; qi < QC; qi++)
 #pragma unroll

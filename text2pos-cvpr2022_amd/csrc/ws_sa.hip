@@ -12,24 +12,26 @@
 //     with double-buffered LDS staging tiles and one barrier per batch;
 //   * the per-object max accumulator is double-buffered in LDS too, so the finished object's [n_cent][C] block is
 //     written to HBM (and re-zeroed) underneath the MFMAs of the next object's first batch.
-#include <stdlib.h>
-#ifndef T2P_SCHED_BARRIER
-#define T2P_SCHED_BARRIER 0
-#endif
-#ifndef T2P_ANY_SKIP
-#define T2P_ANY_SKIP 0
-#endif
-
 #include "t2p_common.h"
 
 namespace t2p {
 namespace {
 
-constexpr int kSub = 512;  // objects whose row counts / self-loop bases are cached in LDS at a time
+constexpr int kSub = 512;
+constexpr int NT = 512;   // threads per workgroup: 8 waves = 2 per SIMD, so one wave's VALU/LDS phases overlap the other's MFMAs  // objects whose row counts / self-loop bases are cached in LDS at a time
 
-template <int K, int N, int WN, int RT>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+// X3 = 1: "f16x3" split-precision MFMA.  Both operands are split x = hi + lo/2048 with hi, lo in fp16 (hi = x rounded
+// toward zero, lo = (x - hi)*2048), and  h.w ~= hi.hi + (hi.lo' + lo'.hi)/2048  is accumulated in fp32 by three
+// v_mfma_f32_32x32x16_f16 per 16 k (the dropped lo.lo term is < 2^-20 relative).  The representation error of the
+// split (~5e-7 on unit-scale data, tests/test_host.py) is below the rounding error of an fp32 fma chain of this
+// length, at 16/3 = 5.3x the fp32-MFMA rate.
+template <int K, int N, int WN, int RT, int X3>
 struct SaCfg {
-    static constexpr int WM = 4 / WN;
+    static constexpr int WM = 8 / WN;
     static constexpr int NTW = N / (32 * WN);
     static constexpr int KS = K / 2;
     static constexpr int TR = WM * RT * 32;
@@ -38,10 +40,16 @@ struct SaCfg {
     static constexpr int ACC_INTS = 8192;  // n_cent * N for all three levels (128x64, 64x128, 32x256)
     static constexpr int F4_PER_ROW = K / 4;
     static constexpr int TOTAL_F4 = TR * F4_PER_ROW;
-    static constexpr int ITERS = TOTAL_F4 / 256;
-    static_assert(TOTAL_F4 % 256 == 0, "staging must divide evenly over 256 threads");
+    static constexpr int ITERS = TOTAL_F4 / NT;
+    static_assert(TOTAL_F4 % NT == 0, "staging must divide evenly over the workgroup");
+    // X3: two fp16 planes (hi, lo) per buffer, row stride K + 8 halves (16-byte pad keeps ds_read_b128 conflict-free)
+    static constexpr int LDHH = K + 8;
+    static constexpr int PLANE = TR * LDHH;   // halves per plane
+    static constexpr int S16 = K / 16;        // MFMA k-steps: lane half h owns k in [h*K/2, (h+1)*K/2), 8 per step
+    static_assert(!X3 || K % 32 == 0, "f16x3 needs K % 32 == 0");
     static constexpr size_t lds_bytes() {
-        return (size_t)(2 * HID_FLOATS + 2 * ACC_INTS) * 4 + 2 * TR + kSub * 2 + kSub * 4;
+        const size_t tile = X3 ? (size_t)2 * PLANE * 2 : (size_t)HID_FLOATS * 4;
+        return 2 * tile + (size_t)2 * ACC_INTS * 4 + 2 * TR + kSub * 2 + kSub * 4;
     }
 };
 
@@ -88,12 +96,14 @@ struct BatchIt {  // position in the flattened batch stream of a sub-range
     int n;        // rows of the object
 };
 
-template <int K, int N, int WN, int RT>
-__global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
-    using C = SaCfg<K, N, WN, RT>;
+template <int K, int N, int WN, int RT, int X3>
+__global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
+    using C = SaCfg<K, N, WN, RT, X3>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* hid = lds;                                       // [2][HID_FLOATS]
-    int* acc_lds = (int*)(lds + 2 * C::HID_FLOATS);         // [2][ACC_INTS]
+    float* hid = lds;                                       // fp32: [2][HID_FLOATS]
+    _Float16* hidh = (_Float16*)lds;                        // f16x3: [2][hi plane | lo plane]
+    constexpr int TILE_FLOATS = X3 ? C::PLANE : C::HID_FLOATS;   // 2 planes of halves == PLANE floats
+    int* acc_lds = (int*)(lds + 2 * TILE_FLOATS);           // [2][ACC_INTS]
     uint8_t* dstl = (uint8_t*)(acc_lds + 2 * C::ACC_INTS);  // [2][TR] destination (centroid) of every staged row
     uint16_t* nr = (uint16_t*)(dstl + 2 * C::TR);           // [kSub] rows per object
     int* sbase = (int*)(nr + kSub);                         // [kSub] source row of centroid 0's self loop
@@ -103,24 +113,40 @@ __global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
     const int nc = p.n_cent;
     const int maxr = nc * 33;
 
-    float w[C::NTW][C::KS];
+    float w[X3 ? 1 : C::NTW][X3 ? 1 : C::KS];
+    half8 w_hi[X3 ? C::NTW : 1][X3 ? C::S16 : 1], w_lo[X3 ? C::NTW : 1][X3 ? C::S16 : 1];
+    if constexpr (X3) {
+        // host-packed register image: [plane][n-tile][step][lane half][32 lanes][8 halves]  (packing.py::pack_f16x3)
+        const uint4* wp = (const uint4*)p.W_x3;
+        constexpr int PLANE_U4 = (N / 32) * C::S16 * 64;
 #pragma unroll
-    for (int nt = 0; nt < C::NTW; nt++)
+        for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
-        for (int s = 0; s < C::KS; s++)
-            w[nt][s] = p.W[(int64_t)(h * C::KS + s) * N + wn * C::NTW * 32 + nt * 32 + l31];
+            for (int s = 0; s < C::S16; s++) {
+                const int idx = (((wn * C::NTW + nt) * C::S16 + s) * 2 + h) * 32 + l31;
+                const uint4 a = wp[idx], b = wp[PLANE_U4 + idx];
+                w_hi[nt][s] = __builtin_bit_cast(half8, a);
+                w_lo[nt][s] = __builtin_bit_cast(half8, b);
+            }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < C::NTW; nt++)
+#pragma unroll
+            for (int s = 0; s < C::KS; s++)
+                w[nt][s] = p.W[(int64_t)(h * C::KS + s) * N + wn * C::NTW * 32 + nt * 32 + l31];
+    }
     float bias[C::NTW];
 #pragma unroll
     for (int nt = 0; nt < C::NTW; nt++) bias[nt] = p.bias[wn * C::NTW * 32 + nt * 32 + l31];
 
-    for (int i = tid; i < 2 * C::ACC_INTS; i += 256) acc_lds[i] = 0;
+    for (int i = tid; i < 2 * C::ACC_INTS; i += NT) acc_lds[i] = 0;
 
     const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
 
     for (int ga = g_begin; ga < g_end; ga += kSub) {
         const int cnt = (g_end - ga) < kSub ? (g_end - ga) : kSub;
         __syncthreads();
-        for (int i = tid; i < cnt; i += 256) {
+        for (int i = tid; i < cnt; i += NT) {
             const int g = ga + i;
             nr[i] = p.n_rows[g];
             const int first = p.first[g];
@@ -147,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
             const uint16_t* rows = p.rows + (int64_t)(ga + it.gi) * maxr;
 #pragma unroll
             for (int k = 0; k < C::ITERS; k++) {
-                const int lr = (k * 256 + tid) / C::F4_PER_ROW;
+                const int lr = (k * NT + tid) / C::F4_PER_ROW;
                 const int r = it.r0 + lr;
                 m[k] = (valid(it) && r < it.n) ? (uint32_t)rows[r] : 0xFFFFu;
             }
@@ -158,10 +184,10 @@ __global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
             const int sb0 = valid(it) ? sbase[it.gi] : 0;
 #pragma unroll
             for (int k = 0; k < C::ITERS; k++) {
-                const int c4 = (k * 256 + tid) % C::F4_PER_ROW;
+                const int c4 = (k * NT + tid) % C::F4_PER_ROW;
                 sa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
                 sb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m[k] != 0xFFFFu && !(p.ablate & 2)) {
+                if (m[k] != 0xFFFFu) {
                     const int src = m[k] & 0xFF, d = m[k] >> 8, dl = d & 127;
                     const int64_t srow = (d & 0x80) ? (int64_t)(sb0 + src) : (g * p.n_dense + src);
                     sa[k] = *(const f32x4*)(p.A + srow * K + c4 * 4);
@@ -172,15 +198,28 @@ __global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
         // W: h = relu(A_j - B_i) -> LDS tile, plus the destination byte of every row
         auto write_tile = [&](int buf, const uint32_t (&m)[C::ITERS]) {
             float* dst = hid + buf * C::HID_FLOATS;
+            _Float16* dsth = hidh + buf * 2 * C::PLANE;
 #pragma unroll
             for (int k = 0; k < C::ITERS; k++) {
-                const int q = k * 256 + tid;
+                const int q = k * NT + tid;
                 const int lr = q / C::F4_PER_ROW, c4 = q % C::F4_PER_ROW;
                 const f32x4 t = sa[k] - sb[k];
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(t[e], 0.f);
-                *(f32x4*)(dst + lr * C::LDH + c4 * 4) = v;
+                if constexpr (X3) {
+                    // hi = fp16(v) toward zero, lo = fp16((v - hi) * 2048): 4 values -> 8 bytes in each plane
+                    const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+                    const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.f, (v[1] - (float)h01[1]) * 2048.f);
+                    const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * 2048.f, (v[3] - (float)h23[1]) * 2048.f);
+                    uint2 ph, pl;
+                    ph.x = __builtin_bit_cast(uint32_t, h01); ph.y = __builtin_bit_cast(uint32_t, h23);
+                    pl.x = __builtin_bit_cast(uint32_t, l01); pl.y = __builtin_bit_cast(uint32_t, l23);
+                    *(uint2*)(dsth + lr * C::LDHH + c4 * 4) = ph;
+                    *(uint2*)(dsth + C::PLANE + lr * C::LDHH + c4 * 4) = pl;
+                } else {
+                    *(f32x4*)(dst + lr * C::LDH + c4 * 4) = v;
+                }
                 if (c4 == 0) dstl[buf * C::TR + lr] = m[k] == 0xFFFFu ? (uint8_t)0xFF : (uint8_t)((m[k] >> 8) & 127);
             }
         };
@@ -189,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
         auto flush = [&](int64_t g, int abuf) {
             int* a = acc_lds + abuf * C::ACC_INTS;
             float* o = p.out + g * nc * (int64_t)p.ldo;
-            for (int i = tid; i < nc * N; i += 256) {
+            for (int i = tid; i < nc * N; i += NT) {
                 const int c = i / N, col = i % N;
                 o[c * (int64_t)p.ldo + col] = __int_as_float(a[i]);
                 a[i] = 0;
@@ -213,59 +252,88 @@ __global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
         for (int t = 0; valid(it_c); t++) {
             // the object finished in the previous batch drains to HBM underneath this batch's MFMAs
             if (flush_g >= 0) {
-                if (!(p.ablate & 8)) flush(flush_g, flush_buf);
+                flush(flush_g, flush_buf);
                 flush_g = -1;
             }
             if (valid(it_d)) load_data(it_d, meta_d);      // D(t+1): gathers go out first ...
-            if (!(p.ablate & 32)) load_meta(it_m, meta_m);  // M(t+2): ... the younger metadata loads stay in flight
+            load_meta(it_m, meta_m);                       // M(t+2): ... the younger metadata loads stay in flight
 
             // C(t): MFMA block on tile t & 1
             f32x16 acc[RT][C::NTW];
+            f32x16 accx[X3 ? RT : 1][X3 ? C::NTW : 1];  // f16x3: cross terms (hi.lo' + lo'.hi), scaled by 2048
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
-                    for (int e = 0; e < 16; e++) acc[rt][nt][e] = bias[nt];  // bias rides in the accumulator
+                    for (int e = 0; e < 16; e++) {
+                        acc[rt][nt][e] = bias[nt];  // bias rides in the accumulator
+                        if constexpr (X3) accx[rt][nt][e] = 0.f;
+                    }
             const int buf = t & 1;
-            const float* hrow = hid + buf * C::HID_FLOATS + ((wm * RT) * 32 + l31) * C::LDH + h * C::KS;
-            constexpr int QC = 4;                 // k-quads (16 k-steps) fetched per LDS round
-            constexpr int NCH = C::KS / 4 / QC;   // chunks
-            static_assert((C::KS / 4) % QC == 0, "K/8 must be a multiple of the LDS prefetch chunk");
-            f32x4 a_cur[RT][QC], a_nxt[RT][QC];
+            if constexpr (X3) {
+                const _Float16* hrow = hidh + buf * 2 * C::PLANE + ((wm * RT) * 32 + l31) * C::LDHH + h * (K / 2);
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++)
+                for (int s = 0; s < C::S16; s++) {
+                    half8 a_hi[RT], a_lo[RT];
 #pragma unroll
-                for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = *(const f32x4*)(hrow + rt * 32 * C::LDH + qi * 4);
-            if (!(p.ablate & 4))
-#pragma unroll
-            for (int ch = 0; ch < NCH; ch++) {
-                if (ch + 1 < NCH) {
+                    for (int rt = 0; rt < RT; rt++) {
+                        a_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH + s * 8);
+                        a_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH + s * 8);
+                    }
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                        for (int qi = 0; qi < QC; qi++)
-                            a_nxt[rt][qi] = *(const f32x4*)(hrow + rt * 32 * C::LDH + ((ch + 1) * QC + qi) * 4);
+                        for (int nt = 0; nt < C::NTW; nt++) {
+                            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_hi[nt][s], acc[rt][nt], 0, 0, 0);
+                            accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_lo[nt][s], accx[rt][nt], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                        for (int nt = 0; nt < C::NTW; nt++)
+                            accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[rt], w_hi[nt][s], accx[rt][nt], 0, 0, 0);
                 }
-                // keep the next chunk's ds_read_b128s ABOVE this chunk's MFMAs (hipcc otherwise sinks each read to just
-                // before its first use and exposes the LDS latency once per 8 MFMAs)
-#if T2P_SCHED_BARRIER
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-                for (int qi = 0; qi < QC; qi++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-#pragma unroll
-                        for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                            for (int nt = 0; nt < C::NTW; nt++)
-                                acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                    a_cur[rt][qi][j], w[nt][(ch * QC + qi) * 4 + j], acc[rt][nt], 0, 0, 0);
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                    for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = a_nxt[rt][qi];
+                    for (int nt = 0; nt < C::NTW; nt++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) acc[rt][nt][e] = fmaf(accx[rt][nt][e], 1.f / 2048.f, acc[rt][nt][e]);
+            } else {
+                const float* hrow = hid + buf * C::HID_FLOATS + ((wm * RT) * 32 + l31) * C::LDH + h * C::KS;
+                constexpr int QC = 4;                 // k-quads (16 k-steps) fetched per LDS round
+                constexpr int NCH = C::KS / 4 / QC;   // chunks
+                static_assert(X3 || (C::KS / 4) % QC == 0, "K/8 must be a multiple of the LDS prefetch chunk");
+                f32x4 a_cur[RT][QC], a_nxt[RT][QC];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = *(const f32x4*)(hrow + rt * 32 * C::LDH + qi * 4);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) {
+                    if (ch + 1 < NCH) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                            for (int qi = 0; qi < QC; qi++)
+                                a_nxt[rt][qi] = *(const f32x4*)(hrow + rt * 32 * C::LDH + ((ch + 1) * QC + qi) * 4);
+                    }
+#pragma unroll
+                    for (int qi = 0; qi < QC; qi++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+#pragma unroll
+                            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                                for (int nt = 0; nt < C::NTW; nt++)
+                                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                        a_cur[rt][qi][j], w[nt][(ch * QC + qi) * 4 + j], acc[rt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                        for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = a_nxt[rt][qi];
+                }
             }
             // segmented max into the object's accumulator (runs of equal destination folded in registers first)
             const int abuf = it_c.gi & 1;
@@ -274,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 const int trow0 = (wm * RT + rt) * 32;
-                if (it_c.r0 + trow0 >= it_c.n || (p.ablate & 1)) continue;
+                if (it_c.r0 + trow0 >= it_c.n) continue;
                 int dq[16];
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
@@ -301,12 +369,7 @@ __global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
                     }
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
-#if T2P_ANY_SKIP
-                        if (__any(is_end[e]))  // wave-uniform skip: most slots are run interiors in both lane halves
-#endif
-                        {
-                            if (is_end[e]) atomicMax(col + dq[e] * N, __float_as_int(v[e]));
-                        }
+                        if (is_end[e]) atomicMax(col + dq[e] * N, __float_as_int(v[e]));
                     }
                 }
             }
@@ -314,22 +377,22 @@ __global__ __launch_bounds__(256, 1) void k_ws_sa(SaParams p) {
                 flush_g = ga + it_c.gi;
                 flush_buf = abuf;
             }
-            if (valid(it_d) && !(p.ablate & 16)) write_tile((t + 1) & 1, meta_d);  // W(t+1)
+            if (valid(it_d)) write_tile((t + 1) & 1, meta_d);  // W(t+1)
 #pragma unroll
             for (int k = 0; k < C::ITERS; k++) meta_d[k] = meta_m[k];
             it_c = it_d;
             it_d = it_m;
             it_m = advance(it_m);
-            if (!(p.ablate & 64)) __syncthreads();
+            __syncthreads();
         }
         if (flush_g >= 0) flush(flush_g, flush_buf);
     }
 }
 
-template <int K, int N, int WN, int RT>
+template <int K, int N, int WN, int RT, int X3>
 int launch_sa_cfg(const SaParams& p_in, hipStream_t st, const char* name) {
-    using C = SaCfg<K, N, WN, RT>;
-    auto kern = k_ws_sa<K, N, WN, RT>;
+    using C = SaCfg<K, N, WN, RT, X3>;
+    auto kern = k_ws_sa<K, N, WN, RT, X3>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -344,11 +407,7 @@ int launch_sa_cfg(const SaParams& p_in, hipStream_t st, const char* name) {
     T2P_CHECK_ARG(p_in.n_obj < (1 << 30) && p_in.n_obj * p_in.n_dense < 0x7fffffffLL, "ws_sa: chunk too large for 32-bit rows");
     int n_wg = num_cus();
     if (n_wg > p_in.n_obj) n_wg = (int)p_in.n_obj;
-    SaParams p = p_in;
-    {
-        const char* ab = getenv("T2P_ABLATE");  // debug: 1 = no epilogue, 2 = no gathers, 4 = no MFMA
-        p.ablate = ab ? atoi(ab) : 0;
-    }
+    const SaParams& p = p_in;
     {
         ProfScope ps_("sa_balance", st);
         hipLaunchKernelGGL(k_balance, dim3(1), dim3(1024), 0, st, p.n_rows, (int)p.n_obj, C::TR, n_wg, p.prefix_ws,
@@ -356,7 +415,7 @@ int launch_sa_cfg(const SaParams& p_in, hipStream_t st, const char* name) {
     }
     T2P_CHECK_LAUNCH("sa_balance");
     ProfScope ps_(name, st);
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), C::lds_bytes(), st, p);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NT), C::lds_bytes(), st, p);
     T2P_CHECK_LAUNCH("ws_sa");
     return 0;
 }
@@ -365,9 +424,16 @@ int launch_sa_cfg(const SaParams& p_in, hipStream_t st, const char* name) {
 
 int launch_ws_sa(int H, int Cout, const SaParams& p, hipStream_t st) {
     T2P_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.Bc) & 15) == 0, "ws_sa: tables must be 16-byte aligned");
-    if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 4>(p, st, "ws_edge_sa_k32_n64");
-    if (H == 128 && Cout == 128) return launch_sa_cfg<128, 128, 4, 2>(p, st, "ws_edge_sa_k128_n128");
-    if (H == 256 && Cout == 256) return launch_sa_cfg<256, 256, 4, 1>(p, st, "ws_edge_sa_k256_n256");
+    if (p.W_x3 != nullptr) {  // f16x3 split-precision path
+        T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_sa: packed f16x3 weights must be 16-byte aligned");
+        if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2, 1>(p, st, "ws_edge_sa_k32_n64");
+        if (H == 128 && Cout == 128) return launch_sa_cfg<128, 128, 4, 1, 1>(p, st, "ws_edge_sa_k128_n128");
+        if (H == 256 && Cout == 256) return launch_sa_cfg<256, 256, 8, 1, 1>(p, st, "ws_edge_sa_k256_n256");
+    } else {
+        if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2, 0>(p, st, "ws_edge_sa_k32_n64");
+        if (H == 128 && Cout == 128) return launch_sa_cfg<128, 128, 4, 1, 0>(p, st, "ws_edge_sa_k128_n128");
+        if (H == 256 && Cout == 256) return launch_sa_cfg<256, 256, 8, 1, 0>(p, st, "ws_edge_sa_k256_n256");
+    }
     set_error("ws_sa: no instantiation for H=%d C=%d", H, Cout);
     return T2P_E_UNSUPPORTED;
 }

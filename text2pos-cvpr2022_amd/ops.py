@@ -130,7 +130,8 @@ def sim_topk(queries: torch.Tensor, cells: torch.Tensor, k: int, index_offset: i
 
 # ---------------------------------------------------------------------------------------------------------------
 def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features=("class", "color", "position"),
-                     self_loops=True, knn_k=8, variation=0, radius=(0.2, 0.3, 0.4), chunk_objects=0) -> L.CellConfig:
+                     self_loops=True, knn_k=8, variation=0, radius=(0.2, 0.3, 0.4), chunk_objects=0,
+                     precision="f16x3") -> L.CellConfig:
     cfg = L.CellConfig()
     cfg.n_pts, cfg.embed_dim, cfg.pointnet_features = int(n_pts), int(embed_dim), int(pointnet_features)
     cfg.use_class = int("class" in use_features)
@@ -139,6 +140,9 @@ def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features
     cfg.self_loops, cfg.knn_k, cfg.variation = int(bool(self_loops)), int(knn_k), int(variation)
     cfg.radius = (C.c_float * 3)(*[float(r) for r in radius])
     cfg.chunk_objects = int(chunk_objects)
+    if precision not in ("fp32", "f16x3"):
+        raise RuntimeError(f"precision must be 'fp32' or 'f16x3', got {precision!r}")
+    cfg.precision = 1 if precision == "f16x3" else 0
     return cfg
 
 
@@ -155,6 +159,15 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
         if t is not None:
             _need(t, name, torch.float32)
         setattr(w, name, 0 if t is None else t.data_ptr())
+    x3 = packed.get("sa_w2_x3")
+    if x3 is not None:
+        for t in x3:
+            _need(t, "sa_w2_x3", torch.int16)
+        w.sa_w2_x3 = (C.c_void_p * 3)(*[t.data_ptr() for t in x3])
+    g = packed.get("ga_w2_x3")
+    if g is not None:
+        _need(g, "ga_w2_x3", torch.int16)
+        w.ga_w2_x3 = g.data_ptr()
     return w
 
 

@@ -37,6 +37,23 @@ def f32(b: torch.Tensor) -> torch.Tensor:
     return b.float().contiguous()
 
 
+def pack_f16x3(w_kmajor: torch.Tensor) -> torch.Tensor:
+    """fp32 [K][N] k-major weights -> int16 [2][N/32][K/16][2][32][8]: the f16x3 split w = hi + lo/2048 (hi, lo fp16,
+    round-to-nearest) laid out exactly as the MFMA B-operand registers of csrc/ws_sa.hip / ws_gemm.hip read it:
+    element (plane, tile, step, half, lane, e) = split(w[k = half*K/2 + 8*step + e][n = 32*tile + lane])."""
+    k, n = w_kmajor.shape
+    assert k % 32 == 0 and n % 32 == 0, (k, n)
+    w = w_kmajor.detach().float().cpu()
+    hi = w.to(torch.float16)
+    lo = ((w - hi.float()) * 2048.0).to(torch.float16)
+    planes = []
+    for t in (hi, lo):
+        # [K][N] -> [half][step][e][tile][lane] -> [tile][step][half][lane][e]
+        t = t.view(2, k // 16, 8, n // 32, 32).permute(3, 1, 0, 4, 2).contiguous()
+        planes.append(t)
+    return torch.stack(planes).view(torch.int16).contiguous()
+
+
 def pack_cell_weights(model, device) -> Dict[str, object]:
     """model: CellRetrievalNetwork (this package).  Returns name -> fp32 device tensor(s) for ops.make_cell_weights."""
     oe, pn = model.object_encoder, model.object_encoder.pointnet
@@ -51,6 +68,7 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
         sa_w2.append(kmajor(w2).to(device))
         sa_b2.append(f32(b2).to(device))
     p.update(sa_w1=sa_w1, sa_b1=sa_b1, sa_w2=sa_w2, sa_b2=sa_b2)
+    p["sa_w2_x3"] = [pack_f16x3(t).to(device) for t in sa_w2]
     w1, b1 = fold_linear_bn(pn.ga.mlp[0])
     w2, b2 = fold_linear_bn(pn.ga.mlp[1])
     p.update(ga_w1=kmajor(w1, 264).to(device), ga_b1=f32(b1).to(device), ga_w2=kmajor(w2).to(device),
