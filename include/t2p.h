@@ -47,12 +47,12 @@ const char* t2p_last_error(void);
 typedef struct t2p_cell_weights {
     /* PointNet2.sa{1,2,3}.point_conv.local_nn (models/pointcloud/pointnet2.py:57-59).  Layer 1 is applied to
      * [x_j | pos_j - pos_i]; sa_w1[l] is [Kpad_l][H_l] with rows = [x features (3,64,128) | pos (3) | zero pad]
-     * (Kpad = 6, 72, 136; H = 32, 128, 256); sa_w2[l] is [H_l][C_l] (C = 64, 128, 256). */
+     * (Kpad = 6, 96, 160; H = 32, 128, 256); sa_w2[l] is [H_l][C_l] (C = 64, 128, 256). */
     const float* sa_w1[3];
     const float* sa_b1[3];
     const float* sa_w2[3];
     const float* sa_b2[3];
-    /* PointNet2.ga.mlp (pointnet2.py:60): [264][512] (rows = [x 256 | pos 3 | pad 5]) and [512][1024] */
+    /* PointNet2.ga.mlp (pointnet2.py:60): [288][512] (rows = [x 256 | pos 3 | pad 29]) and [512][1024] */
     const float* ga_w1;
     const float* ga_b1;
     const float* ga_w2;
@@ -95,6 +95,8 @@ typedef struct t2p_cell_weights {
      * w[k = half*K/2 + 8*step + e][n = 32*tile + lane]  (packing.py::pack_f16x3). */
     const void* sa_w2_x3[3];
     const void* ga_w2_x3;
+    const void* sa_w1_x3[3]; /* levels 1 and 2 only (level 0 has K = 6 and runs on the VALU); [0] is ignored */
+    const void* ga_w1_x3;
 } t2p_cell_weights;
 
 typedef struct t2p_cell_config {
@@ -116,7 +118,7 @@ typedef struct t2p_cell_config {
 /* Optional stage outputs for parity tests (any member may be NULL).  Layouts:
  *   fps_idx[l] uint8 [n_obj][n_cent_l]      local FPS indices into level l's dense ordering
  *   nbr[l]     uint8 [n_obj][n_cent_l][32]  ball-query neighbours (first cnt valid), cnt[l] uint8 [n_obj][n_cent_l]
- *   sa_out[l]  fp32  [n_obj*n_cent_l][C_l+8] rows = [features C_l | centroid xyz | 0 x 5]
+ *   sa_out[l]  fp32  [n_obj*n_cent_l][C_l+32] rows = [features C_l | centroid xyz | 0 x 29]
  *   features0  fp32  [n_obj][1024]; features2 [n_obj][256]; obj_emb [n_obj][D] (ObjectEncoder output)
  *   knn_idx    int32 [n_obj][knn_k] global object rows (-1 = none) */
 typedef struct t2p_cell_trace {

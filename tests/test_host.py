@@ -102,9 +102,9 @@ def test_bn_fold_equals_eval_mode_block():
 def test_cell_weight_pack_shapes_and_edge_split():
     m = _model()
     p = packing.pack_cell_weights(m, "cpu")
-    assert [tuple(t.shape) for t in p["sa_w1"]] == [(6, 32), (72, 128), (136, 256)]
+    assert [tuple(t.shape) for t in p["sa_w1"]] == [(6, 32), (96, 128), (160, 256)]
     assert [tuple(t.shape) for t in p["sa_w2"]] == [(32, 64), (128, 128), (256, 256)]
-    assert tuple(p["ga_w1"].shape) == (264, 512) and tuple(p["ga_w2"].shape) == (512, 1024)
+    assert tuple(p["ga_w1"].shape) == (288, 512) and tuple(p["ga_w2"].shape) == (512, 1024)
     assert (p["sa_w1"][1][67:] == 0).all() and (p["ga_w1"][259:] == 0).all()      # zero K padding
     assert tuple(p["merge_w"].shape) == (768, 256) and tuple(p["lin1_w"].shape) == (1024, 512)
     # layer 1 of an SA block on [x_j | pos_j - pos_i] == A_j - B_i with the packed tables
@@ -113,7 +113,7 @@ def test_cell_weight_pack_shapes_and_edge_split():
     with torch.no_grad():
         want = blk(torch.cat([xj, pj - pi], 1))
     w1, b1 = p["sa_w1"][1], p["sa_b1"][1]
-    a = torch.cat([xj, pj, torch.zeros(9, 5)], 1) @ w1 + b1
+    a = torch.cat([xj, pj, torch.zeros(9, 29)], 1) @ w1 + b1
     bt = pi @ w1[64:67]
     assert torch.allclose(torch.relu(a - bt), want, atol=1e-5)
     # DynamicEdgeConv layer 1 on [x_i | x_j - x_i] == P_i + Q_j

@@ -22,7 +22,7 @@ class CellWeights(C.Structure):
               "lin2_b", "pn_w", "pn_b", "col_w1", "col_b1", "col_w2", "col_b2", "pos_w1", "pos_b1", "pos_w2", "pos_b2",
               "merge_w", "merge_b", "g_wp", "g_bp", "g_wq", "g_w2", "g_b2", "lin_w1", "lin_b1", "lin_w2", "lin_b2"])
     _fields_ = ([(n, c_void * 3) for n in _names[0]] + [(n, c_void) for n in _names[1]] +
-                [("sa_w2_x3", c_void * 3), ("ga_w2_x3", c_void)])
+                [("sa_w2_x3", c_void * 3), ("ga_w2_x3", c_void), ("sa_w1_x3", c_void * 3), ("ga_w1_x3", c_void)])
 
 
 class CellConfig(C.Structure):

@@ -73,7 +73,7 @@ struct Geo {
     int nd[3], nc[3];
     static constexpr int H[3] = {32, 128, 256};
     static constexpr int C[3] = {64, 128, 256};
-    static constexpr int LD[3] = {72, 136, 264};  // SA output row = [C | xyz | 0 x 5]
+    static constexpr int LD[3] = {96, 160, 288};  // SA output row = [C | xyz | 0 x 29]: K % 32 == 0 for the next GEMM
     explicit Geo(int n_pts) {
         nd[0] = n_pts;
         for (int l = 0; l < 3; l++) {
@@ -194,6 +194,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
             p.A = ws.F[l - 1];
             p.lda = Geo::LD[l - 1];
             p.W = W.sa_w1[l];
+            p.W_x3 = cfg.precision == 1 ? W.sa_w1_x3[l] : nullptr;
             p.ldw = H;
             p.bias = W.sa_b1[l];
             p.out = ws.A[l];
@@ -234,6 +235,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.A = ws.F[2];
         p.lda = Geo::LD[2];
         p.W = W.ga_w1;
+        p.W_x3 = cfg.precision == 1 ? W.ga_w1_x3 : nullptr;
         p.ldw = 512;
         p.bias = W.ga_b1;
         p.out = ws.gh;
@@ -245,12 +247,13 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         q.A = ws.gh;
         q.lda = 512;
         q.W = W.ga_w2;
+        q.W_x3 = cfg.precision == 1 ? W.ga_w2_x3 : nullptr;
         q.ldw = 1024;
         q.bias = W.ga_b2;
         q.out = ws.f0;
         q.ldo = 1024;
         q.relu = 1;
-        q.n_groups = n;
+        q.M = n * g.nc[2];
         T2P_TRY(launch_ws(WS_DENSE_GROUPMAX, 512, 1024, q, st));
     }
     // ---- PointNet2 heads + ObjectEncoder ------------------------------------------------------------------------
@@ -394,8 +397,9 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
     T2P_CHECK_ARG(w != nullptr && cell_ptr_host != nullptr && cell_ptr != nullptr && out != nullptr,
                   "encode_cells: NULL argument");
     if (cfg->precision == 1)
-        T2P_CHECK_ARG(w->sa_w2_x3[0] && w->sa_w2_x3[1] && w->sa_w2_x3[2],
-                      "encode_cells: precision = f16x3 needs the packed sa_w2_x3 weight images");
+        T2P_CHECK_ARG(w->sa_w2_x3[0] && w->sa_w2_x3[1] && w->sa_w2_x3[2] && w->sa_w1_x3[1] && w->sa_w1_x3[2] &&
+                          w->ga_w1_x3 && w->ga_w2_x3,
+                      "encode_cells: precision = f16x3 needs the packed *_x3 weight images");
     T2P_CHECK_ARG(n_cells >= 0 && n_obj >= 0, "encode_cells: negative size");
     if (n_cells == 0) return 0;
     T2P_CHECK_ARG(cell_ptr_host[0] == 0 && cell_ptr_host[n_cells] == n_obj,

@@ -44,8 +44,8 @@ __global__ void k_pos_table(const float* __restrict__ src, int ld_src, int col0,
         acc = fmaf(p[1], wp[H + h], acc);
         acc = fmaf(p[2], wp[2 * H + h], acc);
         out[e] = acc;
-        // the centroid's [xyz | 0 x 5] tail of the SA output row (the next layer's GEMM reads [features | xyz | pad])
-        if (tail != nullptr && h < 8) tail[row * ld_tail + tail_col0 + h] = h < 3 ? p[h] : 0.f;
+        // the centroid's [xyz | 0 x 29] tail of the SA output row (the next layer's GEMM reads [features | xyz | pad])
+        if (tail != nullptr && h < 32) tail[row * ld_tail + tail_col0 + h] = h < 3 ? p[h] : 0.f;
     }
 }
 
@@ -256,7 +256,7 @@ int launch_knn(const float* x, int dim, const int32_t* seg_ptr, int n_seg, int m
     size_t lds = (size_t)(max_seg_rows > 0 ? max_seg_rows : 1) * max_seg_rows * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_knn, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_knn, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(kMaxRows * kMaxRows * sizeof(float)));
         attr_set = true;
     }

@@ -98,7 +98,7 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
                 int K, int N, int relu, hipStream_t st);
 
 // ---- ws_gemm.hip: weight-stationary streaming fp32-MFMA kernels ---------------------------------------------
-enum WsMode { WS_DENSE_STORE = 0, WS_DENSE_GROUPMAX = 1, WS_EDGE_SA = 2, WS_EDGE_KNN = 3 };
+enum WsMode { WS_DENSE_STORE = 0, WS_DENSE_GROUPMAX = 1, WS_EDGE_KNN = 3 };
 struct WsParams {
     // operand tables
     const float* A;    // source rows [n_src, lda]   (dense: the GEMM's A; edge: layer-1 point table)
@@ -106,21 +106,13 @@ struct WsParams {
     const float* Bc;   // edge modes: per-destination term [n_dst, H]
     const float* W;    // [K][ldw] k-major weights (BN folded)
     int ldw;
+    const void* W_x3;  // nullptr, or the packed f16x3 register image of the whole [K][ldw] matrix (dense modes)
     const float* bias; // [N]
     float* out;        // dense_store: [M, ldo]; groupmax: [n_groups, ldo]; edge: [n_dst, ldo]
     int ldo;
     int relu;
     int64_t n_groups;  // dense: ceil(M / rows_per_group); edge SA: objects; edge kNN: ceil(n_dst/32)
     int64_t M;         // dense: total rows
-    // edge SA
-    const uint8_t* nbr;     // [n_obj, n_cent, 32]
-    const uint8_t* cnt;     // [n_obj, n_cent]
-    const uint8_t* fps_idx; // [n_obj, n_cent]  (to append the centroid positions to the output rows)
-    const int32_t* obj_cell_first;  // [n_obj] index of the first object of the object's cell (self-loop aliasing)
-    const float* pos_src;   // rows holding the dense positions of this level
-    int ld_pos, pos_col0;
-    int n_dense, n_cent;
-    int self_loops;         // 1 = PyG PointConv(add_self_loops=True) index-aliased loops, 0 = none
     // edge kNN
     const int32_t* knn_idx; // [n_dst, knn_k] (-1 = absent)
     int knn_k;

@@ -1,80 +1,81 @@
-// Weight-stationary streaming fp32-MFMA kernels: the dense hot loop of the PointNet++ / DGCNN cell branch.
+// Weight-stationary streaming MFMA kernels for the dense layers of the PointNet++ / DGCNN cell branch and for the
+// DynamicEdgeConv edge layer.
 //
 // Replaces (reference call sites):
-//   gnn.PointConv(local_nn)(x, (pos, pos[idx]), edge_index)   models/pointcloud/pointnet2.py:31-35  (sa1/sa2/sa3)
-//   GlobalAbstractionLayer mlp + global_max_pool               models/pointcloud/pointnet2.py:45-49
-//   gnn.DynamicEdgeConv(mlp, k=8, aggr="max")                   models/cell_retrieval.py:46-48,97
+//   layer 1 of every SA local_nn, applied per dense point (see below)            models/pointcloud/pointnet2.py:31-35
+//   GlobalAbstractionLayer mlp + global_max_pool                                  models/pointcloud/pointnet2.py:45-49
+//   gnn.DynamicEdgeConv(mlp, k=8, aggr="max")                                     models/cell_retrieval.py:46-48,97
 //
 // Design (MI355X-first, not a translation of PyG's gather -> addmm -> scatter chain):
 //   * Every per-edge MLP  relu(BN(W2 relu(BN(W1 [x_j | pos_j - pos_i]))))  is split algebraically.  Layer 1 is
 //     linear before its ReLU, so  W1 [x_j | pos_j - pos_i] + b = A_j - B_i  with one table row per dense POINT
-//     (A_j = W1 [x_j | pos_j] + b) and per CENTROID (B_i = W1p pos_i); the per-EDGE work is only
-//     h_e = relu(A_j - B_i) (VALU, while staging) and the layer-2 GEMM.  DynamicEdgeConv is the same with
-//     h_e = relu(P_i + Q_j).
-//   * The layer-2 weight slice of a workgroup lives in VGPRs for the whole launch (up to 256 registers per lane:
-//     SA3 keeps the full 256x256 W2 across the 4 waves of a CU), so the persistent loop streams only edge rows:
-//     no weight traffic, one barrier per row tile, MFMA operands B from registers and A from LDS (ds_read_b128).
-//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  Lane half h = lane>>5 owns the contiguous K range
-//     [h*K/2, (h+1)*K/2), which turns the A-operand fetch into 16-byte LDS reads; the k summation order is
-//     therefore (0, K/2, 1, K/2+1, ...) -- fixed, deterministic.
-//   * Staging is software-pipelined over a double-buffered LDS tile: the global gathers of batch t+1 are issued
-//     before the MFMA block of batch t and land in registers behind it; the VALU part (+/- destination term, ReLU)
-//     and the ds_write follow the MFMA block; one barrier per batch.
-//   * Max-aggregation: all layer outputs are post-ReLU (>= 0), so the segmented max is an LDS integer atomic max
-//     on the float bit pattern, initialised to +0.  Rows are sorted by destination, so each lane first folds the
-//     runs of equal destination among its 16 accumulator rows in registers (typically 16 -> 2-3 atomics).
+//     (A_j = W1 [x_j | pos_j] + b: the DENSE_STORE mode below) and per CENTROID (B_i = W1p pos_i); the per-EDGE work
+//     is only h_e = relu(A_j - B_i) and the layer-2 GEMM (csrc/ws_sa.hip).  DynamicEdgeConv is the same with
+//     h_e = relu(P_i + Q_j) (EDGE_KNN mode below).
+//   * The weight slice of a workgroup lives in VGPRs for the whole launch, so the persistent loop streams only
+//     activation rows: no weight traffic, one barrier per row batch, MFMA B operands from registers and A operands
+//     from LDS (ds_read_b128).  Lane half h = lane>>5 owns the contiguous K range [h*K/2, (h+1)*K/2), which makes the
+//     operand fetches 16-byte; the k summation order is therefore fixed and deterministic.
+//   * Two arithmetic paths: X3 = 0: v_mfma_f32_32x32x2_f32 (exact fp32 fma chains); X3 = 1: the "f16x3" split
+//     (x = hi + lo/2048, hi/lo fp16, three v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulation; see csrc/ws_sa.hip).
+//   * Staging is software-pipelined over a double-buffered LDS tile: the global loads of batch t+1 are issued before
+//     the MFMA block of batch t; their VALU part and the LDS write follow it; one barrier per batch.
+//   * Column slices of one row stream (GA: N = 1024 in slices of 128) are mapped to the same XCD (block b runs on
+//     XCD b % 8), so they share the stream's A rows through that XCD's L2.
 #include "t2p_common.h"
 
 namespace t2p {
 namespace {
 
-constexpr int kMaxRows = 128 * 33 + 256;  // largest SA group (128 centroids x (32 + self loop)) + tile padding
-constexpr int kAccFloats = 8192;          // 128x64 = 64x128 = 32x256
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
-template <int K, int NW, int WN, int RT, int MODE>
+constexpr int kMaxRows = 32 * 33;   // kNN group: 32 destination rows x up to 32 neighbours (+ slack)
+constexpr int kAccFloats = 8192;    // 32 x 256
+
+template <int K, int NW, int WN, int RT, int MODE, int X3>
 struct WsCfg {
     static constexpr int WM = 4 / WN;
     static constexpr int NTW = NW / (32 * WN);
     static constexpr int KS = K / 2;
     static constexpr int TR = WM * RT * 32;  // rows staged per barrier interval
-    static constexpr int LDH = K + 4;        // padded hidden-row stride (floats)
-    static constexpr bool EDGE = (MODE == WS_EDGE_SA || MODE == WS_EDGE_KNN);
-    static constexpr int HID_FLOATS = TR * LDH;  // one of the two staging buffers
+    static constexpr int LDH = K + 4;        // fp32 tile row stride (floats)
+    static constexpr int LDHH = K + 8;       // f16x3 plane row stride (halves)
+    static constexpr int PLANE = TR * LDHH;  // halves per plane (hi | lo)
+    static constexpr int S16 = K / 16;
+    static constexpr bool EDGE = (MODE == WS_EDGE_KNN);
+    static constexpr int TILE_FLOATS = X3 ? PLANE : TR * LDH;  // one staging buffer, in floats
     static constexpr int ACC_FLOATS = EDGE ? kAccFloats : 0;
     static constexpr int F4_PER_ROW = K / 4;
     static constexpr int TOTAL_F4 = TR * F4_PER_ROW;
     static constexpr int ITERS = (TOTAL_F4 + 255) / 256;
     static constexpr size_t lds_bytes() {
-        size_t b = (size_t)(2 * HID_FLOATS + ACC_FLOATS) * 4;
-        if (EDGE) b += (size_t)kMaxRows * 4 + kMaxRows + 132 * 4;
+        size_t b = (size_t)(2 * TILE_FLOATS + ACC_FLOATS) * 4;
+        if (EDGE) b += (size_t)kMaxRows * 4 + kMaxRows + 40 * 4;
         return b;
     }
     static_assert(K % 8 == 0, "K must be a multiple of 8");
+    static_assert(!X3 || K % 32 == 0, "f16x3 needs K % 32 == 0");
+    static_assert(!X3 || !EDGE, "the kNN edge mode is fp32 only");
     static_assert(NW % (32 * WN) == 0, "NW must split into 32-column tiles per wave");
 };
 
-template <int K, int NW, int WN, int RT, int MODE>
+template <int K, int NW, int WN, int RT, int MODE, int X3>
 __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
-    using C = WsCfg<K, NW, WN, RT, MODE>;
+    using C = WsCfg<K, NW, WN, RT, MODE, X3>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* hid = lds;  // two buffers of HID_FLOATS
-    int* acc_lds = (int*)(lds + 2 * C::HID_FLOATS);
-    int* rows_src = (int*)(lds + 2 * C::HID_FLOATS + C::ACC_FLOATS);
+    float* hid = lds;                  // fp32: two buffers of TILE_FLOATS
+    _Float16* hidh = (_Float16*)lds;   // f16x3: two buffers of [hi plane | lo plane]
+    int* acc_lds = (int*)(lds + 2 * C::TILE_FLOATS);
+    int* rows_src = (int*)(lds + 2 * C::TILE_FLOATS + C::ACC_FLOATS);
     uint8_t* rows_dst = (uint8_t*)(rows_src + kMaxRows);
     int* scan = (int*)(rows_dst + kMaxRows);
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wn = wave % WN;
-    const int wm = wave / WN;
-    const int h = lane >> 5;
-    const int l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN, h = lane >> 5, l31 = lane & 31;
 
-    // XCD-aware stream/slice mapping: the n_slices column slices of one row stream sit on the same XCD
-    // (block b runs on XCD b % 8), so they share the stream's A rows through that XCD's L2.
-    const int lin = blockIdx.x;
-    const int nblk = gridDim.x;
+    // XCD-aware stream/slice mapping
+    const int lin = blockIdx.x, nblk = gridDim.x;
     int slice, stream, n_streams;
     if ((nblk % (8 * n_slices)) == 0) {
         const int xcd = lin & 7, j = lin >> 3, per_xcd = nblk >> 3;
@@ -89,18 +90,34 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
     const int ncol0 = slice * NW + wn * C::NTW * 32;  // first output column of this wave
 
     // ---- stationary weights -> registers ----------------------------------------------------------------
-    float w[C::NTW][C::KS];
+    float w[X3 ? 1 : C::NTW][X3 ? 1 : C::KS];
+    half8 w_hi[X3 ? C::NTW : 1][X3 ? C::S16 : 1], w_lo[X3 ? C::NTW : 1][X3 ? C::S16 : 1];
+    if constexpr (X3) {
+        // host-packed register image of the whole [K][ldw] matrix (packing.py::pack_f16x3)
+        const uint4* wp = (const uint4*)p.W_x3;
+        const int plane_u4 = (p.ldw / 32) * C::S16 * 64;
 #pragma unroll
-    for (int nt = 0; nt < C::NTW; nt++)
+        for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
-        for (int s = 0; s < C::KS; s++)
-            w[nt][s] = p.W[(int64_t)(h * C::KS + s) * p.ldw + ncol0 + nt * 32 + l31];
+            for (int s = 0; s < C::S16; s++) {
+                const int idx = (((ncol0 / 32 + nt) * C::S16 + s) * 2 + h) * 32 + l31;
+                const uint4 a = wp[idx], b = wp[plane_u4 + idx];
+                w_hi[nt][s] = __builtin_bit_cast(half8, a);
+                w_lo[nt][s] = __builtin_bit_cast(half8, b);
+            }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < C::NTW; nt++)
+#pragma unroll
+            for (int s = 0; s < C::KS; s++)
+                w[nt][s] = p.W[(int64_t)(h * C::KS + s) * p.ldw + ncol0 + nt * 32 + l31];
+    }
     float bias[C::NTW];
 #pragma unroll
     for (int nt = 0; nt < C::NTW; nt++) bias[nt] = p.bias ? p.bias[ncol0 + nt * 32 + l31] : 0.f;
 
     f32x4 sa[C::ITERS];                  // staged source rows (in flight behind the MFMA block)
-    f32x4 sb[C::EDGE ? C::ITERS : 1];    // staged destination terms (edge modes)
+    f32x4 sb[C::EDGE ? C::ITERS : 1];    // staged destination terms (kNN edge mode)
 
     // Issue the global loads of one batch: rows [r0, r0+TR) of group g (n_rows valid rows in the group).
     auto stage_load = [&](int64_t g, int r0, int n_rows) {
@@ -114,12 +131,9 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
             if (((C::TOTAL_F4 % 256) == 0 || q < C::TOTAL_F4) && r < n_rows) {
                 if constexpr (C::EDGE) {
                     const int src = rows_src[r];
-                    const int dl = rows_dst[r];
-                    const int64_t dst = (MODE == WS_EDGE_SA) ? (g * p.n_cent + dl) : (g * 32 + dl);
+                    const int64_t dst = g * 32 + rows_dst[r];
                     sa[it] = *(const f32x4*)(p.A + (int64_t)src * p.lda + c4 * 4);
                     sb[it] = *(const f32x4*)(p.Bc + dst * K + c4 * 4);
-                } else if constexpr (MODE == WS_DENSE_GROUPMAX) {
-                    sa[it] = *(const f32x4*)(p.A + (g * 32 + r) * (int64_t)p.lda + c4 * 4);
                 } else {
                     sa[it] = *(const f32x4*)(p.A + (g * C::TR + r) * (int64_t)p.lda + c4 * 4);
                 }
@@ -128,7 +142,6 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
     };
     // VALU part + LDS write of the staged batch.
     auto stage_write = [&](int buf) {
-        float* dst = hid + buf * C::HID_FLOATS;
 #pragma unroll
         for (int it = 0; it < C::ITERS; it++) {
             const int q = it * 256 + tid;
@@ -136,101 +149,93 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
             const int lr = q / C::F4_PER_ROW, c4 = q % C::F4_PER_ROW;
             f32x4 v = sa[it];
             if constexpr (C::EDGE) {
-                const f32x4 t = (MODE == WS_EDGE_SA) ? (sa[it] - sb[it]) : (sa[it] + sb[it]);
+                const f32x4 t = sa[it] + sb[it];
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(t[e], 0.f);
             }
-            *(f32x4*)(dst + lr * C::LDH + c4 * 4) = v;
+            if constexpr (X3) {
+                _Float16* dsth = hidh + buf * 2 * C::PLANE;
+                const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+                const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.f, (v[1] - (float)h01[1]) * 2048.f);
+                const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * 2048.f, (v[3] - (float)h23[1]) * 2048.f);
+                uint2 ph, pl;
+                ph.x = __builtin_bit_cast(uint32_t, h01); ph.y = __builtin_bit_cast(uint32_t, h23);
+                pl.x = __builtin_bit_cast(uint32_t, l01); pl.y = __builtin_bit_cast(uint32_t, l23);
+                *(uint2*)(dsth + lr * C::LDHH + c4 * 4) = ph;
+                *(uint2*)(dsth + C::PLANE + lr * C::LDHH + c4 * 4) = pl;
+            } else {
+                *(f32x4*)(hid + buf * C::TILE_FLOATS + lr * C::LDH + c4 * 4) = v;
+            }
         }
     };
-    // [RT x 32 rows] x [K] x [NTW x 32 cols] per wave.
+    // [RT x 32 rows] x [K] x [NTW x 32 cols] per wave; the bias rides in the accumulator.
     auto mfma_block = [&](int buf, f32x16 (&acc)[RT][C::NTW]) {
 #pragma unroll
         for (int rt = 0; rt < RT; rt++)
 #pragma unroll
             for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
-                for (int e = 0; e < 16; e++) acc[rt][nt][e] = bias[nt];  // bias rides in the accumulator
-        const float* hrow = hid + buf * C::HID_FLOATS + ((wm * RT) * 32 + l31) * C::LDH + h * C::KS;
-        // A operands are fetched one chunk (QC k-quads) ahead of the MFMAs that consume them
-        constexpr int NQ = C::KS / 4;
-        constexpr int QC = (NQ % 4 == 0) ? 4 : ((NQ % 3 == 0) ? 3 : 1);
-        constexpr int NCH = NQ / QC;
-        f32x4 a_cur[RT][QC], a_nxt[RT][QC];
+                for (int e = 0; e < 16; e++) acc[rt][nt][e] = bias[nt];
+        if constexpr (X3) {
+            f32x16 accx[RT][C::NTW];  // cross terms hi.lo' + lo'.hi, scaled by 2048
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++)
+            for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-            for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = *(const f32x4*)(hrow + rt * 32 * C::LDH + qi * 4);
+                for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            if (ch + 1 < NCH) {
+                    for (int e = 0; e < 16; e++) accx[rt][nt][e] = 0.f;
+            const _Float16* hrow = hidh + buf * 2 * C::PLANE + ((wm * RT) * 32 + l31) * C::LDHH + h * (K / 2);
+#pragma unroll
+            for (int s = 0; s < C::S16; s++) {
+                half8 a_hi[RT], a_lo[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    a_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH + s * 8);
+                    a_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH + s * 8);
+                }
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                    for (int qi = 0; qi < QC; qi++)
-                        a_nxt[rt][qi] = *(const f32x4*)(hrow + rt * 32 * C::LDH + ((ch + 1) * QC + qi) * 4);
+                    for (int nt = 0; nt < C::NTW; nt++) {
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_hi[nt][s], acc[rt][nt], 0, 0, 0);
+                        accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_lo[nt][s], accx[rt][nt], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int nt = 0; nt < C::NTW; nt++)
+                        accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[rt], w_hi[nt][s], accx[rt][nt], 0, 0, 0);
             }
 #pragma unroll
-            for (int qi = 0; qi < QC; qi++)
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int nt = 0; nt < C::NTW; nt++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[rt][nt][e] = fmaf(accx[rt][nt][e], 1.f / 2048.f, acc[rt][nt][e]);
+        } else {
+            const float* hrow = hid + buf * C::TILE_FLOATS + ((wm * RT) * 32 + l31) * C::LDH + h * C::KS;
+            constexpr int NQ = C::KS / 4;
+#pragma unroll
+            for (int s4 = 0; s4 < NQ; s4++) {
+                f32x4 a[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) a[rt] = *(const f32x4*)(hrow + rt * 32 * C::LDH + s4 * 4);
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                         for (int nt = 0; nt < C::NTW; nt++)
-                            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                a_cur[rt][qi][j], w[nt][(ch * QC + qi) * 4 + j], acc[rt][nt], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = a_nxt[rt][qi];
-        }
-    };
-    // Segmented max of one batch into the group's LDS accumulator (edge modes).
-    auto epilogue_edge = [&](int r0, int n_rows, f32x16 (&acc)[RT][C::NTW]) {
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            const int trow0 = r0 + (wm * RT + rt) * 32;
-            if (trow0 >= n_rows) continue;
-            // destinations of this lane's 16 rows: quads of 4 consecutive rows at trow0 + 8*q + 4*h
-            int dq[4][4];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int r = trow0 + 8 * q + 4 * h + e;
-                    dq[q][e] = r < n_rows ? (int)rows_dst[r] : -1;
-                }
-            bool same[16], is_end[16];
-            int dd[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++) dd[e] = dq[e >> 2][e & 3];
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                same[e] = e > 0 && dd[e] == dd[e - 1];
-                is_end[e] = dd[e] >= 0 && (e == 15 || dd[e] != dd[e + 1]);
-            }
-#pragma unroll
-            for (int nt = 0; nt < C::NTW; nt++) {
-                const int lcol = wn * C::NTW * 32 + nt * 32 + l31;
-                float v[16];
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    v[e] = acc[rt][nt][e];  // bias already inside; ReLU is implied by the signed-int max against +0
-                    if (e > 0) v[e] = same[e] ? fmaxf(v[e], v[e - 1]) : v[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    if (is_end[e]) atomicMax(&acc_lds[dd[e] * NW + lcol], __float_as_int(v[e]));
+                            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][j], w[nt][s4 * 4 + j], acc[rt][nt],
+                                                                                0, 0, 0);
             }
         }
     };
 
     if constexpr (!C::EDGE) {
-        // ---- dense streams: every group is one batch; the pipeline runs across groups -----------------------------
+        // ---- dense streams: every group is one batch of TR rows; the pipeline runs across groups --------------------
         int64_t g = stream;
         auto rows_of = [&](int64_t gg) -> int {
-            if constexpr (MODE == WS_DENSE_GROUPMAX) return 32;
             const int64_t left = p.M - gg * C::TR;
             return (int)(left < C::TR ? left : C::TR);
         };
@@ -247,11 +252,11 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
             mfma_block(i & 1, acc);
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
+                const int trow0 = (wm * RT + rt) * 32;
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++) {
                     const int lcol = wn * C::NTW * 32 + nt * 32 + l31;
                     if constexpr (MODE == WS_DENSE_STORE) {
-                        const int trow0 = (wm * RT + rt) * 32;
 #pragma unroll
                         for (int e = 0; e < 16; e++) {
                             const int r = trow0 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -259,12 +264,13 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
                             if (p.relu) v = fmaxf(v, 0.f);
                             if (r < n_rows) p.out[(g * C::TR + r) * (int64_t)p.ldo + slice * NW + lcol] = v;
                         }
-                    } else {  // max over the 32 rows of the object: in registers, then across the two lane halves
+                    } else {  // max over each 32-row tile = one object (ReLU = starting the max at 0)
                         float m = 0.f;
 #pragma unroll
                         for (int e = 0; e < 16; e++) m = fmaxf(m, acc[rt][nt][e]);
                         m = fmaxf(m, __shfl_xor(m, 32, 64));
-                        if (h == 0) p.out[g * (int64_t)p.ldo + slice * NW + lcol] = m;
+                        if (h == 0 && trow0 < n_rows)
+                            p.out[(g * (C::TR / 32) + wm * RT + rt) * (int64_t)p.ldo + slice * NW + lcol] = m;
                     }
                 }
             }
@@ -272,73 +278,28 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
             __syncthreads();
         }
     } else {
-        // ---- edge streams: a group = the destination rows of one object (SA) / 32 objects (kNN) -------------------
+        // ---- kNN edge stream: a group = 32 destination objects, rows = their valid neighbours ----------------------
         for (int64_t g = stream; g < p.n_groups; g += n_streams) {
-            int n_rows;
-            if constexpr (MODE == WS_EDGE_SA) {
-                const int nc = p.n_cent;
-                const int extra = p.self_loops ? 1 : 0;
-                int my = 0;
-                if (tid < nc) my = (int)p.cnt[g * nc + tid] + extra;
-                if (tid <= nc) scan[tid] = 0;
-                __syncthreads();
-                if (tid < nc) scan[tid + 1] = my;
-                __syncthreads();
-                if (wave == 0) {  // inclusive scan of <=128 counts by one wave, two entries per lane
-                    int a0 = (2 * lane + 1 <= nc) ? scan[2 * lane + 1] : 0;
-                    int a1 = (2 * lane + 2 <= nc) ? scan[2 * lane + 2] : 0;
-                    int s = a0 + a1;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        int t = __shfl_up(s, off, 64);
-                        if (lane >= off) s += t;
-                    }
-                    int excl = s - (a0 + a1);
-                    if (2 * lane + 1 <= nc) scan[2 * lane + 1] = excl + a0;
-                    if (2 * lane + 2 <= nc) scan[2 * lane + 2] = excl + a0 + a1;
-                }
-                __syncthreads();
-                n_rows = scan[nc];
-                int64_t self_base = 0;
-                if (p.self_loops) {
-                    const int64_t first = p.obj_cell_first[g];
-                    self_base = first * p.n_dense + (g - first) * (int64_t)nc;
-                }
-                if (tid < nc) {
-                    int off = scan[tid];
-                    const uint8_t* nb = p.nbr + (g * nc + tid) * 32;
-                    const int c = my - extra;
-                    for (int e = 0; e < c; e++) {
-                        rows_src[off + e] = (int)(g * p.n_dense + nb[e]);
-                        rows_dst[off + e] = (uint8_t)tid;
-                    }
-                    if (extra) {
-                        rows_src[off + c] = (int)(self_base + tid);
-                        rows_dst[off + c] = (uint8_t)tid;
-                    }
-                }
-            } else {
-                const int64_t d0 = g * 32;
-                const int nd = (int)((p.n_dst - d0) < 32 ? (p.n_dst - d0) : 32);
-                int my = 0;
-                if (tid < nd)
-                    for (int e = 0; e < p.knn_k; e++) my += p.knn_idx[(d0 + tid) * p.knn_k + e] >= 0 ? 1 : 0;
-                if (tid <= 32) scan[tid] = 0;
-                __syncthreads();
-                if (tid < 32) scan[tid + 1] = my;
-                __syncthreads();
-                if (tid == 0) {
-                    int s = 0;
-                    for (int i = 1; i <= 32; i++) { s += scan[i]; scan[i] = s; }
-                }
-                __syncthreads();
-                n_rows = scan[32];
-                if (tid < nd) {
-                    int off = scan[tid];
-                    for (int e = 0; e < p.knn_k; e++) {
-                        int j = p.knn_idx[(d0 + tid) * p.knn_k + e];
-                        if (j >= 0) { rows_src[off] = j; rows_dst[off] = (uint8_t)tid; off++; }
-                    }
+            const int64_t d0 = g * 32;
+            const int nd = (int)((p.n_dst - d0) < 32 ? (p.n_dst - d0) : 32);
+            int my = 0;
+            if (tid < nd)
+                for (int e = 0; e < p.knn_k; e++) my += p.knn_idx[(d0 + tid) * p.knn_k + e] >= 0 ? 1 : 0;
+            if (tid <= 32) scan[tid] = 0;
+            __syncthreads();
+            if (tid < 32) scan[tid + 1] = my;
+            __syncthreads();
+            if (tid == 0) {
+                int s = 0;
+                for (int i = 1; i <= 32; i++) { s += scan[i]; scan[i] = s; }
+            }
+            __syncthreads();
+            const int n_rows = scan[32];
+            if (tid < nd) {
+                int off = scan[tid];
+                for (int e = 0; e < p.knn_k; e++) {
+                    int j = p.knn_idx[(d0 + tid) * p.knn_k + e];
+                    if (j >= 0) { rows_src[off] = j; rows_dst[off] = (uint8_t)tid; off++; }
                 }
             }
             for (int i = tid; i < kAccFloats; i += 256) acc_lds[i] = 0;
@@ -355,45 +316,53 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
                 if (more) stage_load(g, (bt + 1) * C::TR, n_rows);
                 f32x16 acc[RT][C::NTW];
                 mfma_block(bt & 1, acc);
-                epilogue_edge(bt * C::TR, n_rows, acc);
+                // segmented max (rows sorted by destination; the signed-int atomic max against +0 is the ReLU)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const int trow0 = bt * C::TR + (wm * RT + rt) * 32;
+                    if (trow0 >= n_rows) continue;
+                    int dd[16];
+                    bool same[16], is_end[16];
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int r = trow0 + 8 * (e >> 2) + 4 * h + (e & 3);
+                        dd[e] = r < n_rows ? (int)rows_dst[r] : -1;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        same[e] = e > 0 && dd[e] == dd[e - 1];
+                        is_end[e] = dd[e] >= 0 && (e == 15 || dd[e] != dd[e + 1]);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < C::NTW; nt++) {
+                        const int lcol = wn * C::NTW * 32 + nt * 32 + l31;
+                        float v[16];
+#pragma unroll
+                        for (int e = 0; e < 16; e++) {
+                            v[e] = acc[rt][nt][e];
+                            if (e > 0) v[e] = same[e] ? fmaxf(v[e], v[e - 1]) : v[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            if (is_end[e]) atomicMax(&acc_lds[dd[e] * NW + lcol], __float_as_int(v[e]));
+                    }
+                }
                 if (more) stage_write((bt + 1) & 1);
                 __syncthreads();
             }
-
-            // ---- write the group's result -----------------------------------------------------------------------
-            if constexpr (MODE == WS_EDGE_SA) {
-                const int nc = p.n_cent;
-                for (int i = tid; i < nc * NW; i += 256) {
-                    const int c = i / NW, col = i % NW;
-                    p.out[(g * nc + c) * (int64_t)p.ldo + col] = __int_as_float(acc_lds[i]);
-                }
-                // append [pos_centroid, 0 x 5] so that the next layer's A rows are [features | pos | pad]
-                for (int i = tid; i < nc * 8; i += 256) {
-                    const int c = i >> 3, d = i & 7;
-                    float v = 0.f;
-                    if (d < 3) {
-                        const int loc = p.fps_idx[g * nc + c];
-                        v = p.pos_src[(g * p.n_dense + loc) * (int64_t)p.ld_pos + p.pos_col0 + d];
-                    }
-                    p.out[(g * nc + c) * (int64_t)p.ldo + NW + d] = v;
-                }
-            } else {
-                const int64_t d0 = g * 32;
-                const int nd = (int)((p.n_dst - d0) < 32 ? (p.n_dst - d0) : 32);
-                for (int i = tid; i < nd * NW; i += 256) {
-                    const int c = i / NW, col = i % NW;
-                    p.out[(d0 + c) * (int64_t)p.ldo + col] = __int_as_float(acc_lds[i]);
-                }
+            for (int i = tid; i < nd * NW; i += 256) {
+                const int c = i / NW, col = i % NW;
+                p.out[(d0 + c) * (int64_t)p.ldo + col] = __int_as_float(acc_lds[i]);
             }
             __syncthreads();
         }
     }
 }
 
-template <int K, int NW, int WN, int RT, int MODE>
+template <int K, int NW, int WN, int RT, int MODE, int X3>
 int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
-    using C = WsCfg<K, NW, WN, RT, MODE>;
-    auto kern = k_ws<K, NW, WN, RT, MODE>;
+    using C = WsCfg<K, NW, WN, RT, MODE, X3>;
+    auto kern = k_ws<K, NW, WN, RT, MODE, X3>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -405,7 +374,7 @@ int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
         attr_set = true;
     }
     WsParams p = p_in;
-    if (MODE == WS_DENSE_STORE) p.n_groups = (p.M + C::TR - 1) / C::TR;
+    if (MODE != WS_EDGE_KNN) p.n_groups = (p.M + C::TR - 1) / C::TR;  // dense: one group = one batch of TR rows
     if (p.n_groups <= 0) return 0;
     const int cus = num_cus();
     int64_t streams = cus / n_slices;
@@ -424,25 +393,30 @@ int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
 
 }  // namespace
 
+// mode DENSE_STORE: out[M][ldo] = act(A[M][K] W + b);  DENSE_GROUPMAX: out[M/32][ldo] = max over each 32-row group
+// (M = 32 * groups);  EDGE_KNN: see WsParams.
 int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
     T2P_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && (p.lda % 4) == 0, "ws_gemm: A must be 16-byte aligned, lda %% 4 == 0");
-#define WS_CASE(MODE_, K_, N_, NW_, WN_, RT_)                                     \
-    if (mode == MODE_ && K == K_ && N == N_)                                       \
-        return launch_cfg<K_, NW_, WN_, RT_, MODE_>(p, N_ / NW_, st);
-    // SA layer-2 edge GEMMs (H -> Cout)
-    WS_CASE(WS_EDGE_SA, 32, 64, 64, 2, 4)
-    WS_CASE(WS_EDGE_SA, 128, 128, 128, 4, 2)
-    WS_CASE(WS_EDGE_SA, 256, 256, 256, 4, 1)
-    // DynamicEdgeConv layer 2
-    WS_CASE(WS_EDGE_KNN, 256, 256, 256, 4, 1)
-    // SA2 / SA3 layer-1 point tables  ([feat | pos | pad] -> H), GA layer 1
-    WS_CASE(WS_DENSE_STORE, 72, 128, 128, 4, 2)
-    WS_CASE(WS_DENSE_STORE, 136, 256, 256, 4, 1)
-    WS_CASE(WS_DENSE_STORE, 264, 512, 256, 4, 1)
+    const int x3 = p.W_x3 != nullptr ? 1 : 0;
+    if (x3) T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_gemm: packed f16x3 weights must be 16-byte aligned");
+    if (mode == WS_DENSE_GROUPMAX) T2P_CHECK_ARG(p.M % 32 == 0, "ws_gemm: groupmax needs M %% 32 == 0");
+#define WS_CASE(MODE_, K_, N_, NW_, WN_, RT_, X3_)                                \
+    if (mode == MODE_ && K == K_ && N == N_ && x3 == X3_)                          \
+        return launch_cfg<K_, NW_, WN_, RT_, MODE_, X3_>(p, N_ / NW_, st);
+    // DynamicEdgeConv layer 2 (fp32)
+    WS_CASE(WS_EDGE_KNN, 256, 256, 256, 4, 1, 0)
+    // SA2 / SA3 layer-1 point tables ([feat | pos | zero pad] -> H) and GA layer 1
+    WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 0)
+    WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 0)
+    WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 0)
+    WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 1)
+    WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 1)
+    WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 1)
     // GA layer 2 + max over the 32 points of an object
-    WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1)
+    WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 0)
+    WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 1)
 #undef WS_CASE
-    set_error("ws_gemm: no instantiation for mode=%d K=%d N=%d", mode, K, N);
+    set_error("ws_gemm: no instantiation for mode=%d K=%d N=%d x3=%d", mode, K, N, x3);
     return T2P_E_UNSUPPORTED;
 }
 

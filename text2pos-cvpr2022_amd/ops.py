@@ -159,15 +159,18 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
         if t is not None:
             _need(t, name, torch.float32)
         setattr(w, name, 0 if t is None else t.data_ptr())
-    x3 = packed.get("sa_w2_x3")
-    if x3 is not None:
-        for t in x3:
-            _need(t, "sa_w2_x3", torch.int16)
-        w.sa_w2_x3 = (C.c_void_p * 3)(*[t.data_ptr() for t in x3])
-    g = packed.get("ga_w2_x3")
-    if g is not None:
-        _need(g, "ga_w2_x3", torch.int16)
-        w.ga_w2_x3 = g.data_ptr()
+    for name in ("sa_w2_x3", "sa_w1_x3"):
+        x3 = packed.get(name)
+        if x3 is not None:
+            for t in x3:
+                if t is not None:
+                    _need(t, name, torch.int16)
+            setattr(w, name, (C.c_void_p * 3)(*[0 if t is None else t.data_ptr() for t in x3]))
+    for name in ("ga_w1_x3", "ga_w2_x3"):
+        g = packed.get(name)
+        if g is not None:
+            _need(g, name, torch.int16)
+            setattr(w, name, g.data_ptr())
     return w
 
 
@@ -203,7 +206,7 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
             trace["fps_idx"].append(torch.empty((n_obj, nc), dtype=torch.uint8, device=dev))
             trace["nbr"].append(torch.empty((n_obj, nc, 32), dtype=torch.uint8, device=dev))
             trace["cnt"].append(torch.empty((n_obj, nc), dtype=torch.uint8, device=dev))
-            trace["sa_out"].append(torch.empty((n_obj * nc, c + 8), dtype=torch.float32, device=dev))
+            trace["sa_out"].append(torch.empty((n_obj * nc, c + 32), dtype=torch.float32, device=dev))
             nd = nc
         trace["features0"] = torch.empty((n_obj, 1024), dtype=torch.float32, device=dev)
         trace["features2"] = torch.empty((n_obj, 256), dtype=torch.float32, device=dev)

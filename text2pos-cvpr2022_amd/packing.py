@@ -59,7 +59,7 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
     oe, pn = model.object_encoder, model.object_encoder.pointnet
     p: Dict[str, object] = {}
     sa_w1, sa_b1, sa_w2, sa_b2 = [], [], [], []
-    for sa, kpad in ((pn.sa1, 6), (pn.sa2, 72), (pn.sa3, 136)):
+    for sa, kpad in ((pn.sa1, 6), (pn.sa2, 96), (pn.sa3, 160)):
         nn_ = sa.point_conv.local_nn
         w1, b1 = fold_linear_bn(nn_[0])
         w2, b2 = fold_linear_bn(nn_[1])
@@ -69,10 +69,12 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
         sa_b2.append(f32(b2).to(device))
     p.update(sa_w1=sa_w1, sa_b1=sa_b1, sa_w2=sa_w2, sa_b2=sa_b2)
     p["sa_w2_x3"] = [pack_f16x3(t).to(device) for t in sa_w2]
+    p["sa_w1_x3"] = [None] + [pack_f16x3(t).to(device) for t in sa_w1[1:]]
     w1, b1 = fold_linear_bn(pn.ga.mlp[0])
     w2, b2 = fold_linear_bn(pn.ga.mlp[1])
-    p.update(ga_w1=kmajor(w1, 264).to(device), ga_b1=f32(b1).to(device), ga_w2=kmajor(w2).to(device),
+    p.update(ga_w1=kmajor(w1, 288).to(device), ga_b1=f32(b1).to(device), ga_w2=kmajor(w2).to(device),
              ga_b2=f32(b2).to(device))
+    p.update(ga_w1_x3=pack_f16x3(p["ga_w1"]).to(device), ga_w2_x3=pack_f16x3(p["ga_w2"]).to(device))
     for name, lin in (("lin1", pn.lin1), ("lin2", pn.lin2)):
         p[name + "_w"] = kmajor(lin.weight.detach().double()).to(device)
         p[name + "_b"] = f32(lin.bias.detach().double()).to(device)
