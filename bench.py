@@ -27,7 +27,8 @@ CELLS_PER_GPU = 12000
 QUERIES_PER_GPU = 1000
 TOPK = 10
 SEED = 20220002  # 20220000 + config id
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA (no sparsity)
 DOMINANT = "ws_edge_sa_k256_n256"
 
 
@@ -116,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--chunk-objects", type=int, default=0)
+    ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
+                    help="arithmetic of the MFMA-heavy layers: f16x3 split-precision (default) or exact fp32 MFMA")
     args = ap.parse_args()
 
     import torch
@@ -148,7 +151,8 @@ def main():
 
     # ---- model: random-init weights of the reference architecture (no checkpoints available), BN stats randomised ----
     torch.manual_seed(1234)
-    model = t2p.CellRetrievalNetwork(S.LABELS + ["pad"], S.COLOR_NAMES, S.known_words(), S.default_args())
+    model = t2p.CellRetrievalNetwork(S.LABELS + ["pad"], S.COLOR_NAMES, S.known_words(), S.default_args(),
+                                     precision=args.precision)
     g = torch.Generator().manual_seed(4321)
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm1d):
@@ -212,22 +216,28 @@ def main():
         launches, total_ms = prof.get(DOMINANT, (0, 0.0))
         flops_per_step = 2.0 * 256 * 256 * e3
         achieved = (flops_per_step * args.steps) / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
+        peak = F16_MFMA_PEAK_TFLOPS if args.precision == "f16x3" else FP32_MFMA_PEAK_TFLOPS
         phases = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         out = {
             "metric": "cells+queries encoded/sec and top-k retrieval QPS, 256-pt cells, 12k-cell DB",
             "value": (n_cells_total + n_q_total) / (elapsed / args.steps),
             "unit": "cells+queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (encoders, fp32 MFMA) / f64 (similarity ranking, f64 MFMA)", "data": "synthetic",
+            "dtype": ("f16x3 (fp32 operands split hi+lo into fp16, 3 f16 MFMAs, fp32 accumulate; fp32-class error)"
+                      if args.precision == "f16x3" else "f32 (fp32 MFMA)") + " for the encoders / f64 MFMA for the ranking",
+            "data": "synthetic",
             "config": {"workload": (f"{args.cells} cells/GPU (n~U{{6..26}} objects x 256 pts, {n_obj} objects on rank 0) "
                                     f"+ {args.queries} queries/GPU (6 hints), embed_dim=256, top-{TOPK} over {n_cells_total} cells"),
                        "cells_total": n_cells_total, "queries_total": n_q_total, "objects_rank0": n_obj,
                        "parallelism": f"cells+queries sharded x{world}, 1 all-gather" if world > 1 else "single GPU"},
             "kernel_ms_per_step": phases,
-            "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": (achieved / FP32_MFMA_PEAK_TFLOPS) if achieved else None,
+            "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                          "traffic": None, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
-                         "algorithmic_flop_per_step": flops_per_step, "sa3_edge_rows_per_step": e3},
+                         "algorithmic_flop_per_step": flops_per_step, "sa3_edge_rows_per_step": e3,
+                         "note": ("algorithmic FLOPs = 2*256*256 per SA3 edge row; the f16x3 path executes 3 f16 MFMA FLOPs per "
+                                  "algorithmic FLOP, so its ceiling on this metric is peak/3 = 833 TFLOP/s"
+                                  if args.precision == "f16x3" else "exact fp32 MFMA path")},
             "host_generation_s": round(gen_s, 2),
         }
         if not args.no_cpu_baseline:

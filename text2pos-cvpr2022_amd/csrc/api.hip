@@ -103,7 +103,7 @@ size_t carve(Bump& b, int64_t n, int64_t nb, const t2p_cell_config& cfg, CellWs*
         w.gt.n_dense[l] = g.nd[l];
         w.gt.n_cent[l] = g.nc[l];
         w.gt.fps_idx[l] = b.take<uint8_t>(n * g.nc[l]);
-        w.gt.nbr[l] = b.take<uint8_t>(n * g.nc[l] * 32);
+        w.gt.nbr[l] = b.take<uint8_t>(n * g.nc[l] * 32);   // only filled when a trace asks for it
         w.gt.cnt[l] = b.take<uint8_t>(n * g.nc[l]);
         w.gt.rows[l] = b.take<uint16_t>(n * g.nc[l] * 33);
         w.gt.n_rows[l] = b.take<uint16_t>(n);
@@ -177,7 +177,13 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     const int D = cfg.embed_dim;
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st));
     ws.gt.self_loops = cfg.self_loops;
-    T2P_TRY(launch_sample_group(xyz, n, cfg.n_pts, cfg.radius, ws.gt, st));
+    {
+        GroupTables gt = ws.gt;
+        const bool want_nbr = tr != nullptr && (tr->nbr[0] || tr->nbr[1] || tr->nbr[2] || tr->cnt[0] || tr->cnt[1] || tr->cnt[2]);
+        if (!want_nbr)
+            for (int l = 0; l < 3; l++) gt.nbr[l] = gt.cnt[l] = nullptr;
+        T2P_TRY(launch_sample_group(xyz, n, cfg.n_pts, cfg.radius, gt, st));
+    }
 
     // ---- three set-abstraction levels -----------------------------------------------------------------------
     for (int l = 0; l < 3; l++) {

@@ -30,16 +30,39 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
     return s + zz;
 }
 
+// Cross-lane reductions on the VALU (DPP) instead of LDS-routed shuffles: the FPS loop is a chain of ~220 dependent
+// arg-max steps per object, so the reduction latency is what bounds it.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+// quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140:
+// after the four steps every lane of a 16-lane row holds the row's result; rows are combined through SGPRs.
+__device__ __forceinline__ float wave_max_f(float v) {
+    v = fmaxf(v, __int_as_float(dpp_i<0xB1>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x4E>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x141>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x140>(__float_as_int(v))));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_i<0xB1>(v));
+    v = min(v, dpp_i<0x4E>(v));
+    v = min(v, dpp_i<0x141>(v));
+    v = min(v, dpp_i<0x140>(v));
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
 // wave-wide arg-max of (d, idx): larger d wins, equal d -> smaller idx.  Result uniform across the wave.
 __device__ __forceinline__ void wave_argmax(float& d, int& idx) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        float od = __shfl_xor(d, off, 64);
-        int oi = __shfl_xor(idx, off, 64);
-        bool take = (od > d) || (od == d && oi < idx);
-        d = take ? od : d;
-        idx = take ? oi : idx;
-    }
+    const float m = wave_max_f(d);
+    idx = wave_min_i(d == m ? idx : 0x7fffffff);
+    d = m;
 }
 
 // One level: FPS of n_c samples among the n_d points in (px,py,pz) [LDS], then ball query.
@@ -99,14 +122,14 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
             unsigned long long m = __ballot(hit);
             int pos = count + __popcll(m & ((1ull << lane) - 1ull));
             if (hit && pos < kMaxNbr) {
-                nbr_lds[c * kMaxNbr + pos] = (uint8_t)i;
+                if (nbr_lds) nbr_lds[c * kMaxNbr + pos] = (uint8_t)i;
                 rows_lds[base + pos] = (uint16_t)((c << 8) | i);
             }
             count += __popcll(m);
         }
         const int kept = count < kMaxNbr ? count : kMaxNbr;
         if (lane == 0) {
-            cnt_lds[c] = (uint8_t)kept;
+            if (nbr_lds) cnt_lds[c] = (uint8_t)kept;
             if (self_loops) rows_lds[base + kept] = (uint16_t)(((c | 0x80) << 8) | c);
         }
         base += kept + (self_loops ? 1 : 0);
@@ -117,29 +140,37 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
 
 __global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
                                                      float r0, float r1, float r2, GroupTables gt) {
-    __shared__ float p0[3][kMaxPts];
-    __shared__ float p1[3][kMaxPts / 2];
-    __shared__ float p2[3][kMaxPts / 4];
-    __shared__ float p3[3][kMaxPts / 8];
-    __shared__ __attribute__((aligned(16))) uint8_t nbr_lds[(kMaxPts / 2) * kMaxNbr];
-    __shared__ __attribute__((aligned(16))) uint8_t cnt_lds[kMaxPts / 2];
-    __shared__ __attribute__((aligned(16))) uint8_t sel_lds[kMaxPts / 2];
-    __shared__ __attribute__((aligned(16))) uint16_t rows_lds[(kMaxPts / 2) * (kMaxNbr + 1)];
+    // dynamic LDS: coordinates of the 4 levels | FPS selection | compact rows | (only when the neighbour table is
+    // wanted: nbr + cnt) -- the production path leaves the table out, which lifts occupancy from 8 to 11 waves per CU
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* p0 = (float*)smem;                     // [3][256]
+    float* p1 = p0 + 3 * kMaxPts;                 // [3][128]
+    float* p2 = p1 + 3 * (kMaxPts / 2);           // [3][64]
+    float* p3 = p2 + 3 * (kMaxPts / 4);           // [3][32]
+    uint8_t* sel_lds = (uint8_t*)(p3 + 3 * (kMaxPts / 8));                 // [128]
+    uint16_t* rows_lds = (uint16_t*)(sel_lds + kMaxPts / 2);                 // [128*33]
+    const bool want_nbr = gt.nbr[0] != nullptr;
+    uint8_t* nbr_lds = want_nbr ? (uint8_t*)(rows_lds + (kMaxPts / 2) * (kMaxNbr + 1)) : nullptr;  // [128*32]
+    uint8_t* cnt_lds = want_nbr ? nbr_lds + (kMaxPts / 2) * kMaxNbr : nullptr;                       // [128]
     const int lane = threadIdx.x;
     for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
         const float* src = xyz + o * (int64_t)n_pts * 3;
         for (int i = lane; i < n_pts * 3; i += 64) {
             float v = src[i];
-            p0[i % 3][i / 3] = v;
+            p0[(i % 3) * kMaxPts + i / 3] = v;
         }
         __syncthreads();
-        float* pin[4][3] = {{p0[0], p0[1], p0[2]}, {p1[0], p1[1], p1[2]}, {p2[0], p2[1], p2[2]}, {p3[0], p3[1], p3[2]}};
+        float* pin[4][3] = {{p0, p0 + kMaxPts, p0 + 2 * kMaxPts},
+                            {p1, p1 + kMaxPts / 2, p1 + kMaxPts},
+                            {p2, p2 + kMaxPts / 4, p2 + kMaxPts / 2},
+                            {p3, p3 + kMaxPts / 8, p3 + kMaxPts / 4}};
         const float rr[3] = {r0 * r0, r1 * r1, r2 * r2};
 #pragma unroll
         for (int l = 0; l < 3; l++) {
             const int n_d = gt.n_dense[l], n_c = gt.n_cent[l];
-            // unused neighbour slots are zero-filled so that the table is deterministic
-            for (int i = lane; i < n_c * kMaxNbr / 4; i += 64) ((uint32_t*)nbr_lds)[i] = 0u;
+            if (want_nbr) {  // unused neighbour slots are zero-filled so that the table is deterministic
+                for (int i = lane; i < n_c * kMaxNbr / 4; i += 64) ((uint32_t*)nbr_lds)[i] = 0u;
+            }
             __syncthreads();
             int n_rows = 0;
             level(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
@@ -155,13 +186,13 @@ __global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ x
                 }
                 if (lane == 0) gt.n_rows[l][o] = (uint16_t)n_rows;
             }
-            uint8_t* g_nbr = gt.nbr[l] + o * (int64_t)n_c * kMaxNbr;
-            uint8_t* g_cnt = gt.cnt[l] + o * (int64_t)n_c;
             uint8_t* g_sel = gt.fps_idx[l] + o * (int64_t)n_c;
-            for (int i = lane; i < n_c * kMaxNbr; i += 64) g_nbr[i] = nbr_lds[i];
-            for (int i = lane; i < n_c; i += 64) {
-                g_cnt[i] = cnt_lds[i];
-                g_sel[i] = sel_lds[i];
+            for (int i = lane; i < n_c; i += 64) g_sel[i] = sel_lds[i];
+            if (want_nbr) {
+                uint8_t* g_nbr = gt.nbr[l] + o * (int64_t)n_c * kMaxNbr;
+                uint8_t* g_cnt = gt.cnt[l] + o * (int64_t)n_c;
+                for (int i = lane; i < n_c * kMaxNbr / 4; i += 64) ((uint32_t*)g_nbr)[i] = ((const uint32_t*)nbr_lds)[i];
+                for (int i = lane; i < n_c; i += 64) g_cnt[i] = cnt_lds[i];
             }
             __syncthreads();
         }
@@ -176,7 +207,13 @@ int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float 
     if (n_obj == 0) return 0;
     int64_t grid = n_obj < (int64_t)num_cus() * 64 ? n_obj : (int64_t)num_cus() * 64;
     ProfScope ps_("sample_group", st);
-    hipLaunchKernelGGL(k_sample_group, dim3((unsigned)grid), dim3(64), 0, st, xyz, n_obj, n_pts, radius[0],
+    const bool want_nbr = gt.nbr[0] != nullptr;
+    T2P_CHECK_ARG(!want_nbr || (gt.nbr[1] && gt.nbr[2] && gt.cnt[0] && gt.cnt[1] && gt.cnt[2]),
+                  "sample_group: neighbour tables must be given for all levels or none");
+    size_t lds = sizeof(float) * 3 * (kMaxPts + kMaxPts / 2 + kMaxPts / 4 + kMaxPts / 8) + kMaxPts / 2 +
+                 sizeof(uint16_t) * (kMaxPts / 2) * (kMaxNbr + 1);
+    if (want_nbr) lds += (kMaxPts / 2) * kMaxNbr + kMaxPts / 2;
+    hipLaunchKernelGGL(k_sample_group, dim3((unsigned)grid), dim3(64), lds, st, xyz, n_obj, n_pts, radius[0],
                        radius[1], radius[2], gt);
     T2P_CHECK_LAUNCH("sample_group");
     return 0;

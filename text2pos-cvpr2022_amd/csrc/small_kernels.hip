@@ -29,23 +29,33 @@ __global__ void k_sa1_point_table(const float* __restrict__ rgb, const float* __
     }
 }
 
-__global__ void k_pos_table(const float* __restrict__ src, int ld_src, int col0, const uint8_t* __restrict__ idx,
-                            int64_t n_obj, int n_dense, int n_cent, const float* __restrict__ wp, int H,
-                            float* __restrict__ out, float* __restrict__ tail, int ld_tail, int tail_col0) {
-    int64_t total = n_obj * n_cent * H;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        int64_t row = e / H;
-        int h = (int)(e - row * H);
-        int64_t o = row / n_cent;
-        int c = (int)(row - o * n_cent);
-        int loc = idx ? (int)idx[row] : c;
+// Centroid table B_i = W1p pos_i (one row of H floats per centroid) plus the [xyz | 0 x 29] tail of the centroid's SA
+// output row.  H/4 threads per row, 16-byte stores; pure write bandwidth (no per-element index arithmetic).
+__global__ __launch_bounds__(256) void k_pos_table(const float* __restrict__ src, int ld_src, int col0,
+                                                   const uint8_t* __restrict__ idx, int64_t n_rows, int n_dense,
+                                                   int n_cent, const float* __restrict__ wp, int H,
+                                                   float* __restrict__ out, float* __restrict__ tail, int ld_tail,
+                                                   int tail_col0) {
+    const int tpr = H >> 2;                 // threads per row
+    const int rpb = 256 / tpr;              // rows per block pass
+    const int hq = threadIdx.x % tpr;
+    f32x4 w0 = *(const f32x4*)(wp + hq * 4), w1 = *(const f32x4*)(wp + H + hq * 4), w2 = *(const f32x4*)(wp + 2 * H + hq * 4);
+    for (int64_t row = (int64_t)blockIdx.x * rpb + threadIdx.x / tpr; row < n_rows; row += (int64_t)gridDim.x * rpb) {
+        const int64_t o = row / n_cent;
+        const int loc = idx ? (int)idx[row] : (int)(row - o * n_cent);
         const float* p = src + (o * n_dense + loc) * (int64_t)ld_src + col0;
-        float acc = p[0] * wp[h];
-        acc = fmaf(p[1], wp[H + h], acc);
-        acc = fmaf(p[2], wp[2 * H + h], acc);
-        out[e] = acc;
-        // the centroid's [xyz | 0 x 29] tail of the SA output row (the next layer's GEMM reads [features | xyz | pad])
-        if (tail != nullptr && h < 32) tail[row * ld_tail + tail_col0 + h] = h < 3 ? p[h] : 0.f;
+        const float px = p[0], py = p[1], pz = p[2];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float a = px * w0[e];
+            a = fmaf(py, w1[e], a);
+            a = fmaf(pz, w2[e], a);
+            v[e] = a;
+        }
+        *(f32x4*)(out + row * H + hq * 4) = v;
+        if (tail != nullptr && hq < 8)
+            *(f32x4*)(tail + row * ld_tail + tail_col0 + hq * 4) = hq == 0 ? f32x4{px, py, pz, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -202,8 +212,10 @@ int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx,
                      hipStream_t st) {
     if (n_obj == 0) return 0;
     ProfScope ps_("pos_table", st);
-    hipLaunchKernelGGL(k_pos_table, dim3(grid_for(n_obj * n_cent * H, 256)), dim3(256), 0, st, src, ld_src, col0, idx,
-                       n_obj, n_dense, n_cent, wp, H, out, tail, ld_tail, tail_col0);
+    T2P_CHECK_ARG(H % 4 == 0 && H >= 32 && H <= 1024 && 256 % (H / 4) == 0, "pos_table: H=%d", H);
+    const int64_t n_rows = n_obj * n_cent;
+    hipLaunchKernelGGL(k_pos_table, dim3(grid_for(n_rows * (H / 4), 256)), dim3(256), 0, st, src, ld_src, col0, idx,
+                       n_rows, n_dense, n_cent, wp, H, out, tail, ld_tail, tail_col0);
     T2P_CHECK_LAUNCH("pos_table");
     return 0;
 }
