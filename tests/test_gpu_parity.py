@@ -183,6 +183,23 @@ def test_encode_cells_stagewise_vs_oracle(hip_model, oracle_model, vocab, self_l
     assert np.abs(got.cpu().numpy() - want.numpy()).max() < TOL
 
 
+def test_encode_cells_exact_fp32_path(oracle_model, vocab):
+    """precision="fp32" (v_mfma_f32_32x32x2_f32 everywhere) and the default f16x3 split path agree with the oracle."""
+    import text2pos_amd as t2p
+    from text2pos_amd import synthetic as S
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(61, 6)
+    want = oracle_model.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr).numpy()
+    outs = {}
+    for precision in ("fp32", "f16x3"):
+        m = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(), precision=precision)
+        m.load_state_dict(oracle_model.state_dict(), strict=True)
+        m = m.to(_dev()).eval()
+        with torch.no_grad():
+            outs[precision] = m.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr).cpu().numpy()
+        assert np.abs(outs[precision] - want).max() < TOL, precision
+    assert np.abs(outs["fp32"] - outs["f16x3"]).max() < 2e-5
+
+
 def test_encode_cells_golden(hip_model, golden_dir):
     z = np.load(os.path.join(golden_dir, "cell_encoder.npz"))
     with torch.no_grad():

@@ -125,6 +125,27 @@ def test_cell_weight_pack_shapes_and_edge_split():
     assert torch.allclose(got, want, atol=1e-5)
 
 
+def test_f16x3_split_reconstructs_fp32_weights():
+    """w = hi + lo/2048 with hi, lo fp16: the packed planes must reproduce w to ~2^-22 relative, and the product of two
+    split operands (dropping lo.lo) must match the fp64 product to ~1e-6 relative -- the basis of the f16x3 MFMA path."""
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(256, 128, generator=g) / 16).float()
+    packed = packing.pack_f16x3(w)
+    assert packed.shape == (2, 4, 16, 2, 32, 8) and packed.dtype == torch.int16
+    v = packed.view(torch.float16).float()
+    # undo the register layout: [plane][tile][step][half][lane][e] -> [k = half*128 + 8*step + e][n = 32*tile + lane]
+    planes = v.permute(0, 3, 2, 5, 1, 4).reshape(2, 256, 128)
+    rec = planes[0].double() + planes[1].double() / 2048.0
+    rel = ((rec - w.double()).abs() / w.double().abs().clamp_min(1e-3)).max().item()
+    assert rel < 2.0 ** -20
+    h = torch.relu(torch.randn(64, 256, generator=g))
+    hh = h.half()                                            # hi (round-to-nearest here; the kernel rounds toward zero)
+    hl = ((h - hh.float()) * 2048).half()
+    approx = (hh.double() @ planes[0].double()) + (hh.double() @ planes[1].double() + hl.double() @ planes[0].double()) / 2048
+    exact = h.double() @ w.double()
+    assert (approx - exact).abs().max().item() < 1e-6 * exact.abs().max().item() + 1e-7
+
+
 def test_state_dict_layout_matches_reference_keys(oracle_model):
     m = _model()
     sd = m.state_dict()

@@ -134,6 +134,8 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
         }
         base += kept + (self_loops ? 1 : 0);
     }
+    // pad the list to a multiple of 4 rows with the "no row" marker, so that consumers may fetch 4 rows per load
+    if (lane < 4) rows_lds[base + lane] = 0xFFFF;
     *n_rows_out = base;
     __syncthreads();
 }
@@ -148,9 +150,9 @@ __global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ x
     float* p2 = p1 + 3 * (kMaxPts / 2);           // [3][64]
     float* p3 = p2 + 3 * (kMaxPts / 4);           // [3][32]
     uint8_t* sel_lds = (uint8_t*)(p3 + 3 * (kMaxPts / 8));                 // [128]
-    uint16_t* rows_lds = (uint16_t*)(sel_lds + kMaxPts / 2);                 // [128*33]
+    uint16_t* rows_lds = (uint16_t*)(sel_lds + kMaxPts / 2);                 // [128*33 + 4]
     const bool want_nbr = gt.nbr[0] != nullptr;
-    uint8_t* nbr_lds = want_nbr ? (uint8_t*)(rows_lds + (kMaxPts / 2) * (kMaxNbr + 1)) : nullptr;  // [128*32]
+    uint8_t* nbr_lds = want_nbr ? (uint8_t*)(rows_lds + (kMaxPts / 2) * (kMaxNbr + 1) + 4) : nullptr;  // [128*32]
     uint8_t* cnt_lds = want_nbr ? nbr_lds + (kMaxPts / 2) * kMaxNbr : nullptr;                       // [128]
     const int lane = threadIdx.x;
     for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
@@ -180,7 +182,8 @@ __global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ x
                 uint16_t* g_rows16 = gt.rows[l] + o * (int64_t)maxr;
                 if ((maxr & 1) == 0) {  // every object's list starts 4-byte aligned: copy two rows per store
                     uint32_t* g_rows = (uint32_t*)g_rows16;
-                    for (int i = lane; i < (n_rows + 1) / 2; i += 64) g_rows[i] = ((const uint32_t*)rows_lds)[i];
+                    const int n_copy = n_rows + 4 < maxr ? n_rows + 4 : maxr;  // includes the 0xFFFF padding
+                    for (int i = lane; i < (n_copy + 1) / 2; i += 64) g_rows[i] = ((const uint32_t*)rows_lds)[i];
                 } else {
                     for (int i = lane; i < n_rows; i += 64) g_rows16[i] = rows_lds[i];
                 }
@@ -211,7 +214,7 @@ int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float 
     T2P_CHECK_ARG(!want_nbr || (gt.nbr[1] && gt.nbr[2] && gt.cnt[0] && gt.cnt[1] && gt.cnt[2]),
                   "sample_group: neighbour tables must be given for all levels or none");
     size_t lds = sizeof(float) * 3 * (kMaxPts + kMaxPts / 2 + kMaxPts / 4 + kMaxPts / 8) + kMaxPts / 2 +
-                 sizeof(uint16_t) * (kMaxPts / 2) * (kMaxNbr + 1);
+                 sizeof(uint16_t) * ((kMaxPts / 2) * (kMaxNbr + 1) + 4);
     if (want_nbr) lds += (kMaxPts / 2) * kMaxNbr + kMaxPts / 2;
     hipLaunchKernelGGL(k_sample_group, dim3((unsigned)grid), dim3(64), lds, st, xyz, n_obj, n_pts, radius[0],
                        radius[1], radius[2], gt);

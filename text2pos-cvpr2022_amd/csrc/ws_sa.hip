@@ -37,7 +37,7 @@ struct SaCfg {
     static constexpr int TR = WM * RT * 32;
     static constexpr int LDH = K + 4;
     static constexpr int HID_FLOATS = TR * LDH;
-    static constexpr int ACC_INTS = 8192;  // n_cent * N for all three levels (128x64, 64x128, 32x256)
+    static constexpr int ACC_INTS = 8192 + N;  // n_cent * N (128x64, 64x128, 32x256) + one dummy row for padding rows
     static constexpr int F4_PER_ROW = K / 4;
     static constexpr int TOTAL_F4 = TR * F4_PER_ROW;
     static constexpr int ITERS = TOTAL_F4 / NT;
@@ -165,44 +165,50 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
         };
         auto valid = [&](const BatchIt& it) { return it.gi < cnt; };
 
-        uint32_t meta_d[C::ITERS], meta_m[C::ITERS];  // row metadata for the batch being gathered / the one after
+        // Each thread stages ITERS consecutive rows (lr = (tid / F4_PER_ROW) * ITERS + k) at a fixed column quad, so its
+        // row metadata is ONE aligned vector load of ITERS u16.
+        static_assert(C::ITERS == 2 || C::ITERS == 4, "metadata vector is 4 or 8 bytes");
+        const int rgrp = (tid / C::F4_PER_ROW) * C::ITERS;   // first staged row of this thread inside the batch
+        const int c4 = tid % C::F4_PER_ROW;
+        typedef uint16_t metav __attribute__((ext_vector_type(C::ITERS)));
+        metav meta_d, meta_m;                                 // metadata of the batch being gathered / the one after
         f32x4 sa[C::ITERS], sb[C::ITERS];
 
-        // M: metadata of one batch -> registers (0xFFFF = padding row)
-        auto load_meta = [&](const BatchIt& it, uint32_t (&m)[C::ITERS]) {
-            const uint16_t* rows = p.rows + (int64_t)(ga + it.gi) * maxr;
+        // M: metadata of one batch -> registers (0xFFFF = padding row; lists are padded with 0xFFFF by the producer)
+        auto load_meta = [&](const BatchIt& it, metav& m) {
 #pragma unroll
-            for (int k = 0; k < C::ITERS; k++) {
-                const int lr = (k * NT + tid) / C::F4_PER_ROW;
-                const int r = it.r0 + lr;
-                m[k] = (valid(it) && r < it.n) ? (uint32_t)rows[r] : 0xFFFFu;
+            for (int k = 0; k < C::ITERS; k++) m[k] = 0xFFFF;
+            if (valid(it) && it.r0 + rgrp < it.n) {
+                const uint32_t off = (uint32_t)(ga + it.gi) * (uint32_t)maxr + (uint32_t)(it.r0 + rgrp);
+                m = *(const metav*)(p.rows + off);
+#pragma unroll
+                for (int k = 0; k < C::ITERS; k++)
+                    if (it.r0 + rgrp + k >= it.n) m[k] = 0xFFFF;
             }
         };
-        // D: gathers of the batch's A_j and B_i rows -> registers
-        auto load_data = [&](const BatchIt& it, const uint32_t (&m)[C::ITERS]) {
-            const int64_t g = ga + it.gi;
-            const int sb0 = valid(it) ? sbase[it.gi] : 0;
+        // D: gathers of the batch's A_j and B_i rows -> registers (32-bit element offsets from uniform bases)
+        auto load_data = [&](const BatchIt& it, const metav& m) {
+            const uint32_t g = (uint32_t)(ga + it.gi);
+            const uint32_t sb0 = valid(it) ? (uint32_t)sbase[it.gi] : 0u;
 #pragma unroll
             for (int k = 0; k < C::ITERS; k++) {
-                const int c4 = (k * NT + tid) % C::F4_PER_ROW;
                 sa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
                 sb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m[k] != 0xFFFFu) {
-                    const int src = m[k] & 0xFF, d = m[k] >> 8, dl = d & 127;
-                    const int64_t srow = (d & 0x80) ? (int64_t)(sb0 + src) : (g * p.n_dense + src);
-                    sa[k] = *(const f32x4*)(p.A + srow * K + c4 * 4);
-                    sb[k] = *(const f32x4*)(p.Bc + (g * nc + dl) * (int64_t)K + c4 * 4);
+                if (m[k] != 0xFFFF) {
+                    const uint32_t src = m[k] & 0xFF, d = m[k] >> 8, dl = d & 127;
+                    const uint32_t srow = (d & 0x80) ? (sb0 + src) : (g * (uint32_t)p.n_dense + src);
+                    sa[k] = *(const f32x4*)(p.A + (srow * (uint32_t)K + (uint32_t)c4 * 4u));
+                    sb[k] = *(const f32x4*)(p.Bc + ((g * (uint32_t)nc + dl) * (uint32_t)K + (uint32_t)c4 * 4u));
                 }
             }
         };
         // W: h = relu(A_j - B_i) -> LDS tile, plus the destination byte of every row
-        auto write_tile = [&](int buf, const uint32_t (&m)[C::ITERS]) {
+        auto write_tile = [&](int buf, const metav& m) {
             float* dst = hid + buf * C::HID_FLOATS;
             _Float16* dsth = hidh + buf * 2 * C::PLANE;
 #pragma unroll
             for (int k = 0; k < C::ITERS; k++) {
-                const int q = k * NT + tid;
-                const int lr = q / C::F4_PER_ROW, c4 = q % C::F4_PER_ROW;
+                const int lr = rgrp + k;
                 const f32x4 t = sa[k] - sb[k];
                 f32x4 v;
 #pragma unroll
@@ -220,7 +226,8 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                 } else {
                     *(f32x4*)(dst + lr * C::LDH + c4 * 4) = v;
                 }
-                if (c4 == 0) dstl[buf * C::TR + lr] = m[k] == 0xFFFFu ? (uint8_t)0xFF : (uint8_t)((m[k] >> 8) & 127);
+                // destination of the row; padding rows go to the accumulator's dummy row n_cent
+                if (c4 == 0) dstl[buf * C::TR + lr] = m[k] == 0xFFFF ? (uint8_t)nc : (uint8_t)((m[k] >> 8) & 127);
             }
         };
         // flush one finished object's accumulator (feature columns; the [xyz | 0 x 5] tail of the rows is written
@@ -243,8 +250,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
         load_meta(it_d, meta_m);
         load_data(it_c, meta_d);
         write_tile(0, meta_d);
-#pragma unroll
-        for (int k = 0; k < C::ITERS; k++) meta_d[k] = meta_m[k];
+        meta_d = meta_m;
         __syncthreads();
 
         int64_t flush_g = -1;
@@ -335,7 +341,9 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                         for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = a_nxt[rt][qi];
                 }
             }
-            // segmented max into the object's accumulator (runs of equal destination folded in registers first)
+            // max-aggregation: every accumulator row goes straight to its destination's LDS slot with an integer atomic
+            // max (non-returning; the signed-int max against +0 is also the ReLU).  No run detection, no branches:
+            // padding rows carry destination n_cent = the accumulator's dummy row.
             const int abuf = it_c.gi & 1;
             int* accb = acc_lds + abuf * C::ACC_INTS;
             const uint8_t* dl = dstl + buf * C::TR;
@@ -343,34 +351,18 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
             for (int rt = 0; rt < RT; rt++) {
                 const int trow0 = (wm * RT + rt) * 32;
                 if (it_c.r0 + trow0 >= it_c.n) continue;
-                int dq[16];
+                int doff[16];  // destination row offsets (ints) of this lane's 16 rows: 4 quads of 4 consecutive rows
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int b = dl[trow0 + 8 * (e >> 2) + 4 * h + (e & 3)];
-                    dq[e] = b == 0xFF ? -1 : b;
-                }
-                // Segmented max.  Rows are sorted by destination, so after a forward running-max pass the last row of
-                // every run holds the run's maximum and only those rows touch LDS.  No explicit ReLU: the accumulator is
-                // a signed-integer max against +0, which a negative float (negative as an integer) never beats.
-                bool same[16], is_end[16];
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t four = *(const uint32_t*)(dl + trow0 + 8 * q + 4 * h);
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    same[e] = e > 0 && dq[e] == dq[e - 1];
-                    is_end[e] = dq[e] >= 0 && (e == 15 || dq[e] != dq[e + 1]);
+                    for (int e = 0; e < 4; e++) doff[4 * q + e] = (int)((four >> (8 * e)) & 0xFF) * N;
                 }
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++) {
                     int* col = accb + wn * C::NTW * 32 + nt * 32 + l31;
-                    float v[16];
 #pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        v[e] = acc[rt][nt][e];
-                        if (e > 0) v[e] = same[e] ? fmaxf(v[e], v[e - 1]) : v[e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        if (is_end[e]) atomicMax(col + dq[e] * N, __float_as_int(v[e]));
-                    }
+                    for (int e = 0; e < 16; e++) atomicMax(col + doff[e], __float_as_int(acc[rt][nt][e]));
                 }
             }
             if (it_c.r0 + C::TR >= it_c.n) {  // last batch of this object
@@ -378,8 +370,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                 flush_buf = abuf;
             }
             if (valid(it_d)) write_tile((t + 1) & 1, meta_d);  // W(t+1)
-#pragma unroll
-            for (int k = 0; k < C::ITERS; k++) meta_d[k] = meta_m[k];
+            meta_d = meta_m;
             it_c = it_d;
             it_d = it_m;
             it_m = advance(it_m);
