@@ -12,6 +12,9 @@
 //     with double-buffered LDS staging tiles and one barrier per batch;
 //   * the per-object max accumulator is double-buffered in LDS too, so the finished object's [n_cent][C] block is
 //     written to HBM (and re-zeroed) underneath the MFMAs of the next object's first batch.
+#ifndef T2P_LDS_PREFETCH
+#define T2P_LDS_PREFETCH 1
+#endif
 #include "t2p_common.h"
 
 namespace t2p {
@@ -279,6 +282,45 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
             const int buf = t & 1;
             if constexpr (X3) {
                 const _Float16* hrow = hidh + buf * 2 * C::PLANE + ((wm * RT) * 32 + l31) * C::LDHH + h * (K / 2);
+#if T2P_LDS_PREFETCH
+                // operands of step s+1 are fetched before the MFMAs of step s (register double buffer); the scheduling
+                // barrier keeps hipcc from sinking the reads back to their first use
+                half8 a_hi[RT], a_lo[RT], n_hi[RT], n_lo[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    a_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH);
+                    a_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH);
+                }
+#pragma unroll
+                for (int s = 0; s < C::S16; s++) {
+                    if (s + 1 < C::S16) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; rt++) {
+                            n_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH + (s + 1) * 8);
+                            n_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH + (s + 1) * 8);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                        for (int nt = 0; nt < C::NTW; nt++) {
+                            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_hi[nt][s], acc[rt][nt], 0, 0, 0);
+                            accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_lo[nt][s], accx[rt][nt], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                        for (int nt = 0; nt < C::NTW; nt++)
+                            accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[rt], w_hi[nt][s], accx[rt][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        a_hi[rt] = n_hi[rt];
+                        a_lo[rt] = n_lo[rt];
+                    }
+                }
+#else
 #pragma unroll
                 for (int s = 0; s < C::S16; s++) {
                     half8 a_hi[RT], a_lo[RT];
@@ -300,6 +342,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                         for (int nt = 0; nt < C::NTW; nt++)
                             accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[rt], w_hi[nt][s], accx[rt][nt], 0, 0, 0);
                 }
+#endif
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
