@@ -245,12 +245,24 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.ldw = 512;
         p.bias = W.ga_b1;
         p.out = ws.gh;
+        // f16x3: GA1 hands its ReLU output to GA2 already split into fp16 hi / lo planes (same bytes as fp32), so the
+        // eight column-slice workgroups of GA2 stage it with plain 16-byte copies instead of re-splitting it 8 times
+        _Float16* gh_hi = (_Float16*)ws.gh;
+        _Float16* gh_lo = gh_hi + (size_t)n * g.nc[2] * 512;
+        if (cfg.precision == 1) {
+            p.out_hi = gh_hi;
+            p.out_lo = gh_lo;
+        }
         p.ldo = 512;
         p.relu = 1;
         p.M = n * g.nc[2];
         T2P_TRY(launch_ws(WS_DENSE_STORE, Geo::LD[2], 512, p, st));
         WsParams q{};
         q.A = ws.gh;
+        if (cfg.precision == 1) {
+            q.A_hi = gh_hi;
+            q.A_lo = gh_lo;
+        }
         q.lda = 512;
         q.W = W.ga_w2;
         q.W_x3 = cfg.precision == 1 ? W.ga_w2_x3 : nullptr;

@@ -107,6 +107,11 @@ struct WsParams {
     const float* W;    // [K][ldw] k-major weights (BN folded)
     int ldw;
     const void* W_x3;  // nullptr, or the packed f16x3 register image of the whole [K][ldw] matrix (dense modes)
+    // f16x3 only: activations may travel between two dense kernels already split into fp16 hi / lo planes
+    const void* A_hi;  // non-null: A is given as two [M][lda] fp16 planes (no conversion while staging)
+    const void* A_lo;
+    void* out_hi;      // non-null (DENSE_STORE): write the result as two [M][ldo] fp16 planes instead of fp32
+    void* out_lo;
     const float* bias; // [N]
     float* out;        // dense_store: [M, ldo]; groupmax: [n_groups, ldo]; edge: [n_dst, ldo]
     int ldo;

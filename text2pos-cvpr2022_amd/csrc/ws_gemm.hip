@@ -60,7 +60,7 @@ struct WsCfg {
     static_assert(NW % (32 * WN) == 0, "NW must split into 32-column tiles per wave");
 };
 
-template <int K, int NW, int WN, int RT, int MODE, int X3>
+template <int K, int NW, int WN, int RT, int MODE, int X3, int SPLIT_IO>
 __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
     using C = WsCfg<K, NW, WN, RT, MODE, X3>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -128,12 +128,20 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
             const int r = r0 + lr;
             sa[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (C::EDGE) sb[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (((C::TOTAL_F4 % 256) == 0 || q < C::TOTAL_F4) && r < n_rows) {
+            if (((C::TOTAL_F4 % 256) == 0 || q < C::TOTAL_F4) && (r < n_rows || SPLIT_IO == 1)) {
                 if constexpr (C::EDGE) {
                     const int src = rows_src[r];
                     const int64_t dst = g * 32 + rows_dst[r];
                     sa[it] = *(const f32x4*)(p.A + (int64_t)src * p.lda + c4 * 4);
                     sb[it] = *(const f32x4*)(p.Bc + dst * K + c4 * 4);
+                } else if constexpr (SPLIT_IO == 1) {
+                    // A arrives as fp16 hi / lo planes: thread chunk q = 16 bytes = 8 halves of one plane row
+                    constexpr int CH_PER_PLANE = C::TR * (K / 8);
+                    const int pl = q / CH_PER_PLANE, idx = q % CH_PER_PLANE;
+                    const int prow = idx / (K / 8), c8 = idx % (K / 8);
+                    const _Float16* base = (const _Float16*)(pl ? p.A_lo : p.A_hi);
+                    sa[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (prow < n_rows) sa[it] = *(const f32x4*)(base + (g * C::TR + prow) * (int64_t)p.lda + c8 * 8);
                 } else {
                     sa[it] = *(const f32x4*)(p.A + (g * C::TR + r) * (int64_t)p.lda + c4 * 4);
                 }
@@ -153,7 +161,12 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(t[e], 0.f);
             }
-            if constexpr (X3) {
+            if constexpr (X3 && SPLIT_IO == 1) {
+                constexpr int CH_PER_PLANE = C::TR * (K / 8);
+                const int pl = q / CH_PER_PLANE, idx = q % CH_PER_PLANE;
+                const int prow = idx / (K / 8), c8 = idx % (K / 8);
+                *(f32x4*)(hidh + buf * 2 * C::PLANE + pl * C::PLANE + prow * C::LDHH + c8 * 8) = sa[it];
+            } else if constexpr (X3) {
                 _Float16* dsth = hidh + buf * 2 * C::PLANE;
                 const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                 const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.f, (v[1] - (float)h01[1]) * 2048.f);
@@ -185,14 +198,25 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
 #pragma unroll
                     for (int e = 0; e < 16; e++) accx[rt][nt][e] = 0.f;
             const _Float16* hrow = hidh + buf * 2 * C::PLANE + ((wm * RT) * 32 + l31) * C::LDHH + h * (K / 2);
+            // operands of step s+1 are fetched before the MFMAs of step s (register double buffer); the scheduling
+            // barriers keep hipcc from sinking the reads back to their first use (one wave per SIMD here: nothing else
+            // would cover the LDS latency)
+            half8 a_hi[RT], a_lo[RT], n_hi[RT], n_lo[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                a_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH);
+                a_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH);
+            }
 #pragma unroll
             for (int s = 0; s < C::S16; s++) {
-                half8 a_hi[RT], a_lo[RT];
+                if (s + 1 < C::S16) {
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-                    a_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH + s * 8);
-                    a_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH + s * 8);
+                    for (int rt = 0; rt < RT; rt++) {
+                        n_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH + (s + 1) * 8);
+                        n_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH + (s + 1) * 8);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -205,6 +229,12 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
 #pragma unroll
                     for (int nt = 0; nt < C::NTW; nt++)
                         accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[rt], w_hi[nt][s], accx[rt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    a_hi[rt] = n_hi[rt];
+                    a_lo[rt] = n_lo[rt];
+                }
             }
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
@@ -262,7 +292,17 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
                             const int r = trow0 + (e & 3) + 8 * (e >> 2) + 4 * h;
                             float v = acc[rt][nt][e];
                             if (p.relu) v = fmaxf(v, 0.f);
-                            if (r < n_rows) p.out[(g * C::TR + r) * (int64_t)p.ldo + slice * NW + lcol] = v;
+                            if constexpr (SPLIT_IO == 2) {  // hand the activations on already split into fp16 hi / lo
+                                const fp16x2 hv = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
+                                const fp16x2 lv = __builtin_amdgcn_cvt_pkrtz((v - (float)hv[0]) * 2048.f, 0.f);
+                                const int64_t o = (g * C::TR + r) * (int64_t)p.ldo + slice * NW + lcol;
+                                if (r < n_rows) {
+                                    ((__fp16*)p.out_hi)[o] = hv[0];
+                                    ((__fp16*)p.out_lo)[o] = lv[0];
+                                }
+                            } else {
+                                if (r < n_rows) p.out[(g * C::TR + r) * (int64_t)p.ldo + slice * NW + lcol] = v;
+                            }
                         }
                     } else {  // max over each 32-row tile = one object (ReLU = starting the max at 0)
                         float m = 0.f;
@@ -359,10 +399,10 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
     }
 }
 
-template <int K, int NW, int WN, int RT, int MODE, int X3>
+template <int K, int NW, int WN, int RT, int MODE, int X3, int SPLIT_IO>
 int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
     using C = WsCfg<K, NW, WN, RT, MODE, X3>;
-    auto kern = k_ws<K, NW, WN, RT, MODE, X3>;
+    auto kern = k_ws<K, NW, WN, RT, MODE, X3, SPLIT_IO>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -396,27 +436,33 @@ int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
 // mode DENSE_STORE: out[M][ldo] = act(A[M][K] W + b);  DENSE_GROUPMAX: out[M/32][ldo] = max over each 32-row group
 // (M = 32 * groups);  EDGE_KNN: see WsParams.
 int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
-    T2P_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && (p.lda % 4) == 0, "ws_gemm: A must be 16-byte aligned, lda %% 4 == 0");
+    T2P_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.A_hi | (uintptr_t)p.A_lo) & 15) == 0 && (p.lda % 4) == 0,
+                  "ws_gemm: A must be 16-byte aligned, lda %% 4 == 0");
     const int x3 = p.W_x3 != nullptr ? 1 : 0;
     if (x3) T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_gemm: packed f16x3 weights must be 16-byte aligned");
     if (mode == WS_DENSE_GROUPMAX) T2P_CHECK_ARG(p.M % 32 == 0, "ws_gemm: groupmax needs M %% 32 == 0");
-#define WS_CASE(MODE_, K_, N_, NW_, WN_, RT_, X3_)                                \
-    if (mode == MODE_ && K == K_ && N == N_ && x3 == X3_)                          \
-        return launch_cfg<K_, NW_, WN_, RT_, MODE_, X3_>(p, N_ / NW_, st);
+    // split_io: 0 = fp32 in / fp32 out, 1 = fp16 hi/lo planes in, 2 = fp16 hi/lo planes out (f16x3 only)
+    const int split_io = p.A_hi != nullptr ? 1 : (p.out_hi != nullptr ? 2 : 0);
+    T2P_CHECK_ARG(split_io == 0 || x3 == 1, "ws_gemm: split fp16 activations need the f16x3 path");
+    if (split_io == 1) T2P_CHECK_ARG(p.A_lo != nullptr && p.lda % 8 == 0, "ws_gemm: split input needs both planes, lda %% 8 == 0");
+    if (split_io == 2) T2P_CHECK_ARG(p.out_lo != nullptr, "ws_gemm: split output needs both planes");
+#define WS_CASE(MODE_, K_, N_, NW_, WN_, RT_, X3_, SIO_)                                      \
+    if (mode == MODE_ && K == K_ && N == N_ && x3 == X3_ && split_io == SIO_)                  \
+        return launch_cfg<K_, NW_, WN_, RT_, MODE_, X3_, SIO_>(p, N_ / NW_, st);
     // DynamicEdgeConv layer 2 (fp32)
-    WS_CASE(WS_EDGE_KNN, 256, 256, 256, 4, 1, 0)
+    WS_CASE(WS_EDGE_KNN, 256, 256, 256, 4, 1, 0, 0)
     // SA2 / SA3 layer-1 point tables ([feat | pos | zero pad] -> H) and GA layer 1
-    WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 0)
-    WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 0)
-    WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 0)
-    WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 1)
-    WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 1)
-    WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 1)
+    WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 0, 0)
+    WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 0, 0)
+    WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 0, 0)
+    WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 1, 0)
+    WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 1, 0)
+    WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 1, 2)
     // GA layer 2 + max over the 32 points of an object
-    WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 0)
-    WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 1)
+    WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 0, 0)
+    WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 1, 1)
 #undef WS_CASE
-    set_error("ws_gemm: no instantiation for mode=%d K=%d N=%d x3=%d", mode, K, N, x3);
+    set_error("ws_gemm: no instantiation for mode=%d K=%d N=%d x3=%d split_io=%d", mode, K, N, x3, split_io);
     return T2P_E_UNSUPPORTED;
 }
 
