@@ -67,13 +67,14 @@ __device__ __forceinline__ void wave_argmax(float& d, int& idx) {
 
 // One level: FPS of n_c samples among the n_d points in (px,py,pz) [LDS], then ball query.
 // sel (LDS, n_c bytes) receives the FPS indices; the sampled coordinates are written to (qx,qy,qz).
+template <int PPL>  // points per lane: ceil(n_d / 64)
 __device__ void level(const float* px, const float* py, const float* pz, int n_d, int n_c, float r2,
                       uint8_t* sel, float* qx, float* qy, float* qz, uint8_t* nbr_lds, uint8_t* cnt_lds,
                       uint16_t* rows_lds, int self_loops, int* n_rows_out) {
     const int lane = threadIdx.x;
-    float x[4], y[4], z[4], mind[4];
+    float x[PPL], y[PPL], z[PPL], mind[PPL];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < PPL; j++) {
         int i = lane + 64 * j;
         bool v = i < n_d;
         x[j] = v ? px[i] : 0.f;
@@ -88,7 +89,7 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
         float bd = -1.f;
         int bi = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < PPL; j++) {
             int i = lane + 64 * j;
             if (i < n_d) {
                 float d = dist2(x[j], y[j], z[j], cx, cy, cz);
@@ -116,7 +117,7 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
         float cx = qx[c], cy = qy[c], cz = qz[c];
         int count = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < PPL; j++) {
             int i = lane + 64 * j;
             bool hit = (i < n_d) && (dist2(x[j], y[j], z[j], cx, cy, cz) < r2);
             unsigned long long m = __ballot(hit);
@@ -175,8 +176,15 @@ __global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ x
             }
             __syncthreads();
             int n_rows = 0;
-            level(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
-                  pin[l + 1][2], nbr_lds, cnt_lds, rows_lds, gt.self_loops, &n_rows);
+            if (n_d > 128)
+                level<4>(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
+                         pin[l + 1][2], nbr_lds, cnt_lds, rows_lds, gt.self_loops, &n_rows);
+            else if (n_d > 64)
+                level<2>(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
+                         pin[l + 1][2], nbr_lds, cnt_lds, rows_lds, gt.self_loops, &n_rows);
+            else
+                level<1>(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
+                         pin[l + 1][2], nbr_lds, cnt_lds, rows_lds, gt.self_loops, &n_rows);
             if (gt.rows[l] != nullptr) {
                 const int maxr = n_c * (kMaxNbr + 1);
                 uint16_t* g_rows16 = gt.rows[l] + o * (int64_t)maxr;
