@@ -218,6 +218,19 @@ def main():
         achieved = (flops_per_step * args.steps) / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
         peak = F16_MFMA_PEAK_TFLOPS if args.precision == "f16x3" else FP32_MFMA_PEAK_TFLOPS
         phases = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        # HBM traffic of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this command;
+        # bench.py cannot host rocprofv3 itself): newest profiles/*_pmc_traffic.json, kernel k_ws_sa<256, 256, ...>
+        traffic = None
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+            if files and args.precision == "f16x3" and args.cells == CELLS_PER_GPU:
+                kern = json.load(open(files[-1]))["kernels"]
+                key = [k for k in kern if k.startswith("k_ws_sa<256, 256")]
+                if key:
+                    traffic = kern[key[0]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "cells+queries encoded/sec and top-k retrieval QPS, 256-pt cells, 12k-cell DB",
             "value": (n_cells_total + n_q_total) / (elapsed / args.steps),
@@ -233,7 +246,7 @@ def main():
             "kernel_ms_per_step": phases,
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
-                         "traffic": None, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
+                         "traffic": traffic, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
                          "algorithmic_flop_per_step": flops_per_step, "sa3_edge_rows_per_step": e3,
                          "note": ("algorithmic FLOPs = 2*256*256 per SA3 edge row; the f16x3 path executes 3 f16 MFMA FLOPs per "
                                   "algorithmic FLOP, so its ceiling on this metric is peak/3 = 833 TFLOP/s"
