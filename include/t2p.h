@@ -108,7 +108,7 @@ typedef struct t2p_cell_config {
     int32_t use_position;
     int32_t self_loops;        /* 1 = PyG PointConv(add_self_loops=True) semantics (upstream default), 0 = none */
     int32_t knn_k;             /* DynamicEdgeConv k (cell_retrieval.py:47); 8 */
-    int32_t variation;         /* args.variation (cell_retrieval.py:45-54); only 0 (max aggregation) is built */
+    int32_t variation;         /* args.variation (cell_retrieval.py:45-54): 0 = max, 1 = mean aggregation + mean pool */
     float radius[3];           /* SA ball radii (pointnet2.py:57-59); 0.2, 0.3, 0.4 */
     int32_t chunk_objects;     /* objects processed per internal chunk (whole cells); 0 = default */
     int32_t precision;         /* 0 = fp32 MFMA (exact fp32 fma chains); 1 = f16x3 split-precision MFMA with fp32

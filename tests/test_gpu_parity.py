@@ -200,6 +200,27 @@ def test_encode_cells_exact_fp32_path(oracle_model, vocab):
     assert np.abs(outs["fp32"] - outs["f16x3"]).max() < 2e-5
 
 
+def test_encode_cells_variation1_mean_aggregation(vocab):
+    """args.variation = 1: DynamicEdgeConv(aggr="mean") + global_mean_pool (models/cell_retrieval.py:50-54,100-103)."""
+    import weights as W
+    import text2pos_amd as t2p
+    from oracle import model as OM
+    from text2pos_amd import synthetic as S
+    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(variation=1)).eval()
+    W.fill_state_dict(om, 11)
+    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(variation=1))
+    hm.load_state_dict(om.state_dict(), strict=True)
+    hm = hm.to(_dev()).eval()
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(71, 9)
+    # cells with fewer than 8 objects exercise the "fewer than k neighbours" mean
+    cell_ptr = np.array([0, 3, 4, 11] + list(cell_ptr[1:] + 0)[0:0], dtype=np.int32)
+    n = int(cell_ptr[-1])
+    want = om.encode_objects_packed(xyz[:n], rgb[:n], center[:n], mean_rgb[:n], cell_ptr).numpy()
+    with torch.no_grad():
+        got = hm.encode_objects_packed(*_to_dev(xyz[:n], rgb[:n], center[:n], mean_rgb[:n]), cell_ptr).cpu().numpy()
+    assert np.abs(got - want).max() < TOL
+
+
 def test_encode_cells_golden(hip_model, golden_dir):
     z = np.load(os.path.join(golden_dir, "cell_encoder.npz"))
     with torch.no_grad():

@@ -145,8 +145,10 @@ int check_cfg(const t2p_cell_config* cfg) {
         set_error("encode_cells: embed_dim=%d not built (256)", cfg->embed_dim);
         return T2P_E_UNSUPPORTED;
     }
-    if (cfg->variation != 0) {
-        set_error("encode_cells: variation=%d not built (0 = max aggregation)", cfg->variation);
+    T2P_CHECK_ARG(cfg->variation == 0 || cfg->variation == 1, "encode_cells: variation=%d (0 = max, 1 = mean)",
+                  cfg->variation);
+    if (cfg->variation == 1 && cfg->knn_k != 8) {
+        set_error("encode_cells: variation=1 (mean aggregation) is built for knn_k = 8 only, got %d", cfg->knn_k);
         return T2P_E_UNSUPPORTED;
     }
     T2P_CHECK_ARG(cfg->pointnet_features >= 0 && cfg->pointnet_features <= 2, "encode_cells: pointnet_features=%d",
@@ -321,9 +323,10 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.knn_idx = ws.knn;
         p.knn_k = cfg.knn_k;
         p.n_dst = n;
+        p.mean = cfg.variation == 1;  // cell_retrieval.py:50-54: DynamicEdgeConv(aggr="mean") + global_mean_pool
         T2P_TRY(launch_ws(WS_EDGE_KNN, D, D, p, st));
     }
-    T2P_TRY(launch_segmax(ws.x1, D, ws.seg_ptr, (int)nb, ws.pool, 0, st));
+    T2P_TRY(launch_segmax(ws.x1, D, ws.seg_ptr, (int)nb, ws.pool, cfg.variation == 1, st));
     T2P_TRY(launch_gemm(ws.pool, D, W.lin_w1, W.lin_b1, ws.l1, D, 0, nb, D, D, 1, st));
     T2P_TRY(launch_gemm(ws.l1, D, W.lin_w2, W.lin_b2, ws.l2, D, 0, nb, D, D, 1, st));
     T2P_TRY(launch_rownorm(ws.l2, D, nb, D, out, D, 0, st));

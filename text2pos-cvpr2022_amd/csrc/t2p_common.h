@@ -122,6 +122,7 @@ struct WsParams {
     const int32_t* knn_idx; // [n_dst, knn_k] (-1 = absent)
     int knn_k;
     int64_t n_dst;
+    int mean;               // 0 = max aggregation, 1 = mean (needs knn_k == 8)
 };
 int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st);
 

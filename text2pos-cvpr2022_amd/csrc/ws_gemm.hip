@@ -131,9 +131,11 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
             if (((C::TOTAL_F4 % 256) == 0 || q < C::TOTAL_F4) && (r < n_rows || SPLIT_IO == 1)) {
                 if constexpr (C::EDGE) {
                     const int src = rows_src[r];
-                    const int64_t dst = g * 32 + rows_dst[r];
-                    sa[it] = *(const f32x4*)(p.A + (int64_t)src * p.lda + c4 * 4);
-                    sb[it] = *(const f32x4*)(p.Bc + dst * K + c4 * 4);
+                    const int dl = rows_dst[r];
+                    if (dl != 0xFF) {  // 0xFF = empty neighbour slot (mean aggregation keeps k slots per destination)
+                        sa[it] = *(const f32x4*)(p.A + (int64_t)src * p.lda + c4 * 4);
+                        sb[it] = *(const f32x4*)(p.Bc + (g * 32 + dl) * K + c4 * 4);
+                    }
                 } else if constexpr (SPLIT_IO == 1) {
                     // A arrives as fp16 hi / lo planes: thread chunk q = 16 bytes = 8 halves of one plane row
                     constexpr int CH_PER_PLANE = C::TR * (K / 8);
@@ -334,12 +336,15 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
                 for (int i = 1; i <= 32; i++) { s += scan[i]; scan[i] = s; }
             }
             __syncthreads();
-            const int n_rows = scan[32];
+            // max: rows = the valid neighbours, compacted; mean (knn_k == 8): exactly 8 slots per destination so that a
+            // destination's rows are one aligned 8-row group of a tile and its sum has a fixed, deterministic order
+            const int n_rows = p.mean ? nd * 8 : scan[32];
             if (tid < nd) {
-                int off = scan[tid];
+                int off = p.mean ? tid * 8 : scan[tid];
                 for (int e = 0; e < p.knn_k; e++) {
                     int j = p.knn_idx[(d0 + tid) * p.knn_k + e];
                     if (j >= 0) { rows_src[off] = j; rows_dst[off] = (uint8_t)tid; off++; }
+                    else if (p.mean) { rows_src[off] = 0; rows_dst[off] = 0xFF; off++; }
                 }
             }
             for (int i = tid; i < kAccFloats; i += 256) acc_lds[i] = 0;
@@ -361,6 +366,30 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
                 for (int rt = 0; rt < RT; rt++) {
                     const int trow0 = bt * C::TR + (wm * RT + rt) * 32;
                     if (trow0 >= n_rows) continue;
+                    if (p.mean) {  // DynamicEdgeConv(aggr="mean"): sum of ReLU'd rows / valid neighbours, fixed order
+#pragma unroll
+                        for (int nt = 0; nt < C::NTW; nt++) {
+                            const int lcol = wn * C::NTW * 32 + nt * 32 + l31;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const int d = trow0 / 8 + q;  // destination inside the group
+                                float sum = 0.f;
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int r = trow0 + 8 * q + 4 * h + e;
+                                    const bool ok = r < n_rows && rows_dst[r] != 0xFF;
+                                    sum += ok ? fmaxf(acc[rt][nt][4 * q + e], 0.f) : 0.f;
+                                }
+                                const float other = __shfl_xor(sum, 32, 64);
+                                sum = h == 0 ? sum + other : other + sum;  // rows 0-3 first, then rows 4-7
+                                if (h == 0 && d < nd) {
+                                    const int cnt = scan[d + 1] - scan[d];
+                                    acc_lds[d * NW + lcol] = __float_as_int(cnt > 0 ? sum / (float)cnt : 0.f);
+                                }
+                            }
+                        }
+                        continue;
+                    }
                     int dd[16];
                     bool same[16], is_end[16];
 #pragma unroll
