@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 1
+#define T2P_ABI_VERSION 2
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -97,6 +97,10 @@ typedef struct t2p_cell_weights {
     const void* ga_w2_x3;
     const void* sa_w1_x3[3]; /* levels 1 and 2 only (level 0 has K = 6 and runs on the VALU); [0] is ignored */
     const void* ga_w1_x3;
+    /* ObjectEncoder.class_embedding / color_embedding (object_encoder.py:31-38), used by the --class_embed /
+     * --color_embed ablations only: [n_classes + 1][D], [8][D] */
+    const float* class_embedding;
+    const float* color_embedding;
 } t2p_cell_weights;
 
 typedef struct t2p_cell_config {
@@ -113,6 +117,14 @@ typedef struct t2p_cell_config {
     int32_t chunk_objects;     /* objects processed per internal chunk (whole cells); 0 = default */
     int32_t precision;         /* 0 = fp32 MFMA (exact fp32 fma chains); 1 = f16x3 split-precision MFMA with fp32
                                   accumulation (hi.hi + hi.lo + lo.hi), same 1e-4 parity bar, 5.3x the MFMA rate */
+    /* ground-truth embedding ablations (training/args.py:60-61, object_encoder.py:74-84,103-120): when class_embed
+     * is set the PointNet++ is skipped and the "class" feature is F.normalize(class_embedding[class_idx]); when
+     * color_embed is set the "color" feature is F.normalize(color_embedding[color_idx]).  Index arrays are DEVICE
+     * int32 [n_obj] (NULL when the flag is 0). */
+    int32_t class_embed;
+    int32_t color_embed;
+    const int32_t* class_idx;
+    const int32_t* color_idx;
 } t2p_cell_config;
 
 /* Optional stage outputs for parity tests (any member may be NULL).  Layouts:

@@ -140,20 +140,30 @@ class OracleObjectEncoder(nn.Module):
         self.mlp_pointnet = mlp([dim, embed_dim])
         self.mlp_merge = mlp([len(args.use_features) * embed_dim, embed_dim])
 
-    def forward(self, object_points, mean_rgb, center, trace=None):
+    def forward(self, object_points, mean_rgb, center, trace=None, class_idx=None, color_idx=None):
         """object_points: list (one per cell) of Batch(x=rgb, pos=xyz, batch); mean_rgb/center [Nobj,3]
-        (= obj.get_color_rgb() / obj.get_center(), models/object_encoder.py:121-131)."""
+        (= obj.get_color_rgb() / obj.get_center(), models/object_encoder.py:121-131); class_idx / color_idx [Nobj]
+        for the --class_embed / --color_embed ablations (models/object_encoder.py:74-84,103-120)."""
         key = "features%d" % self.args.pointnet_features
-        if "color" not in self.args.use_features:
-            for b in object_points:
-                b.x[:] = 0.0
-        feats = [getattr(self.pointnet(b, trace), key) for b in object_points]
-        feats = self.mlp_pointnet(torch.cat(feats, dim=0))
+        class_embed = bool(getattr(self.args, "class_embed", False))
+        color_embed = bool(getattr(self.args, "color_embed", False))
+        if not class_embed:  # models/object_encoder.py:86
+            if "color" not in self.args.use_features:
+                for b in object_points:
+                    b.x[:] = 0.0
+            feats = [getattr(self.pointnet(b, trace), key) for b in object_points]
+            feats = self.mlp_pointnet(torch.cat(feats, dim=0))
         parts = []
         if "class" in self.args.use_features:
-            parts.append(F.normalize(feats, dim=-1))
+            if class_embed:
+                parts.append(F.normalize(self.class_embedding(torch.as_tensor(class_idx).long()), dim=-1))
+            else:
+                parts.append(F.normalize(feats, dim=-1))
         if "color" in self.args.use_features:
-            parts.append(F.normalize(self.color_encoder(mean_rgb.float()), dim=-1))
+            if color_embed:
+                parts.append(F.normalize(self.color_embedding(torch.as_tensor(color_idx).long()), dim=-1))
+            else:
+                parts.append(F.normalize(self.color_encoder(mean_rgb.float()), dim=-1))
         if "position" in self.args.use_features:
             parts.append(F.normalize(self.pos_encoder(center.float()), dim=-1))
         if len(parts) > 1:
@@ -177,7 +187,7 @@ class OracleCellRetrieval(nn.Module):
         return F.normalize(self.language_encoder(descriptions))
 
     @torch.no_grad()
-    def encode_objects_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, trace=None):
+    def encode_objects_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, trace=None, class_idx=None, color_idx=None):
         """xyz/rgb [Nobj,P,3] fp32 (already FixedPoints+NormalizeScale'd), center/mean_rgb [Nobj,3], cell_ptr [B+1]."""
         xyz, rgb = torch.as_tensor(xyz).float(), torch.as_tensor(rgb).float()
         cell_ptr = [int(v) for v in cell_ptr]
@@ -190,7 +200,7 @@ class OracleCellRetrieval(nn.Module):
                                      batch=torch.arange(n).repeat_interleave(p)))
             batch += [c] * n
         batch = torch.tensor(batch, dtype=torch.long)
-        emb = self.object_encoder(batches, torch.as_tensor(mean_rgb), torch.as_tensor(center), trace)
+        emb = self.object_encoder(batches, torch.as_tensor(mean_rgb), torch.as_tensor(center), trace, class_idx, color_idx)
         if trace is not None:
             trace.append(dict(object_embeddings=emb.detach().clone()))
         emb = F.normalize(emb, dim=-1)

@@ -221,6 +221,43 @@ def test_encode_cells_variation1_mean_aggregation(vocab):
     assert np.abs(got - want).max() < TOL
 
 
+@pytest.mark.parametrize("class_embed,color_embed", [(True, False), (False, True), (True, True)])
+def test_encode_cells_embedding_ablations(vocab, class_embed, color_embed):
+    """--class_embed / --color_embed (models/object_encoder.py:74-84,103-120): ground-truth label embeddings."""
+    import weights as W
+    import text2pos_amd as t2p
+    from oracle import model as OM
+    from text2pos_amd import data as D, synthetic as S
+    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"],
+                                OM.default_args(class_embed=class_embed, color_embed=color_embed)).eval()
+    W.fill_state_dict(om, 11)
+    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"],
+                                  S.default_args(class_embed=class_embed, color_embed=color_embed))
+    hm.load_state_dict(om.state_dict(), strict=True)
+    hm = hm.to(_dev()).eval()
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(81, 4)
+    n = int(cell_ptr[-1])
+    labels = [vocab["classes"][i % 21] if i % 5 else "unknown-label" for i in range(n)]
+    objects, points = [], []
+    for c in range(4):
+        lo, hi = cell_ptr[c], cell_ptr[c + 1]
+        objects.append([D.Object3d(i, i, np.tile(center[i].astype(np.float64), (2, 1)),
+                                   np.tile(mean_rgb[i].astype(np.float64), (2, 1)), labels[i]) for i in range(lo, hi)])
+        m = hi - lo
+        points.append(D.Batch(x=torch.from_numpy(rgb[lo:hi].reshape(m * 256, 3).copy()),
+                              pos=torch.from_numpy(xyz[lo:hi].reshape(m * 256, 3).copy()),
+                              batch=torch.arange(m).repeat_interleave(256)))
+    oe = hm.object_encoder
+    cls = np.array([oe.known_classes.get(o.label, 0) for objs in objects for o in objs]) if class_embed else None
+    col = np.array([oe.known_colors[o.get_color_text()] for objs in objects for o in objs]) if color_embed else None
+    want = om.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr, class_idx=cls, color_idx=col).numpy()
+    with torch.no_grad():
+        got = hm.encode_objects(objects, points).cpu().numpy()
+    assert np.abs(got - want).max() < TOL
+    if class_embed:
+        assert (cls == 0).any() and (cls > 0).any()      # unknown labels hit the padding row
+
+
 def test_encode_cells_golden(hip_model, golden_dir):
     z = np.load(os.path.join(golden_dir, "cell_encoder.npz"))
     with torch.no_grad():

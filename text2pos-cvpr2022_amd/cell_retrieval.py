@@ -63,15 +63,19 @@ class CellRetrievalNetwork(nn.Module):
             self._pack = (ver, tensors, ops.make_cell_weights(tensors))
         return self._pack[2]
 
-    def _cell_config(self, n_pts, chunk_objects=0):
+    def _cell_config(self, n_pts, chunk_objects=0, class_idx=None, color_idx=None):
         a = self.args
-        if getattr(a, "class_embed", False) or getattr(a, "color_embed", False):
-            raise NotImplementedError("--class_embed / --color_embed ablations are not built on the HIP path")
+        if bool(getattr(a, "class_embed", False)) != (class_idx is not None) or \
+                bool(getattr(a, "color_embed", False)) != (color_idx is not None):
+            raise RuntimeError("args.class_embed / args.color_embed need the per-object class / colour indices "
+                               "(encode_objects derives them from the Object3d labels; pass class_idx / color_idx to "
+                               "encode_objects_packed)")
         radii = self.object_encoder.pointnet.radii
         return ops.make_cell_config(n_pts=n_pts, embed_dim=self.embed_dim, pointnet_features=a.pointnet_features,
                                     use_features=tuple(a.use_features), self_loops=self.add_self_loops,
                                     knn_k=self.graph1.k, variation=self.variation, radius=radii,
-                                    chunk_objects=chunk_objects, precision=self.precision)
+                                    chunk_objects=chunk_objects, precision=self.precision, class_idx=class_idx,
+                                    color_idx=color_idx)
 
     def _check_forward_only(self):
         if self.training:
@@ -80,14 +84,14 @@ class CellRetrievalNetwork(nn.Module):
             raise NotImplementedError("the HIP path is forward-only; call it under torch.no_grad()")
 
     def encode_objects_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, cell_ptr_dev=None, want_trace=False,
-                              chunk_objects=0):
+                              chunk_objects=0, class_idx=None, color_idx=None):
         """Device-resident packed inputs: xyz/rgb [Nobj, P, 3], center/mean_rgb [Nobj, 3] (fp32, on self.device),
         cell_ptr int32 [B+1] on the host.  Returns [B, D] L2-normalised."""
         self._check_forward_only()
         cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int32)
         if cell_ptr_dev is None:
             cell_ptr_dev = torch.from_numpy(cp).to(self.device)
-        cfg = self._cell_config(xyz.shape[1], chunk_objects)
+        cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx)
         return ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
 
     def encode_objects(self, objects, object_points):
@@ -99,7 +103,16 @@ class CellRetrievalNetwork(nn.Module):
         xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, n_pts, zero_color)
         dev = self.device
         to = lambda t: t.to(dev, non_blocking=True)
-        return self.encode_objects_packed(to(xyz), to(rgb), to(center), to(mean_rgb), cell_ptr)
+        # ground-truth embedding ablations (models/object_encoder.py:74-84)
+        oe, class_idx, color_idx = self.object_encoder, None, None
+        if getattr(self.args, "class_embed", False):
+            class_idx = to(torch.tensor([oe.known_classes.get(o.label, 0) for objs in objects for o in objs],
+                                        dtype=torch.int32))
+        if getattr(self.args, "color_embed", False):
+            color_idx = to(torch.tensor([oe.known_colors[o.get_color_text()] for objs in objects for o in objs],
+                                        dtype=torch.int32))
+        return self.encode_objects_packed(to(xyz), to(rgb), to(center), to(mean_rgb), cell_ptr, class_idx=class_idx,
+                                          color_idx=color_idx)
 
     encode_cells = encode_objects  # the name BASELINE.json uses for the same method
 

@@ -157,6 +157,8 @@ int check_cfg(const t2p_cell_config* cfg) {
     T2P_CHECK_ARG(cfg->knn_k >= 1 && cfg->knn_k <= 32, "encode_cells: knn_k=%d outside [1,32]", cfg->knn_k);
     T2P_CHECK_ARG(cfg->precision == 0 || cfg->precision == 1, "encode_cells: precision=%d (0 = fp32, 1 = f16x3)",
                   cfg->precision);
+    T2P_CHECK_ARG(!cfg->class_embed || cfg->class_idx != nullptr, "encode_cells: class_embed needs class_idx");
+    T2P_CHECK_ARG(!cfg->color_embed || cfg->color_idx != nullptr, "encode_cells: color_embed needs color_idx");
     return 0;
 }
 
@@ -178,6 +180,9 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     Geo g(cfg.n_pts);
     const int D = cfg.embed_dim;
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st));
+    // models/object_encoder.py:86: the PointNet++ only runs when the "class" feature does not come from class_embedding
+    const bool run_pointnet = cfg.use_class && !cfg.class_embed;
+    if (run_pointnet) {
     ws.gt.self_loops = cfg.self_loops;
     {
         GroupTables gt = ws.gt;
@@ -279,10 +284,14 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     // ---- PointNet2 heads + ObjectEncoder ------------------------------------------------------------------------
     T2P_TRY(launch_gemm(ws.f0, 1024, W.lin1_w, W.lin1_b, ws.f1, 512, 0, n, 1024, 512, 1, st));
     T2P_TRY(launch_gemm(ws.f1, 512, W.lin2_w, W.lin2_b, ws.f2, 256, 0, n, 512, 256, 1, st));
+    }  // run_pointnet
     const int nfeat = (cfg.use_class ? 1 : 0) + (cfg.use_color ? 1 : 0) + (cfg.use_position ? 1 : 0);
     const int ldcat = nfeat * D;
     int slot = 0;
-    if (cfg.use_class) {
+    if (cfg.use_class && cfg.class_embed) {
+        T2P_TRY(launch_gather_rownorm(W.class_embedding, cfg.class_idx + o_lo, n, D, ws.cat, ldcat, slot * D, st));
+        slot++;
+    } else if (cfg.use_class) {
         const float* fin = cfg.pointnet_features == 0 ? ws.f0 : (cfg.pointnet_features == 1 ? ws.f1 : ws.f2);
         const int kin = cfg.pointnet_features == 0 ? 1024 : (cfg.pointnet_features == 1 ? 512 : 256);
         // mlp_pointnet into P (scratch), then F.normalize into the concat slot
@@ -290,7 +299,10 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         T2P_TRY(launch_rownorm(ws.P, D, n, D, ws.cat, ldcat, slot * D, st));
         slot++;
     }
-    if (cfg.use_color) {
+    if (cfg.use_color && cfg.color_embed) {
+        T2P_TRY(launch_gather_rownorm(W.color_embedding, cfg.color_idx + o_lo, n, D, ws.cat, ldcat, slot * D, st));
+        slot++;
+    } else if (cfg.use_color) {
         T2P_TRY(launch_mlp3_norm(mean_rgb, n, W.col_w1, W.col_b1, W.col_w2, W.col_b2, D, ws.cat, ldcat, slot * D, st));
         slot++;
     }
@@ -331,7 +343,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     T2P_TRY(launch_gemm(ws.l1, D, W.lin_w2, W.lin_b2, ws.l2, D, 0, nb, D, D, 1, st));
     T2P_TRY(launch_rownorm(ws.l2, D, nb, D, out, D, 0, st));
 
-    if (tr) {
+    if (tr && run_pointnet) {
         for (int l = 0; l < 3; l++) {
             T2P_TRY(copy_trace(tr->fps_idx[l] ? tr->fps_idx[l] + trace_obj0 * g.nc[l] : nullptr, ws.gt.fps_idx[l],
                                (size_t)n * g.nc[l], st));
@@ -344,6 +356,8 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         }
         T2P_TRY(copy_trace(tr->features0 ? tr->features0 + trace_obj0 * 1024 : nullptr, ws.f0, (size_t)n * 1024, st));
         T2P_TRY(copy_trace(tr->features2 ? tr->features2 + trace_obj0 * 256 : nullptr, ws.f2, (size_t)n * 256, st));
+    }
+    if (tr) {
         T2P_TRY(copy_trace(tr->obj_emb ? tr->obj_emb + trace_obj0 * D : nullptr, emb, (size_t)n * D, st));
         // knn indices are chunk-local object rows; tests use a single chunk or add the chunk offset themselves
         T2P_TRY(copy_trace(tr->knn_idx ? tr->knn_idx + trace_obj0 * cfg.knn_k : nullptr, ws.knn,
@@ -417,6 +431,8 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
     T2P_TRY(check_cfg(cfg));
     T2P_CHECK_ARG(w != nullptr && cell_ptr_host != nullptr && cell_ptr != nullptr && out != nullptr,
                   "encode_cells: NULL argument");
+    T2P_CHECK_ARG(!cfg->class_embed || w->class_embedding != nullptr, "encode_cells: class_embedding weights missing");
+    T2P_CHECK_ARG(!cfg->color_embed || w->color_embedding != nullptr, "encode_cells: color_embedding weights missing");
     if (cfg->precision == 1)
         T2P_CHECK_ARG(w->sa_w2_x3[0] && w->sa_w2_x3[1] && w->sa_w2_x3[2] && w->sa_w1_x3[1] && w->sa_w1_x3[2] &&
                           w->ga_w1_x3 && w->ga_w2_x3,

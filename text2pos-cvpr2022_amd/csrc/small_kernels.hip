@@ -76,6 +76,25 @@ __global__ __launch_bounds__(256) void k_rownorm(const float* __restrict__ in, i
     for (int i = lane; i < dim; i += 64) y[i] = x[i] / den;
 }
 
+// F.normalize(table[idx[row]]) -> out[row*ld_out + col0 ...]: the --class_embed / --color_embed ablations
+// (models/object_encoder.py:103-120).  One wavefront per row.
+__global__ __launch_bounds__(256) void k_gather_rownorm(const float* __restrict__ table, const int32_t* __restrict__ idx,
+                                                        int64_t n_rows, int dim, float* __restrict__ out, int ld_out,
+                                                        int col0) {
+    const int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* x = table + (int64_t)idx[row] * dim;
+    float ss = 0.f;
+    for (int i = lane; i < dim; i += 64) ss = fmaf(x[i], x[i], ss);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float nrm = sqrtf(ss);
+    const float den = nrm > 1e-12f ? nrm : 1e-12f;
+    float* y = out + row * ld_out + col0;
+    for (int i = lane; i < dim; i += 64) y[i] = x[i] / den;
+}
+
 __global__ void k_segpool(const float* __restrict__ in, int dim, const int32_t* __restrict__ seg_ptr, int n_seg,
                           float* __restrict__ out, int mean) {
     int s = blockIdx.x;
@@ -227,6 +246,16 @@ int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* o
     hipLaunchKernelGGL(k_rownorm, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, in, ld_in, n_rows, dim, out,
                        ld_out, col0);
     T2P_CHECK_LAUNCH("rownorm");
+    return 0;
+}
+
+int launch_gather_rownorm(const float* table, const int32_t* idx, int64_t n_rows, int dim, float* out, int ld_out,
+                          int col0, hipStream_t st) {
+    if (n_rows == 0) return 0;
+    ProfScope ps_("gather_rownorm", st);
+    hipLaunchKernelGGL(k_gather_rownorm, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, table, idx, n_rows, dim,
+                       out, ld_out, col0);
+    T2P_CHECK_LAUNCH("gather_rownorm");
     return 0;
 }
 

@@ -81,6 +81,8 @@ int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx,
 // gather level-l centroid positions: out[(o*n_cent + c), 0..2]
 int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* out, int ld_out, int col0,
                    hipStream_t st);
+int launch_gather_rownorm(const float* table, const int32_t* idx, int64_t n_rows, int dim, float* out, int ld_out,
+                          int col0, hipStream_t st);
 int launch_segmax(const float* in, int dim, const int32_t* seg_ptr, int n_seg, float* out, int mean,
                   hipStream_t st);
 int launch_knn(const float* x, int dim, const int32_t* seg_ptr, int n_seg, int max_seg_rows, int k,

@@ -131,7 +131,8 @@ def sim_topk(queries: torch.Tensor, cells: torch.Tensor, k: int, index_offset: i
 # ---------------------------------------------------------------------------------------------------------------
 def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features=("class", "color", "position"),
                      self_loops=True, knn_k=8, variation=0, radius=(0.2, 0.3, 0.4), chunk_objects=0,
-                     precision="f16x3") -> L.CellConfig:
+                     precision="f16x3", class_idx=None, color_idx=None) -> L.CellConfig:
+    """class_idx / color_idx: int32 device tensors [n_obj] enabling the --class_embed / --color_embed ablations."""
     cfg = L.CellConfig()
     cfg.n_pts, cfg.embed_dim, cfg.pointnet_features = int(n_pts), int(embed_dim), int(pointnet_features)
     cfg.use_class = int("class" in use_features)
@@ -143,6 +144,12 @@ def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features
     if precision not in ("fp32", "f16x3"):
         raise RuntimeError(f"precision must be 'fp32' or 'f16x3', got {precision!r}")
     cfg.precision = 1 if precision == "f16x3" else 0
+    for name, t in (("class", class_idx), ("color", color_idx)):
+        if t is not None:
+            _need(t, name + "_idx", torch.int32, 1)
+            setattr(cfg, name + "_embed", 1)
+            setattr(cfg, name + "_idx", t.data_ptr())
+    cfg._keepalive = (class_idx, color_idx)
     return cfg
 
 
@@ -171,6 +178,11 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
         if g is not None:
             _need(g, name, torch.int16)
             setattr(w, name, g.data_ptr())
+    for name in ("class_embedding", "color_embedding"):
+        t = packed.get(name)
+        if t is not None:
+            _need(t, name, torch.float32, 2)
+            setattr(w, name, t.data_ptr())
     return w
 
 
@@ -188,6 +200,9 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
         raise RuntimeError(f"encode_cells: xyz {tuple(xyz.shape)} / rgb {tuple(rgb.shape)} must both be [n_obj, n_pts, 3]")
     if tuple(center.shape) != (n_obj, 3) or tuple(mean_rgb.shape) != (n_obj, 3):
         raise RuntimeError("encode_cells: center / mean_rgb must be [n_obj, 3]")
+    for name in ("class", "color"):
+        if getattr(cfg, name + "_embed") and cfg._keepalive[0 if name == "class" else 1].numel() != n_obj:
+            raise RuntimeError(f"encode_cells: {name}_idx must have one entry per object")
     if n_pts != cfg.n_pts:
         raise RuntimeError(f"encode_cells: objects have {n_pts} points, config says {cfg.n_pts}")
     cp = np.ascontiguousarray(cell_ptr_host, dtype=np.int32)

@@ -93,6 +93,8 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
     w2, b2 = fold_linear_bn(model.graph1.nn[1])
     p.update(g_wp=kmajor(w1[:, :d] - w1[:, d:]).to(device), g_bp=f32(b1).to(device), g_wq=kmajor(w1[:, d:]).to(device),
              g_w2=kmajor(w2).to(device), g_b2=f32(b2).to(device))
+    p.update(class_embedding=f32(oe.class_embedding.weight.detach()).to(device),
+             color_embedding=f32(oe.color_embedding.weight.detach()).to(device))
     w1, b1 = fold_linear_bn(model.lin[0])
     w2, b2 = fold_linear_bn(model.lin[1])
     p.update(lin_w1=kmajor(w1).to(device), lin_b1=f32(b1).to(device), lin_w2=kmajor(w2).to(device),
