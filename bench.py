@@ -253,7 +253,7 @@ def main():
                                   if args.precision == "f16x3" else "exact fp32 MFMA path")},
             "host_generation_s": round(gen_s, 2),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
             big_host = (os.cpu_count() or 1) >= 32
             n_cells_cpu = args.cpu_cells or (256 if big_host else 16)
             log("cpu baseline")
