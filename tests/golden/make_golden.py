@@ -147,6 +147,61 @@ def golden_retrieval():
     return dict(cells=c, queries=q, top10=np.stack(top).astype(np.int64))
 
 
+def golden_eval():
+    """Metrics: the reference's own calc_sample_accuracies (evaluation/utils.py:31) on reference Pose / Cell objects, and
+    the hit / close-by statements of training/coarse.py:142-163 (restated verbatim: they sit inside eval_epoch)."""
+    from datapreparation.kitti360pose.imports import Cell, Pose, DescriptionBestCell
+    from evaluation.utils import calc_sample_accuracies
+    rng = np.random.default_rng(404)
+    n_cells, n_q, top_k, threshs = 60, 40, [1, 5, 10], [5, 10, 15]
+    scenes = ["0003", "0005"]
+    cell_xy = rng.uniform(0, 200, (n_cells, 2))
+    cells = []
+    for i in range(n_cells):
+        bbox = np.array([cell_xy[i, 0], cell_xy[i, 1], 0.0, cell_xy[i, 0] + 30, cell_xy[i, 1] + 30, 10.0])
+        cells.append(Cell(i, scenes[i % 2], [], 30.0, bbox))
+    cells_dict = {c.id: c for c in cells}
+    db_cell_ids = np.array([c.id for c in cells])
+    descr = [DescriptionBestCell.__new__(DescriptionBestCell)]
+    poses = []
+    for q in range(n_q):
+        c = cells[rng.integers(n_cells)]
+        pw = np.array([*(c.bbox_w[0:2] + rng.uniform(0, 30, 2)), 1.0])
+        poses.append(Pose((pw[0:2] - c.bbox_w[0:2]) / 30.0, pw, c.id, c.scene_name, descr))
+    top_idx = np.stack([rng.permutation(n_cells)[:10] for _ in range(n_q)])
+    for q in range(0, n_q, 3):                       # plant the true cell at a random rank for a third of the queries
+        true = int(np.where(db_cell_ids == poses[q].cell_id)[0][0])
+        if true not in top_idx[q]:
+            top_idx[q, rng.integers(10)] = true
+    query_cell_ids = np.array([p.cell_id for p in poses])
+    query_poses_w = np.array([p.pose_w[0:2] for p in poses])
+    cell_size = cells[0].cell_size
+    accuracies = {k: [] for k in top_k}
+    accuracies_close = {k: [] for k in top_k}
+    for query_idx in range(n_q):
+        retrieved_cell_ids = db_cell_ids[top_idx[query_idx]]                       # training/coarse.py:143
+        target_cell_id = query_cell_ids[query_idx]
+        for k in top_k:
+            accuracies[k].append(target_cell_id in retrieved_cell_ids[0:k])        # :146-147
+        target_pose_w = query_poses_w[query_idx]
+        retrieved_cell_poses = [cells_dict[cell_id].get_center()[0:2] for cell_id in retrieved_cell_ids]
+        dists = np.linalg.norm(target_pose_w - retrieved_cell_poses, axis=1)       # :156
+        for k in top_k:
+            accuracies_close[k].append(np.any(dists[0:k] <= cell_size / 2))        # :158
+    sample = {k: {t: [] for t in threshs} for k in top_k}
+    for q in range(n_q):                                                            # evaluation/pipeline.py:124-131
+        tc = [cells_dict[cid] for cid in db_cell_ids[top_idx[q]]]
+        accs = calc_sample_accuracies(poses[q], tc, 0.5 * np.ones((10, 2)), top_k, threshs)
+        for k in top_k:
+            for t in threshs:
+                sample[k][t].append(accs[k][t])
+    return dict(cell_bbox=np.stack([c.bbox_w for c in cells]), cell_scene=np.array([c.scene_name for c in cells]),
+                pose_w=np.stack([p.pose_w for p in poses]), pose_cell=query_cell_ids, top_idx=top_idx,
+                hit=np.array([np.mean(accuracies[k]) for k in top_k]),
+                close=np.array([np.mean(accuracies_close[k]) for k in top_k]),
+                recall=np.array([[np.mean(sample[k][t]) for t in threshs] for k in top_k]))
+
+
 def main():
     install_standins()
     import importlib
@@ -159,7 +214,8 @@ def main():
     cells = golden_cells(model, S)
     np.savez_compressed(os.path.join(HERE, "cell_encoder.npz"), **cells)
     np.savez_compressed(os.path.join(HERE, "retrieval.npz"), **golden_retrieval())
-    for f in ("text_encoder.npz", "cell_encoder.npz", "retrieval.npz"):
+    np.savez_compressed(os.path.join(HERE, "eval_metrics.npz"), **golden_eval())
+    for f in ("text_encoder.npz", "cell_encoder.npz", "retrieval.npz", "eval_metrics.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

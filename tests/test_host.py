@@ -249,3 +249,25 @@ def test_shard_range_partitions_exactly():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+# ---- evaluation metrics ------------------------------------------------------------------------------
+def test_evaluation_metrics_match_reference_fixture(golden_dir):
+    """hit@k / close-by@k (training/coarse.py:142-163) and recall@k within thresholds (evaluation/utils.py:31-54):
+    fixture produced by the reference's own calc_sample_accuracies on reference Pose / Cell objects."""
+    from text2pos_amd import evaluation as E
+    z = np.load(os.path.join(golden_dir, "eval_metrics.npz"))
+    top_k, threshs = [1, 5, 10], [5, 10, 15]
+    cells = [D.Cell(i, str(z["cell_scene"][i]), [], 30.0, z["cell_bbox"][i]) for i in range(len(z["cell_bbox"]))]
+    cells_dict = {c.id: c for c in cells}
+    db_ids = np.array([c.id for c in cells])
+    poses = [D.Pose(None, z["pose_w"][q], str(z["pose_cell"][q]), str(z["pose_cell"][q]).split("_")[0]) for q in range(len(z["pose_w"]))]
+    centers = np.array([c.get_center()[0:2] for c in cells])
+    acc, close, top = E.retrieval_accuracies(z["top_idx"], db_ids, z["pose_cell"], z["pose_w"][:, 0:2], centers, 30.0, top_k)
+    assert np.allclose([acc[k] for k in top_k], z["hit"]) and np.allclose([close[k] for k in top_k], z["close"])
+    assert list(top[3]) == list(db_ids[z["top_idx"][3]])
+    rec = E.localisation_accuracies(poses, [db_ids[r] for r in z["top_idx"]], cells_dict, top_k, threshs)
+    assert np.allclose([[rec[k][t] for t in threshs] for k in top_k], z["recall"])
+    one = E.calc_sample_accuracies(poses[0], [cells_dict[c] for c in db_ids[z["top_idx"][0]]], 0.5 * np.ones((10, 2)), top_k, threshs)
+    assert set(one) == set(top_k) and all(isinstance(v, bool) for d in one.values() for v in d.values())
+    assert 0.0 < z["hit"][2] < 1.0 and z["recall"][2, 2] >= z["recall"][0, 0]      # the fixture is not degenerate

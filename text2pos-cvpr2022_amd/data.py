@@ -41,10 +41,16 @@ class Object3d:
 class Cell:
     def __init__(self, idx, scene_name, objects: List[Object3d], cell_size, bbox_w):
         self.scene_name, self.objects, self.cell_size, self.bbox_w = scene_name, objects, cell_size, np.asarray(bbox_w)
-        self.id = f"{scene_name[-9:-5]}_{idx:05.0f}" if isinstance(idx, (int, float)) else str(idx)
+        self.id = f"{scene_name}_{idx:05.0f}"   # "00XX_XXXXX" (datapreparation/kitti360pose/imports.py:189)
 
     def get_center(self):
-        return 0.5 * (self.bbox_w[0:3] + self.bbox_w[3:6])
+        return 1 / 2 * (self.bbox_w[0:3] + self.bbox_w[3:6])
+
+
+class Pose:
+    def __init__(self, pose_in_cell, pose_w, cell_id, scene_name, descriptions=None, described_by=None):
+        self.pose, self.pose_w, self.cell_id = pose_in_cell, np.asarray(pose_w), cell_id
+        self.scene_name, self.descriptions, self.described_by = scene_name, descriptions, described_by
 
 
 class Data:
