@@ -156,6 +156,19 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
                      void* workspace, size_t workspace_bytes, t2p_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Input packing on the device: replaces the per-object host work of
+ * dataloading/kitti360pose/utils.py:89-110 (Data -> T.FixedPoints -> T.NormalizeScale -> Batch) and the per-object
+ * NumPy means of models/object_encoder.py:121-131 (Object3d.get_color_rgb / get_center).
+ * raw_xyz, raw_rgb [n_points_total][3] fp32: the raw points of all objects back to back; obj_ptr [n_obj+1] int32 CSR;
+ * sample_idx [n_obj][n_pts] int32: per-object LOCAL indices drawn with replacement by the host's seeded generator
+ * (T.FixedPoints is random even at evaluation time, evaluation/pipeline.py:290-293 -- the draw stays on the host so that
+ * runs are reproducible).  Outputs are exactly the inputs of t2p_encode_cells.
+ * ---------------------------------------------------------------------------------------------------------- */
+int t2p_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
+                     int64_t n_obj, int32_t n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
+                     t2p_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Text branch: CellRetrievalNetwork.encode_text (models/cell_retrieval.py:69-75) on token ids produced by the
  * host tokeniser of LanguageEncoder.forward (models/modules.py:60-72).
  * ---------------------------------------------------------------------------------------------------------- */

@@ -258,6 +258,37 @@ def test_encode_cells_embedding_ablations(vocab, class_embed, color_embed):
         assert (cls == 0).any() and (cls > 0).any()      # unknown labels hit the padding row
 
 
+def test_pack_objects_matches_host_transform_chain(hip_model, oracle_model):
+    """On-device FixedPoints gather + NormalizeScale + means == the host chain of dataloading/kitti360pose/utils.py:99-109
+    (restated in oracle/pyg_restated.py) given the same draw; and the raw-object entry point encodes like the packed one."""
+    from oracle import pyg_restated as P
+    from text2pos_amd import data as D, ops
+    rng = np.random.default_rng(5)
+    objects = []
+    for c in range(3):
+        objs = []
+        for i in range(4 + c):
+            m = int(rng.integers(25, 900))
+            objs.append(D.Object3d(i, i, rng.random((m, 3)) * np.array([8.0, 3.0, 1.5]) + 2.0, rng.random((m, 3)), "box"))
+        objects.append(objs)
+    raw_xyz, raw_rgb, obj_ptr, sample_idx, cell_ptr = D.flatten_raw_objects(objects, 256, np.random.default_rng(9))
+    got = [t.cpu().numpy() for t in ops.pack_objects(*_to_dev(raw_xyz, raw_rgb, obj_ptr, sample_idx))]
+    flat = [o for objs in objects for o in objs]
+    for i, o in enumerate(flat):
+        d = P.Data(x=torch.tensor(o.rgb, dtype=torch.float)[sample_idx[i].astype(np.int64)],
+                   pos=torch.tensor(o.xyz, dtype=torch.float)[sample_idx[i].astype(np.int64)])
+        d = P.NormalizeScale()(d)
+        assert np.abs(got[0][i] - d.pos.numpy()).max() < 2e-6
+        assert np.array_equal(got[1][i], d.x.numpy())
+        assert np.abs(got[2][i] - o.get_center()).max() < 1e-6 and np.abs(got[3][i] - o.get_color_rgb()).max() < 1e-6
+    with torch.no_grad():
+        a = hip_model.encode_raw_objects(objects, np.random.default_rng(9)).cpu()
+        b = hip_model.encode_objects_packed(*_to_dev(*got), cell_ptr).cpu()
+    assert torch.equal(a, b)
+    want = oracle_model.encode_objects_packed(got[0], got[1], got[2], got[3], cell_ptr)
+    assert (a - want).abs().max().item() < TOL
+
+
 def test_encode_cells_golden(hip_model, golden_dir):
     z = np.load(os.path.join(golden_dir, "cell_encoder.npz"))
     with torch.no_grad():

@@ -57,6 +57,8 @@ SYMBOLS = {
     "t2p_sim_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "t2p_sim_topk": (C.c_int, [c_void, c_void, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, c_void, c_void,
                                c_void, C.c_size_t, c_void]),
+    "t2p_pack_objects": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, c_void, c_void, c_void, c_void,
+                                   c_void]),
     "t2p_profile_enable": (None, [C.c_int]),
     "t2p_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),
     "t2p_sample_group": (C.c_int, [c_void, C.c_int64, C.c_int32, c_float_p, C.POINTER(c_void), C.POINTER(c_void),

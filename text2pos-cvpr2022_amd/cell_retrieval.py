@@ -114,6 +114,21 @@ class CellRetrievalNetwork(nn.Module):
         return self.encode_objects_packed(to(xyz), to(rgb), to(center), to(mean_rgb), cell_ptr, class_idx=class_idx,
                                           color_idx=color_idx)
 
+    def encode_raw_objects(self, objects, generator: np.random.Generator):
+        """objects: List[List[Object3d]] with RAW point sets.  The dataloader's per-object transform chain
+        (T.FixedPoints(256) -> T.NormalizeScale, dataloading/kitti360pose/utils.py:99-109) and the per-object means run on
+        the GPU (csrc/small_kernels.hip::k_pack_objects); only the random draw of T.FixedPoints stays on the host."""
+        from .data import flatten_raw_objects
+        self._check_forward_only()
+        n_pts = int(getattr(self.args, "pointnet_numpoints", 256))
+        raw_xyz, raw_rgb, obj_ptr, sample_idx, cell_ptr = flatten_raw_objects(objects, n_pts, generator)
+        dev = self.device
+        to = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+        xyz, rgb, center, mean_rgb = ops.pack_objects(to(raw_xyz), to(raw_rgb), to(obj_ptr), to(sample_idx))
+        if "color" not in self.args.use_features:
+            rgb.zero_()
+        return self.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)
+
     encode_cells = encode_objects  # the name BASELINE.json uses for the same method
 
     def forward(self):

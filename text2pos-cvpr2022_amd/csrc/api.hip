@@ -537,6 +537,15 @@ int t2p_sample_group(const float* xyz, int64_t n_obj, int32_t n_pts, const float
     return launch_sample_group(xyz, n_obj, n_pts, radius_host, gt, (hipStream_t)stream);
 }
 
+int t2p_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
+                     int64_t n_obj, int32_t n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
+                     t2p_stream_t stream) {
+    T2P_CHECK_ARG(raw_xyz && raw_rgb && obj_ptr && sample_idx && xyz && rgb && center && mean_rgb, "pack_objects: NULL argument");
+    T2P_CHECK_ARG(n_obj >= 0 && n_pts >= 1, "pack_objects: bad sizes");
+    return launch_pack_objects(raw_xyz, raw_rgb, obj_ptr, sample_idx, n_obj, n_pts, xyz, rgb, center, mean_rgb,
+                               (hipStream_t)stream);
+}
+
 int t2p_knn(const float* x, int32_t dim, const int32_t* seg_ptr, int32_t n_seg, int32_t max_seg_rows, int32_t k,
             int32_t* out_idx, t2p_stream_t stream) {
     return launch_knn(x, dim, seg_ptr, n_seg, max_seg_rows, k, out_idx, (hipStream_t)stream);

@@ -194,6 +194,72 @@ __global__ __launch_bounds__(256) void k_mlp3_norm(const float* __restrict__ in3
     for (int j = 0; j < per; j++) out[row * ld_out + col0 + j * 64 + lane] = o[j] / den;
 }
 
+// On-device version of dataloading/kitti360pose/utils.py::batch_object_points + the per-object means of
+// models/object_encoder.py:121-131: for every raw object (ragged point list) gather the P sampled points
+// (T.FixedPoints: the indices come from the host's seeded generator), apply T.NormalizeScale (subtract the mean of the
+// SAMPLED points, scale by 0.999999 / max|.|) and emit Object3d.get_center() / get_color_rgb() (means over ALL raw
+// points, accumulated in float64 like NumPy).  One wavefront per object.
+__global__ __launch_bounds__(256) void k_pack_objects(const float* __restrict__ raw_xyz, const float* __restrict__ raw_rgb,
+                                                      const int32_t* __restrict__ obj_ptr,
+                                                      const int32_t* __restrict__ sample_idx, int64_t n_obj, int n_pts,
+                                                      float* __restrict__ xyz, float* __restrict__ rgb,
+                                                      float* __restrict__ center, float* __restrict__ mean_rgb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= n_obj) return;
+    const int lo = obj_ptr[o], hi = obj_ptr[o + 1], m = hi - lo;
+    // means over all raw points
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = lane; i < m; i += 64) {
+        const float* p = raw_xyz + (int64_t)(lo + i) * 3;
+        const float* c = raw_rgb + (int64_t)(lo + i) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; d++) { acc[d] += (double)p[d]; acc[3 + d] += (double)c[d]; }
+    }
+#pragma unroll
+    for (int d = 0; d < 6; d++) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc[d] += __shfl_xor(acc[d], off, 64);
+    }
+    if (lane < 3) center[o * 3 + lane] = (float)(acc[lane] / (double)m);
+    else if (lane < 6) mean_rgb[o * 3 + lane - 3] = (float)(acc[lane] / (double)m);
+    // resample + NormalizeScale
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = lane; i < n_pts; i += 64) {
+        const int j = lo + sample_idx[o * n_pts + i];
+        sx += raw_xyz[(int64_t)j * 3 + 0];
+        sy += raw_xyz[(int64_t)j * 3 + 1];
+        sz += raw_xyz[(int64_t)j * 3 + 2];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sx += __shfl_xor(sx, off, 64);
+        sy += __shfl_xor(sy, off, 64);
+        sz += __shfl_xor(sz, off, 64);
+    }
+    const float mx = sx / (float)n_pts, my = sy / (float)n_pts, mz = sz / (float)n_pts;
+    float amax = 0.f;
+    for (int i = lane; i < n_pts; i += 64) {
+        const int j = lo + sample_idx[o * n_pts + i];
+        amax = fmaxf(amax, fmaxf(fabsf(raw_xyz[(int64_t)j * 3] - mx),
+                                 fmaxf(fabsf(raw_xyz[(int64_t)j * 3 + 1] - my), fabsf(raw_xyz[(int64_t)j * 3 + 2] - mz))));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    const float scale = (1.f / amax) * 0.999999f;
+    for (int i = lane; i < n_pts; i += 64) {
+        const int j = lo + sample_idx[o * n_pts + i];
+        float* q = xyz + (o * n_pts + i) * 3;
+        float* c = rgb + (o * n_pts + i) * 3;
+        q[0] = (raw_xyz[(int64_t)j * 3] - mx) * scale;
+        q[1] = (raw_xyz[(int64_t)j * 3 + 1] - my) * scale;
+        q[2] = (raw_xyz[(int64_t)j * 3 + 2] - mz) * scale;
+        c[0] = raw_rgb[(int64_t)j * 3];
+        c[1] = raw_rgb[(int64_t)j * 3 + 1];
+        c[2] = raw_rgb[(int64_t)j * 3 + 2];
+    }
+}
+
 __global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, int32_t o_lo,
                              int32_t* __restrict__ seg_ptr_local, int32_t* __restrict__ first) {
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= n_cells; c += gridDim.x * blockDim.x) {
@@ -275,6 +341,17 @@ int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const fl
     hipLaunchKernelGGL(k_mlp3_norm, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, in3, n_rows, w1, b1, w2, b2, D,
                        out, ld_out, col0);
     T2P_CHECK_LAUNCH("mlp3_norm");
+    return 0;
+}
+
+int launch_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
+                        int64_t n_obj, int n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
+                        hipStream_t st) {
+    if (n_obj == 0) return 0;
+    ProfScope ps_("pack_objects", st);
+    hipLaunchKernelGGL(k_pack_objects, dim3((unsigned)((n_obj + 3) / 4)), dim3(256), 0, st, raw_xyz, raw_rgb, obj_ptr,
+                       sample_idx, n_obj, n_pts, xyz, rgb, center, mean_rgb);
+    T2P_CHECK_LAUNCH("pack_objects");
     return 0;
 }
 

@@ -148,3 +148,20 @@ def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_co
         center[lo:hi] = torch.tensor(np.stack([o.get_center() for o in objs]), dtype=torch.float)
         mean_rgb[lo:hi] = torch.tensor(np.stack([o.get_color_rgb() for o in objs]), dtype=torch.float)
     return xyz, rgb, center, mean_rgb, cell_ptr
+
+
+def flatten_raw_objects(objects: List[List[Object3d]], n_pts: int, generator: np.random.Generator):
+    """Host side of the on-device packing (ops.pack_objects): raw points of all objects back to back + CSR pointers +
+    the T.FixedPoints draw (indices with replacement from the seeded generator, one row per object)."""
+    flat = [o for objs in objects for o in objs]
+    sizes = np.array([len(o.xyz) for o in flat], dtype=np.int64)
+    if (sizes < 1).any():
+        raise RuntimeError("an object without points cannot be resampled")
+    obj_ptr = np.zeros(len(flat) + 1, dtype=np.int32)
+    obj_ptr[1:] = np.cumsum(sizes)
+    raw_xyz = np.concatenate([np.asarray(o.xyz, dtype=np.float32) for o in flat], 0)
+    raw_rgb = np.concatenate([np.asarray(o.rgb, dtype=np.float32) for o in flat], 0)
+    sample_idx = np.stack([generator.choice(int(m), n_pts, replace=True) for m in sizes]).astype(np.int32)
+    cell_ptr = np.zeros(len(objects) + 1, dtype=np.int32)
+    cell_ptr[1:] = np.cumsum([len(o) for o in objects])
+    return raw_xyz, raw_rgb, obj_ptr, sample_idx, cell_ptr
