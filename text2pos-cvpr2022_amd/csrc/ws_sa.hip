@@ -15,10 +15,34 @@
 #ifndef T2P_LDS_PREFETCH
 #define T2P_LDS_PREFETCH 1
 #endif
+// T2P_ABL: timing-only ablations (results are WRONG when non-zero): 1 no atomics, 2 no MFMA, 4 no gathers, 8 no tile
+// staging, 16 no LDS operand reads
+#ifndef T2P_ABL
+#define T2P_ABL 0
+#endif
+#ifndef T2P_MASKSPLIT
+#define T2P_MASKSPLIT 0
+#endif
+#ifndef T2P_QUADMAX
+#define T2P_QUADMAX 0
+#endif
 #include "t2p_common.h"
 
 namespace t2p {
 namespace {
+
+typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ half8_ abl_keep(half8_ a) { asm volatile("" : "+v"(a)); return a; }
+#if T2P_ABL & 16
+#define LOADA(ptr) abl_keep(w_hi[0][0])
+#else
+#define LOADA(ptr) (*(const half8*)(ptr))
+#endif
+#if T2P_ABL & 2
+#define MFMA16(a, b, c) (abl_keep(a), c)
+#else
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
 
 constexpr int kSub = 512;
 constexpr int NT = 512;   // threads per workgroup: 8 waves = 2 per SIMD, so one wave's VALU/LDS phases overlap the other's MFMAs  // objects whose row counts / self-loop bases are cached in LDS at a time
@@ -177,17 +201,22 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
         metav meta_d, meta_m;                                 // metadata of the batch being gathered / the one after
         f32x4 sa[C::ITERS], sb[C::ITERS];
 
-        // M: metadata of one batch -> registers (0xFFFF = padding row; lists are padded with 0xFFFF by the producer)
+        // M: metadata of one batch -> registers (0xFFFF = padding row).  Split in two: the load is ISSUED at the top of a
+        // batch, the clean-up of the rows past the object's end runs after the MFMA block -- touching the loaded value
+        // any earlier puts an s_waitcnt vmcnt(0) in front of the MFMAs, which also waits for the gathers just issued
+        // (measured: that exposed the whole gather latency, 28 % of the SA3 kernel).
         auto load_meta = [&](const BatchIt& it, metav& m) {
 #pragma unroll
             for (int k = 0; k < C::ITERS; k++) m[k] = 0xFFFF;
             if (valid(it) && it.r0 + rgrp < it.n) {
                 const uint32_t off = (uint32_t)(ga + it.gi) * (uint32_t)maxr + (uint32_t)(it.r0 + rgrp);
                 m = *(const metav*)(p.rows + off);
-#pragma unroll
-                for (int k = 0; k < C::ITERS; k++)
-                    if (it.r0 + rgrp + k >= it.n) m[k] = 0xFFFF;
             }
+        };
+        auto fix_meta = [&](const BatchIt& it, metav& m) {
+#pragma unroll
+            for (int k = 0; k < C::ITERS; k++)
+                if (it.r0 + rgrp + k >= it.n) m[k] = 0xFFFF;
         };
         // D: gathers of the batch's A_j and B_i rows -> registers (32-bit element offsets from uniform bases)
         auto load_data = [&](const BatchIt& it, const metav& m) {
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
             for (int k = 0; k < C::ITERS; k++) {
                 sa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
                 sb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m[k] != 0xFFFF) {
+                if (!(T2P_ABL & 4) && m[k] != 0xFFFF) {
                     const uint32_t src = m[k] & 0xFF, d = m[k] >> 8, dl = d & 127;
                     const uint32_t srow = (d & 0x80) ? (sb0 + src) : (g * (uint32_t)p.n_dense + src);
                     sa[k] = *(const f32x4*)(p.A + (srow * (uint32_t)K + (uint32_t)c4 * 4u));
@@ -218,9 +247,20 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(t[e], 0.f);
                 if constexpr (X3) {
                     // hi = fp16(v) toward zero, lo = fp16((v - hi) * 2048): 4 values -> 8 bytes in each plane
+#if T2P_MASKSPLIT
+                    // truncating to fp16 == clearing the 13 low mantissa bits (exact in fp16's normal range; below it the
+                    // conversion drops < 2^-24 absolute, far under the fp32 rounding of the sums these feed)
+                    float hf[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) hf[e] = __uint_as_float(__float_as_uint(v[e]) & 0xFFFFE000u);
+                    const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]), h23 = __builtin_amdgcn_cvt_pkrtz(hf[2], hf[3]);
+                    const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - hf[0]) * 2048.f, (v[1] - hf[1]) * 2048.f);
+                    const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((v[2] - hf[2]) * 2048.f, (v[3] - hf[3]) * 2048.f);
+#else
                     const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                     const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.f, (v[1] - (float)h01[1]) * 2048.f);
                     const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * 2048.f, (v[3] - (float)h23[1]) * 2048.f);
+#endif
                     uint2 ph, pl;
                     ph.x = __builtin_bit_cast(uint32_t, h01); ph.y = __builtin_bit_cast(uint32_t, h23);
                     pl.x = __builtin_bit_cast(uint32_t, l01); pl.y = __builtin_bit_cast(uint32_t, l23);
@@ -251,6 +291,8 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
         // prologue: M(0), M(1), D(0), W(0)
         load_meta(it_c, meta_d);
         load_meta(it_d, meta_m);
+        fix_meta(it_c, meta_d);
+        fix_meta(it_d, meta_m);
         load_data(it_c, meta_d);
         write_tile(0, meta_d);
         meta_d = meta_m;
@@ -288,16 +330,16 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                 half8 a_hi[RT], a_lo[RT], n_hi[RT], n_lo[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
-                    a_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH);
-                    a_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH);
+                    a_hi[rt] = LOADA(hrow + rt * 32 * C::LDHH);
+                    a_lo[rt] = LOADA(hrow + C::PLANE + rt * 32 * C::LDHH);
                 }
 #pragma unroll
                 for (int s = 0; s < C::S16; s++) {
                     if (s + 1 < C::S16) {
 #pragma unroll
                         for (int rt = 0; rt < RT; rt++) {
-                            n_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH + (s + 1) * 8);
-                            n_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH + (s + 1) * 8);
+                            n_hi[rt] = LOADA(hrow + rt * 32 * C::LDHH + (s + 1) * 8);
+                            n_lo[rt] = LOADA(hrow + C::PLANE + rt * 32 * C::LDHH + (s + 1) * 8);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -305,14 +347,14 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                         for (int nt = 0; nt < C::NTW; nt++) {
-                            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_hi[nt][s], acc[rt][nt], 0, 0, 0);
-                            accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_lo[nt][s], accx[rt][nt], 0, 0, 0);
+                            acc[rt][nt] = MFMA16(a_hi[rt], w_hi[nt][s], acc[rt][nt]);
+                            accx[rt][nt] = MFMA16(a_hi[rt], w_lo[nt][s], accx[rt][nt]);
                         }
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                         for (int nt = 0; nt < C::NTW; nt++)
-                            accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[rt], w_hi[nt][s], accx[rt][nt], 0, 0, 0);
+                            accx[rt][nt] = MFMA16(a_lo[rt], w_hi[nt][s], accx[rt][nt]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) {
@@ -393,7 +435,38 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 const int trow0 = (wm * RT + rt) * 32;
+                if (T2P_ABL & 1) {  // keep the MFMA results alive without the atomics
+#pragma unroll
+                    for (int nt = 0; nt < C::NTW; nt++) asm volatile("" ::"v"(acc[rt][nt]));
+                    continue;
+                }
                 if (it_c.r0 + trow0 >= it_c.n) continue;
+#if T2P_QUADMAX
+                // rows are sorted by destination inside an object, so most quads of 4 consecutive rows share one
+                // destination: reduce those in registers and issue one atomic instead of four
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t four = *(const uint32_t*)(dl + trow0 + 8 * q + 4 * h);
+                    const int d0 = (int)(four & 0xFF) * N, d3 = (int)(four >> 24) * N;
+                    if (d0 == d3) {
+#pragma unroll
+                        for (int nt = 0; nt < C::NTW; nt++) {
+                            int* col = accb + wn * C::NTW * 32 + nt * 32 + l31;
+                            const float m = fmaxf(fmaxf(acc[rt][nt][4 * q], acc[rt][nt][4 * q + 1]),
+                                                  fmaxf(acc[rt][nt][4 * q + 2], acc[rt][nt][4 * q + 3]));
+                            atomicMax(col + d0, __float_as_int(m));
+                        }
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < C::NTW; nt++) {
+                            int* col = accb + wn * C::NTW * 32 + nt * 32 + l31;
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                atomicMax(col + (int)((four >> (8 * e)) & 0xFF) * N, __float_as_int(acc[rt][nt][4 * q + e]));
+                        }
+                    }
+                }
+#else
                 int doff[16];  // destination row offsets (ints) of this lane's 16 rows: 4 quads of 4 consecutive rows
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -407,12 +480,14 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
 #pragma unroll
                     for (int e = 0; e < 16; e++) atomicMax(col + doff[e], __float_as_int(acc[rt][nt][e]));
                 }
+#endif
             }
             if (it_c.r0 + C::TR >= it_c.n) {  // last batch of this object
                 flush_g = ga + it_c.gi;
                 flush_buf = abuf;
             }
-            if (valid(it_d)) write_tile((t + 1) & 1, meta_d);  // W(t+1)
+            if (!(T2P_ABL & 8) && valid(it_d)) write_tile((t + 1) & 1, meta_d);  // W(t+1)
+            fix_meta(it_m, meta_m);
             meta_d = meta_m;
             it_c = it_d;
             it_d = it_m;
