@@ -33,6 +33,7 @@ namespace {
 
 typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ half8_ abl_keep(half8_ a) { asm volatile("" : "+v"(a)); return a; }
+__device__ __forceinline__ void abl_keep16(f32x16 a) { asm volatile("" ::"v"(a)); }
 #if T2P_ABL & 16
 #define LOADA(ptr) abl_keep(w_hi[0][0])
 #else
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                 const int trow0 = (wm * RT + rt) * 32;
                 if (T2P_ABL & 1) {  // keep the MFMA results alive without the atomics
 #pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++) asm volatile("" ::"v"(acc[rt][nt]));
+                    for (int nt = 0; nt < C::NTW; nt++) abl_keep16(acc[rt][nt]);
                     continue;
                 }
                 if (it_c.r0 + trow0 >= it_c.n) continue;
