@@ -1,0 +1,177 @@
+// GlobalAbstraction layer 2 + global max pool (512 -> 1024, max over each object's 32 points), f16x3 path.
+// (reference: GlobalAbstractionLayer.forward, models/pointcloud/pointnet2.py:45-49)
+//
+// The generic weight-stationary kernel (ws_gemm.hip) needs 256 registers per lane for the hi/lo weight image of a
+// [512 x 32] column block, so it runs one wave per SIMD on 447 registers, keeps half of the weights in AGPRs (hipcc
+// copies them back operand by operand: 4 v_accvgpr_mov + s_nop per MFMA) and has nothing to cover a stall with: it
+// sat at 50 % of the MFMA rate.  Here the K = 512 reduction of a column block is split over a PAIR of waves (k halves
+// of 256: 128 weight registers each), so the workgroup has 8 waves = 2 per SIMD at <= 256 registers, no AGPR traffic,
+// and the partner's MFMAs cover each wave's LDS / barrier / epilogue time.  One wave of a pair hands its partial
+// 32x32 block over through an LDS exchange area; the other adds it, applies bias + ReLU and reduces the 32 rows
+// (= one object) to the pooled row.
+//
+// Input: the activations of GA layer 1 as two fp16 planes (hi, lo) [M][512] (written by ws_gemm's split output).
+// Column slices of 128 of one row stream run on the same XCD (block b -> XCD b % 8) and share the rows through its L2.
+#include "t2p_common.h"
+
+namespace t2p {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int K = 512, NW = 128, NT = 512;
+constexpr int KH = K / 2;            // k range of one wave
+constexpr int S16 = KH / 16;         // 16 MFMA k-steps per wave and tile
+constexpr int S16_FULL = K / 16;     // steps of the packed weight image
+constexpr int LDHH = K + 8;          // plane row stride in halves (16-byte pad: conflict-free ds_read_b128)
+constexpr int PLANE = 32 * LDHH;     // halves
+constexpr int TILE_HALVES = 2 * PLANE;
+constexpr int XCH_FLOATS = 4 * 16 * 64;  // exchange area: 4 column blocks x 16 accumulator registers x 64 lanes
+constexpr size_t kLds = (size_t)2 * TILE_HALVES * 2 + (size_t)XCH_FLOATS * 4;
+constexpr int CHUNKS = (2 * 32 * (K / 8)) / NT;  // 16-byte chunks staged per thread and tile (= 8)
+
+__global__ __launch_bounds__(NT, 2) void k_ga2(WsParams p, int n_slices) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    _Float16* tile = (_Float16*)lds;                  // [2][hi plane | lo plane]
+    float* xch = (float*)(tile + 2 * TILE_HALVES);    // [4][16][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 3, kh = wave >> 2, h = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware stream / slice mapping (same as ws_gemm.hip)
+    const int lin = blockIdx.x, nblk = gridDim.x;
+    int slice, stream, n_streams;
+    if ((nblk % (8 * n_slices)) == 0) {
+        const int xcd = lin & 7, j = lin >> 3, per_xcd = nblk >> 3;
+        slice = j % n_slices;
+        stream = xcd * (per_xcd / n_slices) + j / n_slices;
+        n_streams = nblk / n_slices;
+    } else {
+        slice = lin % n_slices;
+        stream = lin / n_slices;
+        n_streams = nblk / n_slices;
+    }
+    const int ncol0 = slice * NW + wn * 32;
+
+    // stationary weights: k = kh*256 + h*128 + s*8 .. +8 for lane half h at step s.  In the packed image
+    // (packing.py::pack_f16x3: [plane][n-tile][step][lane half][32 lanes][8 halves] with k = half*256 + step*8) that
+    // is entry (step = h*16 + s, half = kh).
+    half8 w_hi[S16], w_lo[S16];
+    {
+        const uint4* wp = (const uint4*)p.W_x3;
+        const int plane_u4 = (p.ldw / 32) * S16_FULL * 64;
+#pragma unroll
+        for (int s = 0; s < S16; s++) {
+            const int idx = (((ncol0 / 32) * S16_FULL + (h * 16 + s)) * 2 + kh) * 32 + l31;
+            const uint4 a = wp[idx], b = wp[plane_u4 + idx];
+            w_hi[s] = __builtin_bit_cast(half8, a);
+            w_lo[s] = __builtin_bit_cast(half8, b);
+        }
+    }
+    const float bias = p.bias ? p.bias[ncol0 + l31] : 0.f;
+
+    f32x4 st[CHUNKS];
+    // chunk q (16 bytes = 8 halves): plane q / 2048, row (q % 2048) / 64, column group q % 64
+    auto stage_load = [&](int64_t g) {
+#pragma unroll
+        for (int it = 0; it < CHUNKS; it++) {
+            const int q = it * NT + tid;
+            const int pl = q >> 11, idx = q & 2047, row = idx >> 6, c8 = idx & 63;
+            const _Float16* base = (const _Float16*)(pl ? p.A_lo : p.A_hi);
+            st[it] = *(const f32x4*)(base + (g * 32 + row) * (int64_t)p.lda + c8 * 8);
+        }
+    };
+    auto stage_write = [&](int buf, int it) {
+        const int q = it * NT + tid;
+        const int pl = q >> 11, idx = q & 2047, row = idx >> 6, c8 = idx & 63;
+        *(f32x4*)(tile + buf * TILE_HALVES + pl * PLANE + row * LDHH + c8 * 8) = st[it];
+    };
+
+    int64_t g = stream;
+    if (g < p.n_groups) {
+        stage_load(g);
+#pragma unroll
+        for (int it = 0; it < CHUNKS; it++) stage_write(0, it);
+    }
+    __syncthreads();
+    for (int i = 0; g < p.n_groups; g += n_streams, i++) {
+        const int64_t gn = g + n_streams;
+        const bool more = gn < p.n_groups;
+        if (more) stage_load(gn);
+
+        f32x16 acc, accx;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            acc[e] = 0.f;
+            accx[e] = 0.f;
+        }
+        const _Float16* hrow = tile + (i & 1) * TILE_HALVES + l31 * LDHH + kh * KH + h * (KH / 2);
+        half8 a_hi = *(const half8*)(hrow), a_lo = *(const half8*)(hrow + PLANE), n_hi = a_hi, n_lo = a_lo;
+#pragma unroll
+        for (int s = 0; s < S16; s++) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < S16) {
+                n_hi = *(const half8*)(hrow + (s + 1) * 8);
+                n_lo = *(const half8*)(hrow + PLANE + (s + 1) * 8);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, w_hi[s], acc, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, w_lo[s], accx, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the LDS writes of the next tile ride between the MFMAs (they are not VALU work)
+            if (more && (s & 1) == 1) stage_write((i + 1) & 1, s >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, w_hi[s], accx, 0, 0, 0);
+            a_hi = n_hi;
+            a_lo = n_lo;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = fmaf(accx[e], 1.f / 2048.f, acc[e]);
+        // The two waves of a pair alternate as sender / finisher from tile to tile, so the wave that writes the
+        // (single) exchange area for tile i+1 is the one that read it for tile i: no second barrier, no second buffer.
+        float* x = xch + wn * (16 * 64) + lane;
+        const bool sender = ((i & 1) != 0) == (kh == 0);
+        if (sender) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e * 64] = acc[e];
+        }
+        __syncthreads();
+        if (!sender) {
+            // partner's partial + bias, ReLU (= starting the max at 0), max over the 32 rows of the object
+            float m = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) m = fmaxf(m, (acc[e] + x[e * 64]) + bias);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            if (h == 0) p.out[g * (int64_t)p.ldo + ncol0 + l31] = m;
+        }
+    }
+}
+
+}  // namespace
+
+// out[M/32][ldo] (columns [0, 1024)) = max over each 32-row group of relu(A W + b); A as fp16 hi / lo planes [M][lda]
+int launch_ga2(const WsParams& p_in, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ga2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        if (e != hipSuccess) {
+            set_error("ga2: cannot reserve %zu B of LDS: %s", kLds, hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    WsParams p = p_in;
+    p.n_groups = p.M / 32;
+    if (p.n_groups <= 0) return 0;
+    const int n_slices = 1024 / NW;
+    int64_t streams = num_cus() / n_slices;
+    if (streams < 1) streams = 1;
+    if (streams > p.n_groups) streams = p.n_groups;
+    if (streams >= 8) streams -= streams % 8;
+    ProfScope ps_("ws_groupmax_k512_n1024", st);
+    hipLaunchKernelGGL(k_ga2, dim3((unsigned)(streams * n_slices)), dim3(NT), kLds, st, p, n_slices);
+    T2P_CHECK_LAUNCH("ga2");
+    return 0;
+}
+
+}  // namespace t2p

@@ -22,6 +22,9 @@
 //     the MFMA block of batch t; their VALU part and the LDS write follow it; one barrier per batch.
 //   * Column slices of one row stream (GA: N = 1024 in slices of 128) are mapped to the same XCD (block b runs on
 //     XCD b % 8), so they share the stream's A rows through that XCD's L2.
+#ifndef T2P_GA2_V1
+#define T2P_GA2_V1 0
+#endif
 #include "t2p_common.h"
 
 namespace t2p {
@@ -464,6 +467,8 @@ int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
 
 // mode DENSE_STORE: out[M][ldo] = act(A[M][K] W + b);  DENSE_GROUPMAX: out[M/32][ldo] = max over each 32-row group
 // (M = 32 * groups);  EDGE_KNN: see WsParams.
+int launch_ga2(const WsParams& p, hipStream_t st);  // ga2.hip
+
 int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
     T2P_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.A_hi | (uintptr_t)p.A_lo) & 15) == 0 && (p.lda % 4) == 0,
                   "ws_gemm: A must be 16-byte aligned, lda %% 4 == 0");
@@ -489,6 +494,9 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
     WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 1, 2)
     // GA layer 2 + max over the 32 points of an object
     WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 0, 0)
+#if !T2P_GA2_V1
+    if (mode == WS_DENSE_GROUPMAX && K == 512 && N == 1024 && x3 == 1 && split_io == 1) return launch_ga2(p, st);
+#endif
     WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 1, 1)
 #undef WS_CASE
     set_error("ws_gemm: no instantiation for mode=%d K=%d N=%d x3=%d split_io=%d", mode, K, N, x3, split_io);

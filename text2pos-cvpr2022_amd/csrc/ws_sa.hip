@@ -15,35 +15,16 @@
 #ifndef T2P_LDS_PREFETCH
 #define T2P_LDS_PREFETCH 1
 #endif
-// T2P_ABL: timing-only ablations (results are WRONG when non-zero): 1 no atomics, 2 no MFMA, 4 no gathers, 8 no tile
-// staging, 16 no LDS operand reads
-#ifndef T2P_ABL
-#define T2P_ABL 0
-#endif
-#ifndef T2P_MASKSPLIT
-#define T2P_MASKSPLIT 0
-#endif
-#ifndef T2P_QUADMAX
-#define T2P_QUADMAX 0
+#ifndef T2P_SA_V1
+#define T2P_SA_V1 0
 #endif
 #include "t2p_common.h"
 
 namespace t2p {
 namespace {
 
-typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ half8_ abl_keep(half8_ a) { asm volatile("" : "+v"(a)); return a; }
-__device__ __forceinline__ void abl_keep16(f32x16 a) { asm volatile("" ::"v"(a)); }
-#if T2P_ABL & 16
-#define LOADA(ptr) abl_keep(w_hi[0][0])
-#else
 #define LOADA(ptr) (*(const half8*)(ptr))
-#endif
-#if T2P_ABL & 2
-#define MFMA16(a, b, c) (abl_keep(a), c)
-#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#endif
 
 constexpr int kSub = 512;
 constexpr int NT = 512;   // threads per workgroup: 8 waves = 2 per SIMD, so one wave's VALU/LDS phases overlap the other's MFMAs  // objects whose row counts / self-loop bases are cached in LDS at a time
@@ -227,7 +208,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
             for (int k = 0; k < C::ITERS; k++) {
                 sa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
                 sb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (!(T2P_ABL & 4) && m[k] != 0xFFFF) {
+                if (m[k] != 0xFFFF) {
                     const uint32_t src = m[k] & 0xFF, d = m[k] >> 8, dl = d & 127;
                     const uint32_t srow = (d & 0x80) ? (sb0 + src) : (g * (uint32_t)p.n_dense + src);
                     sa[k] = *(const f32x4*)(p.A + (srow * (uint32_t)K + (uint32_t)c4 * 4u));
@@ -248,20 +229,9 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(t[e], 0.f);
                 if constexpr (X3) {
                     // hi = fp16(v) toward zero, lo = fp16((v - hi) * 2048): 4 values -> 8 bytes in each plane
-#if T2P_MASKSPLIT
-                    // truncating to fp16 == clearing the 13 low mantissa bits (exact in fp16's normal range; below it the
-                    // conversion drops < 2^-24 absolute, far under the fp32 rounding of the sums these feed)
-                    float hf[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) hf[e] = __uint_as_float(__float_as_uint(v[e]) & 0xFFFFE000u);
-                    const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]), h23 = __builtin_amdgcn_cvt_pkrtz(hf[2], hf[3]);
-                    const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - hf[0]) * 2048.f, (v[1] - hf[1]) * 2048.f);
-                    const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((v[2] - hf[2]) * 2048.f, (v[3] - hf[3]) * 2048.f);
-#else
                     const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                     const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.f, (v[1] - (float)h01[1]) * 2048.f);
                     const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * 2048.f, (v[3] - (float)h23[1]) * 2048.f);
-#endif
                     uint2 ph, pl;
                     ph.x = __builtin_bit_cast(uint32_t, h01); ph.y = __builtin_bit_cast(uint32_t, h23);
                     pl.x = __builtin_bit_cast(uint32_t, l01); pl.y = __builtin_bit_cast(uint32_t, l23);
@@ -436,38 +406,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 const int trow0 = (wm * RT + rt) * 32;
-                if (T2P_ABL & 1) {  // keep the MFMA results alive without the atomics
-#pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++) abl_keep16(acc[rt][nt]);
-                    continue;
-                }
                 if (it_c.r0 + trow0 >= it_c.n) continue;
-#if T2P_QUADMAX
-                // rows are sorted by destination inside an object, so most quads of 4 consecutive rows share one
-                // destination: reduce those in registers and issue one atomic instead of four
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t four = *(const uint32_t*)(dl + trow0 + 8 * q + 4 * h);
-                    const int d0 = (int)(four & 0xFF) * N, d3 = (int)(four >> 24) * N;
-                    if (d0 == d3) {
-#pragma unroll
-                        for (int nt = 0; nt < C::NTW; nt++) {
-                            int* col = accb + wn * C::NTW * 32 + nt * 32 + l31;
-                            const float m = fmaxf(fmaxf(acc[rt][nt][4 * q], acc[rt][nt][4 * q + 1]),
-                                                  fmaxf(acc[rt][nt][4 * q + 2], acc[rt][nt][4 * q + 3]));
-                            atomicMax(col + d0, __float_as_int(m));
-                        }
-                    } else {
-#pragma unroll
-                        for (int nt = 0; nt < C::NTW; nt++) {
-                            int* col = accb + wn * C::NTW * 32 + nt * 32 + l31;
-#pragma unroll
-                            for (int e = 0; e < 4; e++)
-                                atomicMax(col + (int)((four >> (8 * e)) & 0xFF) * N, __float_as_int(acc[rt][nt][4 * q + e]));
-                        }
-                    }
-                }
-#else
                 int doff[16];  // destination row offsets (ints) of this lane's 16 rows: 4 quads of 4 consecutive rows
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -481,13 +420,12 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
 #pragma unroll
                     for (int e = 0; e < 16; e++) atomicMax(col + doff[e], __float_as_int(acc[rt][nt][e]));
                 }
-#endif
             }
             if (it_c.r0 + C::TR >= it_c.n) {  // last batch of this object
                 flush_g = ga + it_c.gi;
                 flush_buf = abuf;
             }
-            if (!(T2P_ABL & 8) && valid(it_d)) write_tile((t + 1) & 1, meta_d);  // W(t+1)
+            if (valid(it_d)) write_tile((t + 1) & 1, meta_d);  // W(t+1)
             fix_meta(it_m, meta_m);
             meta_d = meta_m;
             it_c = it_d;
@@ -532,10 +470,23 @@ int launch_sa_cfg(const SaParams& p_in, hipStream_t st, const char* name) {
 
 }  // namespace
 
+int launch_ws_sa2(int H, int Cout, const SaParams& p, hipStream_t st);  // ws_sa2.hip
+
+int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st) {
+    ProfScope ps_("sa_balance", st);
+    hipLaunchKernelGGL(k_balance, dim3(1), dim3(1024), 0, st, p.n_rows, (int)p.n_obj, tile_rows, n_wg, p.prefix_ws,
+                       p.bounds_ws);
+    T2P_CHECK_LAUNCH("sa_balance");
+    return 0;
+}
+
 int launch_ws_sa(int H, int Cout, const SaParams& p, hipStream_t st) {
     T2P_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.Bc) & 15) == 0, "ws_sa: tables must be 16-byte aligned");
     if (p.W_x3 != nullptr) {  // f16x3 split-precision path
         T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_sa: packed f16x3 weights must be 16-byte aligned");
+#if !T2P_SA_V1
+        return launch_ws_sa2(H, Cout, p, st);
+#endif
         if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2, 1>(p, st, "ws_edge_sa_k32_n64");
         if (H == 128 && Cout == 128) return launch_sa_cfg<128, 128, 4, 1, 1>(p, st, "ws_edge_sa_k128_n128");
         if (H == 256 && Cout == 256) return launch_sa_cfg<256, 256, 8, 1, 1>(p, st, "ws_edge_sa_k256_n256");

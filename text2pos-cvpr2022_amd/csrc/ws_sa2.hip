@@ -1,0 +1,407 @@
+// Set-abstraction edge kernel, f16x3 path, instruction-interleaved schedule.
+// (reference: gnn.PointConv(local_nn)(x, (pos, pos[idx]), edge_index), models/pointcloud/pointnet2.py:31-35).
+//
+// Same data flow as ws_sa.hip (balanced contiguous object ranges, flattened batch stream, register-resident weights,
+// LDS atomic-max accumulator) but the batch loop is ONE straight-line block whose instruction order is pinned by hand:
+//
+//   * four batches are in flight per workgroup: MFMA on tile t (LDS), staging of tile t+1 (gathered rows held in
+//     registers -> ReLU(A_j - B_i) -> fp16 hi/lo planes in the other LDS buffer), gathers of batch t+2 (re-issued into
+//     each register quad as soon as its t+1 content is staged), row metadata of batch t+3;
+//   * the staging / gather work is cut into 12 chunks that are placed BETWEEN the MFMAs of the 16 (or 8, or 4) MFMA
+//     groups -- in the shadow of the accx -> accx accumulator dependency -- with __builtin_amdgcn_sched_barrier fences,
+//     so VALU, LDS, the texture path and the matrix pipe work at the same time inside every wave instead of taking
+//     turns between barriers (measured on the phase-per-barrier kernel: MFMA, gather and staging time simply added up);
+//   * all loads are unconditional: padding rows read row 0 of their object and are routed to the accumulator's dummy
+//     row, so the block has no branches besides the (rare) accumulator flush.
+// T2P_TRACE: wave 0 of block 0 stamps s_memtime at 8 points of its first 96 batches into prefix_ws; printed by the launcher
+#ifndef T2P_TRACE
+#define T2P_TRACE 0
+#endif
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#include "t2p_common.h"
+
+namespace t2p {
+int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st);  // ws_sa.hip
+
+namespace {
+
+constexpr int kSub = 512;
+constexpr int NT = 512;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+template <int K, int N, int WN, int RT>
+struct Cfg2 {
+    static constexpr int WM = 8 / WN;
+    static constexpr int NTW = N / (32 * WN);
+    static constexpr int TR = WM * RT * 32;
+    static constexpr int F4_PER_ROW = K / 4;
+    static constexpr int ITERS = TR * F4_PER_ROW / NT;
+    static_assert(ITERS == 4 && TR * F4_PER_ROW == ITERS * NT, "every thread stages 4 consecutive rows of one column quad");
+    static constexpr int LDHH = K + 8;       // halves; 16-byte pad keeps ds_read_b128 conflict-free
+    static constexpr int PLANE = TR * LDHH;  // halves per plane
+    static constexpr int S16 = K / 16;
+    static constexpr int ACC_INTS = 8192 + N;
+    static constexpr int NG = S16 * RT;      // MFMA groups per batch and wave
+    static constexpr int NCH = 3 * ITERS;    // staging chunks per batch and thread
+    static constexpr size_t lds_bytes() {
+        return (size_t)2 * 2 * PLANE * 2 + (size_t)2 * ACC_INTS * 4 + 4 * TR + kSub * 2 + kSub * 4;
+    }
+};
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+
+#if T2P_TRACE
+#define STAMP(i)                                                                                           \
+    if (blockIdx.x == 0 && tid == 0 && trace_n < 96) p.prefix_ws[trace_n * 8 + (i)] = (int)__builtin_amdgcn_s_memtime();
+#else
+#define STAMP(i)
+#endif
+
+struct BatchIt {
+    int gi, r0, n;
+    int sb;  // source row of centroid 0's self loop for the current object (kept from the last object past the end)
+};
+
+#define CHUNKS()                                                                              \
+    _Pragma("unroll") for (int c = (j * C::NCH) / C::NG; c < ((j + 1) * C::NCH) / C::NG; c++) { \
+        const int k = c / 3, part = c % 3;                                                     \
+        if (part == 0) stage_a(sbuf, k);                                                       \
+        else if (part == 1) stage_b(sbuf, k);                                                  \
+        else issue(it_g, meta_g, k, dbuf);                                                     \
+    }
+
+template <int K, int N, int WN, int RT>
+__global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
+    using C = Cfg2<K, N, WN, RT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    _Float16* hidh = (_Float16*)lds;                            // [2][hi plane | lo plane]
+    int* acc_lds = (int*)(hidh + 2 * 2 * C::PLANE);             // [2][ACC_INTS]
+    uint8_t* dstl = (uint8_t*)(acc_lds + 2 * C::ACC_INTS);      // [4][TR] destination (centroid) of every staged row
+    uint16_t* nr = (uint16_t*)(dstl + 4 * C::TR);               // [kSub]
+    int* sbase = (int*)(nr + kSub);                             // [kSub]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN, h = lane >> 5, l31 = lane & 31;
+    const int nc = p.n_cent;
+    const int maxr = nc * 33;
+
+    half8 w_hi[C::NTW][C::S16], w_lo[C::NTW][C::S16];
+    {
+        const uint4* wp = (const uint4*)p.W_x3;
+        constexpr int PLANE_U4 = (N / 32) * C::S16 * 64;
+#pragma unroll
+        for (int nt = 0; nt < C::NTW; nt++)
+#pragma unroll
+            for (int s = 0; s < C::S16; s++) {
+                const int idx = (((wn * C::NTW + nt) * C::S16 + s) * 2 + h) * 32 + l31;
+                const uint4 a = wp[idx], b = wp[PLANE_U4 + idx];
+                w_hi[nt][s] = __builtin_bit_cast(half8, a);
+                w_lo[nt][s] = __builtin_bit_cast(half8, b);
+            }
+    }
+    float bias[C::NTW];
+#pragma unroll
+    for (int nt = 0; nt < C::NTW; nt++) bias[nt] = p.bias[wn * C::NTW * 32 + nt * 32 + l31];
+
+    for (int i = tid; i < 2 * C::ACC_INTS; i += NT) acc_lds[i] = 0;
+
+    const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
+    const int rgrp = (tid / C::F4_PER_ROW) * C::ITERS;  // first of this thread's 4 staged rows inside a batch
+    const int c4 = tid % C::F4_PER_ROW;
+    const uint32_t c4b = (uint32_t)c4 * 16u;
+    typedef uint16_t metav __attribute__((ext_vector_type(4)));
+
+    for (int ga = g_begin; ga < g_end; ga += kSub) {
+        const int cnt = (g_end - ga) < kSub ? (g_end - ga) : kSub;
+        __syncthreads();
+        for (int i = tid; i < cnt; i += NT) {
+            const int g = ga + i;
+            nr[i] = p.n_rows[g];
+            const int first = p.first[g];
+            sbase[i] = first * p.n_dense + (g - first) * nc;
+        }
+        __syncthreads();
+
+        auto advance = [&](BatchIt it) -> BatchIt {
+            it.r0 += C::TR;
+            if (it.r0 >= it.n) {
+                it.gi++;
+                it.r0 = 0;
+                it.n = it.gi < cnt ? (int)nr[it.gi] : 0;
+                if (it.gi < cnt) it.sb = sbase[it.gi];
+            }
+            return it;
+        };
+        auto valid = [&](const BatchIt& it) { return it.gi < cnt; };
+
+        metav meta_g, meta_m;
+        f32x4 sa[4], sb[4];
+        f32x4 vv;            // staged values between the two halves of a staging step
+        fp16x2 vh01, vh23;
+
+        // row metadata of a batch: the load is issued early, the clean-up of rows past the object's end runs at the
+        // end of the batch (touching the value earlier would put a vmcnt wait in front of the MFMAs)
+        auto load_meta = [&](const BatchIt& it, metav& m) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) m[k] = 0xFFFF;
+            if (valid(it) && it.r0 + rgrp < it.n) {
+                const uint32_t off = (uint32_t)(ga + it.gi) * (uint32_t)maxr + (uint32_t)(it.r0 + rgrp);
+                m = *(const metav*)(p.rows + off);
+            }
+        };
+        auto fix_meta = [&](const BatchIt& it, metav& m) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (it.r0 + rgrp + k >= it.n) m[k] = 0xFFFF;
+        };
+        // gathers of row k of a batch (A_j and B_i) + its destination byte.  Unconditional: padding rows (and batches
+        // past the end of the range) read row 0 of a valid object and go to the dummy accumulator row n_cent.
+        auto issue = [&](const BatchIt& it, const metav& m, int k, int dbuf) {
+            const int gi = it.gi < cnt ? it.gi : cnt - 1;
+            const uint32_t g = (uint32_t)(ga + gi);
+            const uint32_t sb0 = (uint32_t)it.sb;
+            const bool pad = m[k] == 0xFFFF;
+            const uint32_t mm = pad ? 0u : (uint32_t)m[k];
+            const uint32_t src = mm & 0xFF, d = mm >> 8, dl = d & 127;
+            const uint32_t srow = (d & 0x80) ? (sb0 + src) : (g * (uint32_t)p.n_dense + src);
+            {
+                // 32-bit BYTE offsets from the uniform table bases (checked by the launcher): SGPR base + VGPR offset loads
+                sa[k] = *(const f32x4*)((const char*)p.A + (srow * (uint32_t)(K * 4) + c4b));
+                sb[k] = *(const f32x4*)((const char*)p.Bc + ((g * (uint32_t)nc + dl) * (uint32_t)(K * 4) + c4b));
+            }
+            if (c4 == 0) dstl[dbuf * C::TR + rgrp + k] = pad ? (uint8_t)nc : (uint8_t)dl;
+        };
+        // staging of row k, first half: v = relu(A_j - B_i), hi = fp16(v) toward zero -> hi plane
+        auto stage_a = [&](int buf, int k) {
+            _Float16* dsth = hidh + buf * 2 * C::PLANE;
+            const f32x4 t = sa[k] - sb[k];
+#pragma unroll
+            for (int e = 0; e < 4; e++) vv[e] = fmaxf(t[e], 0.f);
+            vh01 = __builtin_amdgcn_cvt_pkrtz(vv[0], vv[1]);
+            vh23 = __builtin_amdgcn_cvt_pkrtz(vv[2], vv[3]);
+            uint2 ph;
+            ph.x = __builtin_bit_cast(uint32_t, vh01);
+            ph.y = __builtin_bit_cast(uint32_t, vh23);
+            *(uint2*)(dsth + (rgrp + k) * C::LDHH + c4 * 4) = ph;
+        };
+        // second half: lo = fp16((v - hi) * 2048) -> lo plane
+        auto stage_b = [&](int buf, int k) {
+            _Float16* dsth = hidh + buf * 2 * C::PLANE;
+            const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((vv[0] - (float)vh01[0]) * 2048.f, (vv[1] - (float)vh01[1]) * 2048.f);
+            const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((vv[2] - (float)vh23[0]) * 2048.f, (vv[3] - (float)vh23[1]) * 2048.f);
+            uint2 pl;
+            pl.x = __builtin_bit_cast(uint32_t, l01);
+            pl.y = __builtin_bit_cast(uint32_t, l23);
+            *(uint2*)(dsth + C::PLANE + (rgrp + k) * C::LDHH + c4 * 4) = pl;
+        };
+        auto flush = [&](int64_t g, int abuf) {
+            int* a = acc_lds + abuf * C::ACC_INTS;
+            float* o = p.out + g * nc * (int64_t)p.ldo;
+            for (int i = tid; i < nc * N; i += NT) {
+                const int c = i / N, col = i % N;
+                o[c * (int64_t)p.ldo + col] = __int_as_float(a[i]);
+                a[i] = 0;
+            }
+        };
+
+        BatchIt it_c{0, 0, (int)nr[0], sbase[0]};
+        BatchIt it_s = advance(it_c);
+        BatchIt it_g = advance(it_s);
+        BatchIt it_m = advance(it_g);
+        // prologue: tile 0 staged, gathers of batch 1 in flight, metadata of batch 2 in registers
+        load_meta(it_c, meta_g);
+        fix_meta(it_c, meta_g);
+#pragma unroll
+        for (int k = 0; k < 4; k++) issue(it_c, meta_g, k, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            stage_a(0, k);
+            stage_b(0, k);
+        }
+        load_meta(it_s, meta_g);
+        fix_meta(it_s, meta_g);
+#pragma unroll
+        for (int k = 0; k < 4; k++) issue(it_s, meta_g, k, 1);
+        load_meta(it_g, meta_g);
+        fix_meta(it_g, meta_g);
+        __syncthreads();
+
+        int64_t flush_g = -1;
+        int flush_buf = 0;
+        int trace_n = 0;
+        for (int t = 0; valid(it_c); t++) {
+            STAMP(0);
+            if (flush_g >= 0) {  // the object finished in the previous batch drains to HBM
+                flush(flush_g, flush_buf);
+                flush_g = -1;
+            }
+
+            const int buf = t & 1, sbuf = buf ^ 1, dbuf = (t + 2) & 3;
+            BatchIt it_n = it_m;
+            f32x16 acc[RT][C::NTW], accx[RT][C::NTW];
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int nt = 0; nt < C::NTW; nt++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        acc[rt][nt][e] = bias[nt];
+                        accx[rt][nt][e] = 0.f;
+                    }
+            STAMP(1);
+            // destination bytes of this lane's 16 accumulator rows (4 quads of 4 consecutive rows per row tile); written
+            // two batches ago, fetched here so that the atomics behind the MFMAs do not start with an LDS round trip
+            uint32_t four[RT][4];
+            constexpr bool HOIST = K <= 128;  // K = 256 has no registers to spare (weights alone take 128)
+            auto load_four = [&]() {
+                const uint8_t* dl = dstl + (t & 3) * C::TR;
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) four[rt][q] = *(const uint32_t*)(dl + (wm * RT + rt) * 32 + 8 * q + 4 * h);
+            };
+            if constexpr (HOIST) load_four();
+            const _Float16* hrow = hidh + buf * 2 * C::PLANE + ((wm * RT) * 32 + l31) * C::LDHH + h * (K / 2);
+            half8 a_hi = *(const half8*)(hrow), a_lo = *(const half8*)(hrow + C::PLANE), n_hi = a_hi, n_lo = a_lo;
+#pragma unroll
+            for (int j = 0; j < C::NG; j++) {
+                const int s = j / RT, rt = j % RT;
+                SB();
+                if (j + 1 < C::NG) {
+                    const int s2 = (j + 1) / RT, rt2 = (j + 1) % RT;
+                    n_hi = *(const half8*)(hrow + rt2 * 32 * C::LDHH + s2 * 8);
+                    n_lo = *(const half8*)(hrow + C::PLANE + rt2 * 32 * C::LDHH + s2 * 8);
+                }
+#pragma unroll
+                for (int nt = 0; nt < C::NTW; nt++) {
+                    acc[rt][nt] = MFMA16(a_hi, w_hi[nt][s], acc[rt][nt]);
+                    accx[rt][nt] = MFMA16(a_hi, w_lo[nt][s], accx[rt][nt]);
+                }
+                SB();
+                if (j == 0) load_meta(it_m, meta_m);  // M(t+3); issued behind the first MFMAs so nothing waits on it
+                CHUNKS();
+                SB();
+#pragma unroll
+                for (int nt = 0; nt < C::NTW; nt++)
+                    accx[rt][nt] = MFMA16(a_lo, w_hi[nt][s], accx[rt][nt]);
+                a_hi = n_hi;
+                a_lo = n_lo;
+                if (j == C::NG / 2 - 1) {
+                    STAMP(2);
+                    it_n = advance(it_m);  // iterator bookkeeping (LDS reads of the object table) off the loop's tail
+                }
+            }
+            STAMP(3);
+            SB();
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int nt = 0; nt < C::NTW; nt++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[rt][nt][e] = fmaf(accx[rt][nt][e], 1.f / 2048.f, acc[rt][nt][e]);
+
+            STAMP(4);
+            if constexpr (!HOIST) load_four();
+            // max-aggregation: integer atomic max into the object's LDS accumulator (the max against +0 is the ReLU)
+            const int abuf = it_c.gi & 1;
+            int* accb = acc_lds + abuf * C::ACC_INTS;
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const int trow0 = (wm * RT + rt) * 32;
+                if (it_c.r0 + trow0 >= it_c.n) continue;
+                int doff[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) doff[4 * q + e] = (int)((four[rt][q] >> (8 * e)) & 0xFF) * N;
+                }
+#pragma unroll
+                for (int nt = 0; nt < C::NTW; nt++) {
+                    int* col = accb + wn * C::NTW * 32 + nt * 32 + l31;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) atomicMax(col + doff[e], __float_as_int(acc[rt][nt][e]));
+                }
+            }
+            STAMP(5);
+            if (it_c.r0 + C::TR >= it_c.n) {
+                flush_g = ga + it_c.gi;
+                flush_buf = abuf;
+            }
+            fix_meta(it_m, meta_m);
+            meta_g = meta_m;
+            it_c = it_s;
+            it_s = it_g;
+            it_g = it_m;
+            it_m = advance(it_m);
+            STAMP(6);
+            __syncthreads();
+            STAMP(7);
+            trace_n++;
+        }
+        if (flush_g >= 0) flush(flush_g, flush_buf);
+    }
+}
+
+template <int K, int N, int WN, int RT>
+int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
+    using C = Cfg2<K, N, WN, RT>;
+    auto kern = k_ws_sa2<K, N, WN, RT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)C::lds_bytes());
+        if (e != hipSuccess) {
+            set_error("ws_sa2: cannot reserve %zu B of LDS: %s", C::lds_bytes(), hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    if (p.n_obj <= 0) return 0;
+    T2P_CHECK_ARG(p.n_obj < (1 << 30) && p.n_obj * p.n_dense * (int64_t)K * 4 < 0xffffffffLL &&
+                      p.n_obj * p.n_cent * (int64_t)K * 4 < 0xffffffffLL,
+                  "ws_sa: chunk too large for 32-bit table offsets");
+    int n_wg = num_cus();
+    if (n_wg > p.n_obj) n_wg = (int)p.n_obj;
+    int rc = launch_sa_balance(p, C::TR, n_wg, st);
+    if (rc != 0) return rc;
+    ProfScope ps_(name, st);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NT), C::lds_bytes(), st, p);
+    T2P_CHECK_LAUNCH("ws_sa2");
+#if T2P_TRACE
+    {
+        static int printed = 0;
+        if (!printed && K == T2P_TRACE) {
+            printed = 1;
+            hipStreamSynchronize(st);
+            int h[96 * 8];
+            hipMemcpy(h, p.prefix_ws, sizeof(h), hipMemcpyDeviceToHost);
+            double sum[8] = {0};
+            for (int b = 8; b < 88; b++)
+                for (int i = 0; i < 8; i++) sum[i] += (double)(unsigned)(h[b * 8 + (i + 1) % 8 + (i == 7 ? 8 : 0)] - h[b * 8 + i]);
+            fprintf(stderr, "[trace %s] mean s_memtime ticks per segment over 80 batches:", name);
+            for (int i = 0; i < 8; i++) fprintf(stderr, " s%d->%d=%.0f", i, (i + 1) % 8, sum[i] / 80);
+            fprintf(stderr, "\n");
+            for (int b = 8; b < 14; b++) {
+                fprintf(stderr, "[trace] batch %d:", b);
+                for (int i = 0; i < 7; i++) fprintf(stderr, " %u", (unsigned)(h[b * 8 + i + 1] - h[b * 8 + i]));
+                fprintf(stderr, " | next %u\n", (unsigned)(h[(b + 1) * 8] - h[b * 8 + 7]));
+            }
+        }
+    }
+#endif
+    return 0;
+}
+
+}  // namespace
+
+int launch_ws_sa2(int H, int Cout, const SaParams& p, hipStream_t st) {
+    if (H == 32 && Cout == 64) return launch_cfg2<32, 64, 2, 2>(p, st, "ws_edge_sa_k32_n64");
+    if (H == 128 && Cout == 128) return launch_cfg2<128, 128, 4, 1>(p, st, "ws_edge_sa_k128_n128");
+    if (H == 256 && Cout == 256) return launch_cfg2<256, 256, 8, 1>(p, st, "ws_edge_sa_k256_n256");
+    set_error("ws_sa2: no instantiation for H=%d C=%d", H, Cout);
+    return T2P_E_UNSUPPORTED;
+}
+
+}  // namespace t2p
