@@ -226,12 +226,39 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
         for (int k = 0; k < 4; k++) issue(it_s, meta_g, k, 1);
         load_meta(it_g, meta_g);
         fix_meta(it_g, meta_g);
+        for (int i = tid; i < C::TR; i += NT) dstl[3 * C::TR + i] = (uint8_t)nc;  // "batch -1": every row is padding
         __syncthreads();
 
-        int64_t flush_g = -1;
-        int flush_buf = 0;
+        int64_t flush_g = -1, flush_g1 = -1;
+        int flush_buf = 0, flush_buf1 = 0;
         int trace_n = 0;
+        // DEFER (K <= 128, registers to spare): the atomics of batch t-1 ride between the MFMAs of batch t, fed from a
+        // copy of its results; one more batch passes before a finished object may be flushed.
+        constexpr bool DEFER = K <= 128;
+        f32x16 res[DEFER ? RT : 1][DEFER ? C::NTW : 1];
+        int prev_abuf = 0;
+        if constexpr (DEFER) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int nt = 0; nt < C::NTW; nt++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) res[rt][nt][e] = 0.f;
+        }
+        // atomics e0 .. e1-1 (flattened over row tile, column tile, accumulator register) of a finished batch
+        auto atomics = [&](const f32x16 (&v)[DEFER ? RT : 1][DEFER ? C::NTW : 1], const uint32_t (&four)[RT][4], int abuf,
+                           int e0, int e1) {
+            int* accb = acc_lds + abuf * C::ACC_INTS;
+#pragma unroll
+            for (int idx = e0; idx < e1; idx++) {
+                const int rt = idx / (C::NTW * 16), nt = (idx / 16) % C::NTW, e = idx % 16;
+                const int doff = (int)((four[rt][e >> 2] >> (8 * (e & 3))) & 0xFF) * N;
+                atomicMax(accb + wn * C::NTW * 32 + nt * 32 + l31 + doff, __float_as_int(v[rt][nt][e]));
+            }
+        };
+        int t_end = 0;
         for (int t = 0; valid(it_c); t++) {
+            t_end = t + 1;
             STAMP(0);
             if (flush_g >= 0) {  // the object finished in the previous batch drains to HBM
                 flush(flush_g, flush_buf);
@@ -254,9 +281,9 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
             // destination bytes of this lane's 16 accumulator rows (4 quads of 4 consecutive rows per row tile); written
             // two batches ago, fetched here so that the atomics behind the MFMAs do not start with an LDS round trip
             uint32_t four[RT][4];
-            constexpr bool HOIST = K <= 128;  // K = 256 has no registers to spare (weights alone take 128)
+            constexpr bool HOIST = DEFER;  // K = 256 has no registers to spare (weights alone take 128)
             auto load_four = [&]() {
-                const uint8_t* dl = dstl + (t & 3) * C::TR;
+                const uint8_t* dl = dstl + ((DEFER ? t + 3 : t) & 3) * C::TR;
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -282,6 +309,10 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
                 SB();
                 if (j == 0) load_meta(it_m, meta_m);  // M(t+3); issued behind the first MFMAs so nothing waits on it
                 CHUNKS();
+                if constexpr (DEFER) {
+                    constexpr int TOT = RT * C::NTW * 16;
+                    atomics(res, four, prev_abuf, (j * TOT) / C::NG, ((j + 1) * TOT) / C::NG);
+                }
                 SB();
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++)
@@ -295,52 +326,78 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
             }
             STAMP(3);
             SB();
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                for (int nt = 0; nt < C::NTW; nt++)
-#pragma unroll
-                    for (int e = 0; e < 16; e++) acc[rt][nt][e] = fmaf(accx[rt][nt][e], 1.f / 2048.f, acc[rt][nt][e]);
-
-            STAMP(4);
-            if constexpr (!HOIST) load_four();
-            // max-aggregation: integer atomic max into the object's LDS accumulator (the max against +0 is the ReLU)
             const int abuf = it_c.gi & 1;
-            int* accb = acc_lds + abuf * C::ACC_INTS;
+            const bool obj_done = it_c.r0 + C::TR >= it_c.n;
+            if constexpr (DEFER) {
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
-                const int trow0 = (wm * RT + rt) * 32;
-                if (it_c.r0 + trow0 >= it_c.n) continue;
-                int doff[16];
+                for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                    for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) doff[4 * q + e] = (int)((four[rt][q] >> (8 * e)) & 0xFF) * N;
+                        for (int e = 0; e < 16; e++) res[rt][nt][e] = fmaf(accx[rt][nt][e], 1.f / 2048.f, acc[rt][nt][e]);
+                prev_abuf = abuf;
+                // the object whose atomics ran in this batch may be flushed next; the one that just ended waits a batch
+                flush_g = flush_g1;
+                flush_buf = flush_buf1;
+                flush_g1 = obj_done ? (int64_t)(ga + it_c.gi) : -1;
+                flush_buf1 = abuf;
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int nt = 0; nt < C::NTW; nt++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) acc[rt][nt][e] = fmaf(accx[rt][nt][e], 1.f / 2048.f, acc[rt][nt][e]);
+                STAMP(4);
+                load_four();
+                // max-aggregation: integer atomic max into the object's LDS accumulator (the max against +0 is the ReLU)
+                int* accb = acc_lds + abuf * C::ACC_INTS;
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const int trow0 = (wm * RT + rt) * 32;
+                    if (it_c.r0 + trow0 >= it_c.n) continue;
+                    int doff[16];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) doff[4 * q + e] = (int)((four[rt][q] >> (8 * e)) & 0xFF) * N;
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < C::NTW; nt++) {
+                        int* col = accb + wn * C::NTW * 32 + nt * 32 + l31;
+#pragma unroll
+                        for (int e = 0; e < 16; e++) atomicMax(col + doff[e], __float_as_int(acc[rt][nt][e]));
+                    }
                 }
-#pragma unroll
-                for (int nt = 0; nt < C::NTW; nt++) {
-                    int* col = accb + wn * C::NTW * 32 + nt * 32 + l31;
-#pragma unroll
-                    for (int e = 0; e < 16; e++) atomicMax(col + doff[e], __float_as_int(acc[rt][nt][e]));
+                STAMP(5);
+                if (obj_done) {
+                    flush_g = ga + it_c.gi;
+                    flush_buf = abuf;
                 }
-            }
-            STAMP(5);
-            if (it_c.r0 + C::TR >= it_c.n) {
-                flush_g = ga + it_c.gi;
-                flush_buf = abuf;
             }
             fix_meta(it_m, meta_m);
             meta_g = meta_m;
             it_c = it_s;
             it_s = it_g;
             it_g = it_m;
-            it_m = advance(it_m);
+            it_m = it_n;
             STAMP(6);
             __syncthreads();
             STAMP(7);
             trace_n++;
         }
         if (flush_g >= 0) flush(flush_g, flush_buf);
+        if constexpr (DEFER) {  // drain: atomics of the last batch, then its object
+            uint32_t four[RT][4];
+            const uint8_t* dl = dstl + ((t_end + 3) & 3) * C::TR;
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) four[rt][q] = *(const uint32_t*)(dl + (wm * RT + rt) * 32 + 8 * q + 4 * h);
+            atomics(res, four, prev_abuf, 0, RT * C::NTW * 16);
+            __syncthreads();
+            if (flush_g1 >= 0) flush(flush_g1, flush_buf1);
+        }
     }
 }
 
