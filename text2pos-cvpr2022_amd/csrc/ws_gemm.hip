@@ -22,6 +22,9 @@
 //     the MFMA block of batch t; their VALU part and the LDS write follow it; one barrier per batch.
 //   * Column slices of one row stream (GA: N = 1024 in slices of 128) are mapped to the same XCD (block b runs on
 //     XCD b % 8), so they share the stream's A rows through that XCD's L2.
+#ifndef T2P_GA1_V1
+#define T2P_GA1_V1 0
+#endif
 #ifndef T2P_GA2_V1
 #define T2P_GA2_V1 0
 #endif
@@ -38,7 +41,9 @@ constexpr int kAccFloats = 8192;    // 32 x 256
 
 template <int K, int NW, int WN, int RT, int MODE, int X3>
 struct WsCfg {
-    static constexpr int WM = 4 / WN;
+    static constexpr int NWAVES = WN > 4 ? WN : 4;  // WN = 8: eight waves (two per SIMD, <= 256 registers each)
+    static constexpr int NTH = 64 * NWAVES;
+    static constexpr int WM = NWAVES / WN;
     static constexpr int NTW = NW / (32 * WN);
     static constexpr int KS = K / 2;
     static constexpr int TR = WM * RT * 32;  // rows staged per barrier interval
@@ -51,7 +56,7 @@ struct WsCfg {
     static constexpr int ACC_FLOATS = EDGE ? kAccFloats : 0;
     static constexpr int F4_PER_ROW = K / 4;
     static constexpr int TOTAL_F4 = TR * F4_PER_ROW;
-    static constexpr int ITERS = (TOTAL_F4 + 255) / 256;
+    static constexpr int ITERS = (TOTAL_F4 + NTH - 1) / NTH;
     static constexpr size_t lds_bytes() {
         size_t b = (size_t)(2 * TILE_FLOATS + ACC_FLOATS) * 4;
         if (EDGE) b += (size_t)kMaxRows * 4 + kMaxRows + 40 * 4;
@@ -64,7 +69,7 @@ struct WsCfg {
 };
 
 template <int K, int NW, int WN, int RT, int MODE, int X3, int SPLIT_IO>
-__global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
+__global__ __launch_bounds__(WN > 4 ? 512 : 256, WN > 4 ? 2 : 1) void k_ws(WsParams p, int n_slices) {
     using C = WsCfg<K, NW, WN, RT, MODE, X3>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* hid = lds;                  // fp32: two buffers of TILE_FLOATS
@@ -126,12 +131,12 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
     auto stage_load = [&](int64_t g, int r0, int n_rows) {
 #pragma unroll
         for (int it = 0; it < C::ITERS; it++) {
-            const int q = it * 256 + tid;
+            const int q = it * C::NTH + tid;
             const int lr = q / C::F4_PER_ROW, c4 = q % C::F4_PER_ROW;
             const int r = r0 + lr;
             sa[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (C::EDGE) sb[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (((C::TOTAL_F4 % 256) == 0 || q < C::TOTAL_F4) && (r < n_rows || SPLIT_IO == 1)) {
+            if (((C::TOTAL_F4 % C::NTH) == 0 || q < C::TOTAL_F4) && (r < n_rows || SPLIT_IO == 1)) {
                 if constexpr (C::EDGE) {
                     const int src = rows_src[r];
                     const int dl = rows_dst[r];
@@ -157,8 +162,8 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
     auto stage_write = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < C::ITERS; it++) {
-            const int q = it * 256 + tid;
-            if ((C::TOTAL_F4 % 256) != 0 && q >= C::TOTAL_F4) break;
+            const int q = it * C::NTH + tid;
+            if ((C::TOTAL_F4 % C::NTH) != 0 && q >= C::TOTAL_F4) break;
             const int lr = q / C::F4_PER_ROW, c4 = q % C::F4_PER_ROW;
             f32x4 v = sa[it];
             if constexpr (C::EDGE) {
@@ -292,21 +297,23 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
                 for (int nt = 0; nt < C::NTW; nt++) {
                     const int lcol = wn * C::NTW * 32 + nt * 32 + l31;
                     if constexpr (MODE == WS_DENSE_STORE) {
+                        // rows of this lane: trow0 + 4h + (e & 3) + 8 (e >> 2); one base pointer, uniform row steps
+                        const int64_t o0 = (g * C::TR + trow0 + 4 * h) * (int64_t)p.ldo + slice * NW + lcol;
 #pragma unroll
                         for (int e = 0; e < 16; e++) {
-                            const int r = trow0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            const int rr = (e & 3) + 8 * (e >> 2);
+                            const int r = trow0 + 4 * h + rr;
                             float v = acc[rt][nt][e];
                             if (p.relu) v = fmaxf(v, 0.f);
                             if constexpr (SPLIT_IO == 2) {  // hand the activations on already split into fp16 hi / lo
                                 const fp16x2 hv = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
                                 const fp16x2 lv = __builtin_amdgcn_cvt_pkrtz((v - (float)hv[0]) * 2048.f, 0.f);
-                                const int64_t o = (g * C::TR + r) * (int64_t)p.ldo + slice * NW + lcol;
                                 if (r < n_rows) {
-                                    ((__fp16*)p.out_hi)[o] = hv[0];
-                                    ((__fp16*)p.out_lo)[o] = lv[0];
+                                    ((__fp16*)p.out_hi + o0)[rr * p.ldo] = hv[0];
+                                    ((__fp16*)p.out_lo + o0)[rr * p.ldo] = lv[0];
                                 }
                             } else {
-                                if (r < n_rows) p.out[(g * C::TR + r) * (int64_t)p.ldo + slice * NW + lcol] = v;
+                                if (r < n_rows) (p.out + o0)[rr * p.ldo] = v;
                             }
                         }
                     } else {  // max over each 32-row tile = one object (ReLU = starting the max at 0)
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
                     else if (p.mean) { rows_src[off] = 0; rows_dst[off] = 0xFF; off++; }
                 }
             }
-            for (int i = tid; i < kAccFloats; i += 256) acc_lds[i] = 0;
+            for (int i = tid; i < kAccFloats; i += C::NTH) acc_lds[i] = 0;
             __syncthreads();
 
             const int n_batches = (n_rows + C::TR - 1) / C::TR;
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void k_ws(WsParams p, int n_slices) {
                 if (more) stage_write((bt + 1) & 1);
                 __syncthreads();
             }
-            for (int i = tid; i < nd * NW; i += 256) {
+            for (int i = tid; i < nd * NW; i += C::NTH) {
                 const int c = i / NW, col = i % NW;
                 p.out[(d0 + c) * (int64_t)p.ldo + col] = __int_as_float(acc_lds[i]);
             }
@@ -458,7 +465,7 @@ int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
     static char name[64];
     if (name[0] == 0) snprintf(name, sizeof(name), "ws_%s_k%d_n%d", kMode[MODE], K, NW * n_slices);
     ProfScope ps_(name, st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::lds_bytes(), st, p, n_slices);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTH), C::lds_bytes(), st, p, n_slices);
     T2P_CHECK_LAUNCH("ws_gemm");
     return 0;
 }
@@ -491,7 +498,11 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
     WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 0, 0)
     WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 1, 0)
     WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 1, 0)
+#if T2P_GA1_V1
     WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 1, 2)
+#else
+    WS_CASE(WS_DENSE_STORE, 288, 512, 256, 8, 1, 1, 2)  // 8 waves: two per SIMD, two column slices instead of four
+#endif
     // GA layer 2 + max over the 32 points of an object
     WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 0, 0)
 #if !T2P_GA2_V1
