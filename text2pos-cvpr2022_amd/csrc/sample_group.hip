@@ -82,46 +82,36 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
         z[j] = v ? pz[i] : 0.f;
         mind[j] = INFINITY;
     }
+    // FPS and ball query share their distance pass: iteration c measures every dense point against centroid c (chosen
+    // by the previous iteration), which is both the FPS update for the choice of centroid c+1 and the ball-query test
+    // of centroid c -- same dist2() call, so the same bits as two separate passes.
+    // The hits are emitted as the object's compact edge-row list (sorted by centroid), one u16 per row: low byte =
+    // source (dense index; for a self-loop row: the centroid index), high byte = centroid | 0x80 if self loop.
     int cur = 0;
-    if (lane == 0) sel[0] = 0;
-    for (int s = 1; s < n_c; s++) {
-        float cx = px[cur], cy = py[cur], cz = pz[cur];
-        float bd = -1.f;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            int i = lane + 64 * j;
-            if (i < n_d) {
-                float d = dist2(x[j], y[j], z[j], cx, cy, cz);
-                mind[j] = d < mind[j] ? d : mind[j];
-                if (mind[j] > bd) { bd = mind[j]; bi = i; }
-            }
-        }
-        wave_argmax(bd, bi);
-        cur = bi;
-        if (lane == 0) sel[s] = (uint8_t)cur;
-    }
-    __syncthreads();
-    for (int c = lane; c < n_c; c += 64) {
-        int i = sel[c];
-        qx[c] = px[i];
-        qy[c] = py[i];
-        qz[c] = pz[i];
-    }
-    __syncthreads();
-    // ball query: centroids one after the other, the wave scans the dense points 64 at a time in ascending order
-    // The same hits are also emitted as the object's compact edge-row list (sorted by centroid), one u16 per row:
-    // low byte = source (dense index; for a self-loop row: the centroid index), high byte = centroid | 0x80 if self loop.
     int base = 0;
     for (int c = 0; c < n_c; c++) {
-        float cx = qx[c], cy = qy[c], cz = qz[c];
+        const float cx = px[cur], cy = py[cur], cz = pz[cur];
+        if (lane == 0) {
+            sel[c] = (uint8_t)cur;
+            qx[c] = cx;
+            qy[c] = cy;
+            qz[c] = cz;
+        }
+        float bd = -1.f;
+        int bi = 0x7fffffff;
         int count = 0;
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
-            int i = lane + 64 * j;
-            bool hit = (i < n_d) && (dist2(x[j], y[j], z[j], cx, cy, cz) < r2);
-            unsigned long long m = __ballot(hit);
-            int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+            const int i = lane + 64 * j;
+            const bool in = i < n_d;
+            const float d = dist2(x[j], y[j], z[j], cx, cy, cz);
+            if (in) {
+                mind[j] = d < mind[j] ? d : mind[j];
+                if (mind[j] > bd) { bd = mind[j]; bi = i; }
+            }
+            const bool hit = in && (d < r2);
+            const unsigned long long m = __ballot(hit);
+            const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
             if (hit && pos < kMaxNbr) {
                 if (nbr_lds) nbr_lds[c * kMaxNbr + pos] = (uint8_t)i;
                 rows_lds[base + pos] = (uint16_t)((c << 8) | i);
@@ -134,6 +124,10 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
             if (self_loops) rows_lds[base + kept] = (uint16_t)(((c | 0x80) << 8) | c);
         }
         base += kept + (self_loops ? 1 : 0);
+        if (c + 1 < n_c) {  // uniform
+            wave_argmax(bd, bi);
+            cur = bi;
+        }
     }
     // pad the list to a multiple of 4 rows with the "no row" marker, so that consumers may fetch 4 rows per load
     if (lane < 4) rows_lds[base + lane] = 0xFFFF;
