@@ -72,10 +72,13 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
                       uint8_t* sel, float* qx, float* qy, float* qz, uint8_t* nbr_lds, uint8_t* cnt_lds,
                       uint16_t* rows_lds, int self_loops, int* n_rows_out) {
     const int lane = threadIdx.x;
+    // Lane l owns the CONTIGUOUS points [l*PPL, (l+1)*PPL): ascending index order is then lane-major, so "ties -> lowest
+    // index" is "lowest lane, then lowest j" (one ballot + s_ff1 instead of a second wave reduction), and a hit's rank
+    // in the ascending neighbour list is (hits in lower lanes) + (own earlier hits).
     float x[PPL], y[PPL], z[PPL], mind[PPL];
 #pragma unroll
     for (int j = 0; j < PPL; j++) {
-        int i = lane + 64 * j;
+        int i = lane * PPL + j;
         bool v = i < n_d;
         x[j] = v ? px[i] : 0.f;
         y[j] = v ? py[i] : 0.f;
@@ -99,24 +102,32 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
         }
         float bd = -1.f;
         int bi = 0x7fffffff;
-        int count = 0;
+        bool hit[PPL];
+        int lower = 0;   // hits of this centroid in lower lanes
+        int count = 0;   // all hits (uniform)
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
-            const int i = lane + 64 * j;
+            const int i = lane * PPL + j;
             const bool in = i < n_d;
             const float d = dist2(x[j], y[j], z[j], cx, cy, cz);
             if (in) {
                 mind[j] = d < mind[j] ? d : mind[j];
                 if (mind[j] > bd) { bd = mind[j]; bi = i; }
             }
-            const bool hit = in && (d < r2);
-            const unsigned long long m = __ballot(hit);
-            const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-            if (hit && pos < kMaxNbr) {
+            hit[j] = in && (d < r2);
+            const unsigned long long m = __ballot(hit[j]);
+            lower = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, lower));
+            count += __popcll(m);
+        }
+        int pos = lower;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            if (hit[j] && pos < kMaxNbr) {
+                const int i = lane * PPL + j;
                 if (nbr_lds) nbr_lds[c * kMaxNbr + pos] = (uint8_t)i;
                 rows_lds[base + pos] = (uint16_t)((c << 8) | i);
             }
-            count += __popcll(m);
+            pos += hit[j] ? 1 : 0;
         }
         const int kept = count < kMaxNbr ? count : kMaxNbr;
         if (lane == 0) {
@@ -125,8 +136,9 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
         }
         base += kept + (self_loops ? 1 : 0);
         if (c + 1 < n_c) {  // uniform
-            wave_argmax(bd, bi);
-            cur = bi;
+            const float mx = wave_max_f(bd);
+            const unsigned long long tie = __ballot(bd == mx);
+            cur = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(tie));
         }
     }
     // pad the list to a multiple of 4 rows with the "no row" marker, so that consumers may fetch 4 rows per load
