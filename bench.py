@@ -47,9 +47,9 @@ def _gen_objects(args):
     return S.make_objects(seed, lo, hi)
 
 
-def generate_cells(S, seed, n_cells_total, cell_lo, cell_hi, workers):
+def generate_cells(S, seed, n_cells_total, cell_lo, cell_hi, workers, fixed_n=0):
     """This rank's cell block, generated in parallel on the host (pure function of seed and global object index)."""
-    sizes = S.cell_sizes(seed, n_cells_total)
+    sizes = S.cell_sizes(seed, n_cells_total, fixed_n)
     ptr = np.zeros(n_cells_total + 1, dtype=np.int64)
     ptr[1:] = np.cumsum(sizes)
     o_lo, o_hi = int(ptr[cell_lo]), int(ptr[cell_hi])
@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--chunk-objects", type=int, default=0)
+    ap.add_argument("--cell-variant", choices=["ragged", "fixed16", "single"], default="ragged",
+                    help="objects per cell: n~U{6..26} (default, the headline workload), 16, or 1 (SURVEY 8(d) variants)")
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="arithmetic of the MFMA-heavy layers: f16x3 split-precision (default) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -138,7 +140,8 @@ def main():
     # ---- synthetic inputs on the host first (worker processes are forked before the HIP runtime is touched) ----------
     workers = max(1, min(64, (os.cpu_count() or 1) // max(1, world)))
     t0 = time.perf_counter()
-    xyz, rgb, center, mean_rgb, cell_ptr = generate_cells(S, SEED, n_cells_total, c_lo, c_hi, workers)
+    fixed_n = {"ragged": 0, "fixed16": 16, "single": 1}[args.cell_variant]
+    xyz, rgb, center, mean_rgb, cell_ptr = generate_cells(S, SEED, n_cells_total, c_lo, c_hi, workers, fixed_n)
     gen_s = time.perf_counter() - t0
     n_obj = int(cell_ptr[-1])
     log(f"generated {n_obj} objects / {c_hi - c_lo} cells on the host in {gen_s:.1f}s ({workers} workers)")
@@ -202,6 +205,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # per-phase rates (outside the timed region; SURVEY 8(d) sub-metrics): each phase alone, events on torch's stream
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps, r
+    with torch.no_grad():
+        t_cells, cells_ = timed(lambda: model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
+                                                                    chunk_objects=args.chunk_objects), 1)
+        t_text, q_ = timed(lambda: model.language_encoder.encode_tokens(d_tok, d_len, normalize=True), 3)
+        t_topk, _ = timed(lambda: ops.sim_topk(q_, cells_, TOPK), 5)
+    phase_rates = {"cells_per_s": (c_hi - c_lo) / t_cells, "objects_per_s": n_obj / t_cells,
+                   "queries_per_s": (q_hi - q_lo) / t_text, "retrieval_qps": (q_hi - q_lo) / t_topk,
+                   "note": "this rank, each phase alone (encode cells / encode text / sim + top-k over this rank's cells)"}
+
     # sanity on the result of the last step (not timed): sorted scores, valid indices
     assert bool((score[:, :-1] >= score[:, 1:]).all()) and bool((idx >= 0).all()) and bool((idx < n_cells_total).all())
 
@@ -224,9 +245,9 @@ def main():
         try:
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            if files and args.precision == "f16x3" and args.cells == CELLS_PER_GPU:
+            if files and args.precision == "f16x3" and args.cells == CELLS_PER_GPU and args.cell_variant == "ragged":
                 kern = json.load(open(files[-1]))["kernels"]
-                key = [k for k in kern if k.startswith("k_ws_sa<256, 256")]
+                key = [k for k in kern if k.startswith("k_ws_sa2<256, 256") or k.startswith("k_ws_sa<256, 256")]
                 if key:
                     traffic = kern[key[0]]["hbm_bytes_per_launch"]
         except Exception:
@@ -239,11 +260,11 @@ def main():
             "dtype": ("f16x3 (fp32 operands split hi+lo into fp16, 3 f16 MFMAs, fp32 accumulate; fp32-class error)"
                       if args.precision == "f16x3" else "f32 (fp32 MFMA)") + " for the encoders / f64 MFMA for the ranking",
             "data": "synthetic",
-            "config": {"workload": (f"{args.cells} cells/GPU (n~U{{6..26}} objects x 256 pts, {n_obj} objects on rank 0) "
+            "config": {"workload": (f"{args.cells} cells/GPU ({dict(ragged='n~U{6..26}', fixed16='16', single='1')[args.cell_variant]} objects x 256 pts, {n_obj} objects on rank 0) "
                                     f"+ {args.queries} queries/GPU (6 hints), embed_dim=256, top-{TOPK} over {n_cells_total} cells"),
                        "cells_total": n_cells_total, "queries_total": n_q_total, "objects_rank0": n_obj,
                        "parallelism": f"cells+queries sharded x{world}, 1 all-gather" if world > 1 else "single GPU"},
-            "kernel_ms_per_step": phases,
+            "kernel_ms_per_step": phases, "phase_rates": phase_rates,
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                          "traffic": traffic, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
