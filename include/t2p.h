@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 2
+#define T2P_ABI_VERSION 3
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -125,6 +125,11 @@ typedef struct t2p_cell_config {
     int32_t color_embed;
     const int32_t* class_idx;
     const int32_t* color_idx;
+    /* 1 = stop after ObjectEncoder.forward (models/object_encoder.py:61-142): no cell head; `out` is ignored (may be
+     * NULL), the [n_obj][D] result is returned through trace->obj_emb (required).  This is the entry the fine stage
+     * uses (SuperGlueMatch.forward, models/superglue_matcher.py:101-103); embed_dim may then be any multiple of 64
+     * up to 512 (the fine stage trains with 128, README.md:62). */
+    int32_t objects_only;
 } t2p_cell_config;
 
 /* Optional stage outputs for parity tests (any member may be NULL).  Layouts:
@@ -167,6 +172,34 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
 int t2p_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
                      int64_t n_obj, int32_t n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
                      t2p_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fine stage: hint <-> object matching + offset regression.
+ * Replaces SuperGlue.forward models/superglue.py:239-330 (GNN of ["self","cross"] x num_layers AttentionalPropagation
+ * layers, final_proj, scores / sqrt(D), log-space optimal transport with dustbin, mutual nearest neighbours + 0.2
+ * threshold) and mlp_offsets (models/superglue_matcher.py:116).  Inputs are the L2-normalised object / hint encodings
+ * of SuperGlueMatch.forward (:94-103), tokens-major: desc0 [B][n_obj][D], desc1 [B][n_hints][D] fp32.
+ * All matrices k-major [in][out], BatchNorm (eval) folded into mlp.0: per GNN layer l
+ *   wqkv [D][3D] = attn.proj.{0,1,2} side by side (q | k | v), bqkv [3D];  wm [D][D], bm [D] = attn.merge;
+ *   w1 [2D][2D], b1 [2D] = mlp.0 + mlp.1 (BN);  w2 [2D][D], b2 [D] = mlp.3;   cross[l] (HOST array) 0 = self, 1 = cross.
+ * Outputs: P [B][n_obj+1][n_hints+1] fp32; matches0 [B][n_obj], matches1 [B][n_hints] int64 (-1 = no match);
+ * matching_scores0/1 fp32; offsets [B][n_hints][2] fp32.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct t2p_match_weights {
+    int32_t n_layers;
+    const int32_t* cross;
+    const float *wqkv, *bqkv, *wm, *bm, *w1, *b1, *w2, *b2; /* [n_layers][...] device */
+    const float *wf, *bf;                                   /* final_proj [D][D], [D] */
+    float bin_score;
+    const float *wo1, *bo1, *wo2, *bo2;                     /* mlp_offsets: [D][D/2], [D/2], [D/2][2], [2] */
+} t2p_match_weights;
+
+size_t t2p_match_workspace_bytes(int64_t batch, int32_t n_obj, int32_t n_hints, int32_t embed_dim);
+
+int t2p_match(const float* desc0, const float* desc1, int64_t batch, int32_t n_obj, int32_t n_hints, int32_t embed_dim,
+              const t2p_match_weights* w, int32_t sinkhorn_iters, float match_threshold, float* P, int64_t* matches0,
+              int64_t* matches1, float* mscores0, float* mscores1, float* offsets, void* workspace,
+              size_t workspace_bytes, t2p_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Text branch: CellRetrievalNetwork.encode_text (models/cell_retrieval.py:69-75) on token ids produced by the

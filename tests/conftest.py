@@ -44,3 +44,38 @@ def hip_model(vocab, oracle_model):
     m = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
     m.load_state_dict(oracle_model.state_dict(), strict=True)
     return m.to("cuda:0").eval()
+
+
+def fine_args(num_layers):
+    from oracle import model as OM
+    return OM.default_args(embed_dim=128, num_layers=num_layers, sinkhorn_iters=50)
+
+
+def make_fine_pair(vocab, num_layers, seed, device=None):
+    """(product SuperGlueMatch with deterministic weights, CPU oracle carrying the same weights).  The product module
+    has the reference's parameter names and shapes, so tests/golden/weights.py fills it exactly as it filled the
+    reference model when the fixture was generated; the oracle copies from its state_dict."""
+    import weights as W
+    import text2pos_amd as t2p
+    from oracle import fine as OF
+    args = fine_args(num_layers)
+    prod = t2p.SuperGlueMatch(vocab["classes"], vocab["colors"], vocab["words"], args).eval()
+    W.fill_state_dict(prod, seed)
+    sd = prod.state_dict()
+    orc = OF.OracleSuperGlueMatch(vocab["classes"], vocab["colors"], vocab["words"], args).eval()
+    own = orc.state_dict()
+    orc.load_state_dict({k: sd[k] for k in own if not k.startswith("superglue.")}, strict=False)
+    orc.superglue.load_reference_state(sd)
+    if device is not None:
+        prod = prod.to(device)
+    return prod, orc
+
+
+@pytest.fixture(scope="session")
+def fine_pair_cpu(vocab):
+    return make_fine_pair(vocab, 2, 14)
+
+
+@pytest.fixture(scope="session")
+def fine_pair_gpu(vocab):
+    return make_fine_pair(vocab, 2, 14, "cuda:0")

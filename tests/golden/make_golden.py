@@ -53,7 +53,8 @@ def install_standins():
     for pkg in ("dataloading.semantic3d", "datapreparation.semantic3d"):
         mod(pkg).__path__ = []
     dummy = type("Absent", (), {})
-    mod("dataloading.semantic3d.semantic3d", Semantic3dCellRetrievalDataset=dummy, Semantic3dPoseReferenceMockDataset=dummy)
+    mod("dataloading.semantic3d.semantic3d", Semantic3dCellRetrievalDataset=dummy, Semantic3dPoseReferenceMockDataset=dummy,
+        Semantic3dObjectReferenceDataset=dummy)
     mod("dataloading.semantic3d.semantic3d_poses", Semantic3dPosesDataset=dummy)
     mod("dataloading.semantic3d.semantic3d_pointcloud", Semantic3dObjectDataset=dummy)
     mod("datapreparation.semantic3d.imports", Object3D=dummy, ViewObject=dummy, Pose=dummy, DescriptionObject=dummy)
@@ -202,6 +203,67 @@ def golden_eval():
                 recall=np.array([[np.mean(sample[k][t]) for t in threshs] for k in top_k]))
 
 
+def golden_fine(S):
+    """Fine stage.  (a) `sg.*`: the reference's own models/superglue.py::SuperGlue (pure torch, runs
+    unmodified) on random unit descriptors, default depth (6 x [self, cross]), 50 Sinkhorn iterations;  (b) `m.*`: the
+    reference's SuperGlueMatch.forward glue (models/superglue_matcher.py:87-128) on two samples of 16 synthetic objects
+    and 6 hints, with the PyG primitives restated as for the coarse fixture."""
+    from models.superglue import SuperGlue
+    from models.superglue_matcher import SuperGlueMatch
+    from models.pointcloud.pointnet2 import PointNet2
+    from datapreparation.kitti360pose.imports import Object3d
+    out = {}
+    torch.manual_seed(0)
+    sg = SuperGlue({"descriptor_dim": 128, "GNN_layers": ["self", "cross"] * 6, "sinkhorn_iterations": 50,
+                    "match_threshold": 0.2})
+    W.fill_state_dict(sg, 13)
+    sg.eval()
+    rng = np.random.default_rng(404)
+    d0 = rng.standard_normal((5, 16, 128)).astype(np.float32)
+    d1 = rng.standard_normal((5, 6, 128)).astype(np.float32)
+    # make some hints near-copies of objects so that real matches appear
+    d1[:, :4] = d0[:, [3, 7, 0, 12]] + 0.15 * rng.standard_normal((5, 4, 128)).astype(np.float32)
+    d0 /= np.linalg.norm(d0, axis=-1, keepdims=True)
+    d1 /= np.linalg.norm(d1, axis=-1, keepdims=True)
+    with torch.no_grad():
+        r = sg(torch.from_numpy(d0).transpose(1, 2).contiguous(), torch.from_numpy(d1).transpose(1, 2).contiguous())
+    out.update({"sg.desc0": d0, "sg.desc1": d1, "sg.P": r["P"].numpy(), "sg.matches0": r["matches0"].numpy(),
+                "sg.matches1": r["matches1"].numpy(), "sg.matching_scores0": r["matching_scores0"].numpy(),
+                "sg.matching_scores1": r["matching_scores1"].numpy()})
+
+    known_classes = S.LABELS + ["pad"]
+    args = ref_args(embed_dim=128, num_layers=2, sinkhorn_iters=50)
+    with tempfile.TemporaryDirectory() as td:
+        args.pointnet_path = os.path.join(td, "pn.pth")
+        torch.save(PointNet2(len(known_classes), len(S.COLOR_NAMES), args).state_dict(), args.pointnet_path)
+        model = SuperGlueMatch(known_classes, S.COLOR_NAMES, S.known_words(), args)
+    W.fill_state_dict(model, 14)
+    model.eval()
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(505, 2, fixed_n=16)
+    objects, points = [], []
+    for c in range(2):
+        lo, hi = cell_ptr[c], cell_ptr[c + 1]
+        objects.append([Object3d(i, i, np.tile(center[i].astype(np.float64), (2, 1)),
+                                 np.tile(mean_rgb[i].astype(np.float64), (2, 1)), "box") for i in range(lo, hi)])
+        n = hi - lo
+        points.append(pyg_restated.Batch(x=torch.from_numpy(rgb[lo:hi].reshape(n * 256, 3).copy()),
+                                         pos=torch.from_numpy(xyz[lo:hi].reshape(n * 256, 3).copy()),
+                                         batch=torch.arange(n).repeat_interleave(256)))
+    flat = S.make_texts(606, 0, 12, n_hints=1)
+    hints = [flat[0:6], flat[6:12]]
+    grabbed = {}
+    h = model.superglue.register_forward_pre_hook(lambda m, a: grabbed.update(desc0=a[0].detach().clone(), desc1=a[1].detach().clone()))
+    with torch.no_grad():
+        o = model(objects, hints, points)
+    h.remove()
+    out.update({"m.xyz": xyz, "m.rgb": rgb, "m.center": center, "m.mean_rgb": mean_rgb, "m.cell_ptr": cell_ptr,
+                "m.hints": np.array(hints), "m.object_encodings": grabbed["desc0"].transpose(1, 2).numpy(),
+                "m.hint_encodings": grabbed["desc1"].transpose(1, 2).numpy(), "m.P": o.P.numpy(),
+                "m.matches0": o.matches0.numpy(), "m.matches1": o.matches1.numpy(), "m.offsets": o.offsets.numpy(),
+                "m.matching_scores0": o.matching_scores0.numpy(), "m.matching_scores1": o.matching_scores1.numpy()})
+    return out
+
+
 def main():
     install_standins()
     import importlib
@@ -215,7 +277,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "cell_encoder.npz"), **cells)
     np.savez_compressed(os.path.join(HERE, "retrieval.npz"), **golden_retrieval())
     np.savez_compressed(os.path.join(HERE, "eval_metrics.npz"), **golden_eval())
-    for f in ("text_encoder.npz", "cell_encoder.npz", "retrieval.npz", "eval_metrics.npz"):
+    np.savez_compressed(os.path.join(HERE, "fine.npz"), **golden_fine(S))
+    for f in ("text_encoder.npz", "cell_encoder.npz", "retrieval.npz", "eval_metrics.npz", "fine.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -37,6 +37,9 @@ def fill_state_dict(module: torch.nn.Module, seed: int) -> None:
             new[name] = torch.zeros_like(t)
             continue
         u = _uniform(seed, name, n).reshape(tuple(t.shape))
+        if t.dim() == 0:                           # scalar parameter (SuperGlue.bin_score)
+            new[name] = torch.tensor(1.0 + 0.5 * float(u), dtype=t.dtype)
+            continue
         if name.endswith("running_var"):
             v = 1.0 + 0.5 * u                      # (0.5, 1.5)
         elif name.endswith("running_mean"):
@@ -49,9 +52,11 @@ def fill_state_dict(module: torch.nn.Module, seed: int) -> None:
             v = u.copy()
             v[0] = 0.0                              # padding_idx = 0
         else:                                       # Linear / LSTM weight [out, in]
-            fan_in = t.shape[-1]
+            fan_in = t.shape[1] if t.dim() == 3 else t.shape[-1]   # Conv1d [out, in, 1] / Linear [out, in]
             v = u / np.sqrt(fan_in)
             if "lstm" in name:
                 v = u / np.sqrt(t.shape[-1]) * 1.5
+            if name.endswith("final_proj.weight"):  # SuperGlue: peaked scores, so that real matches (and rejections)
+                v = v * 8.0                          # occur with random weights (4-5 of 6 hints matched)
         new[name] = torch.from_numpy(np.ascontiguousarray(v)).to(t.dtype)
     module.load_state_dict(new, strict=True)

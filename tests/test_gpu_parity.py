@@ -418,3 +418,81 @@ def test_retrieval_properties_full_size():
     # self-retrieval: a cell queried by its own embedding ranks first with score ~1
     idx4, s4 = t2p.retrieve_topk(c, c[:50].contiguous(), 1)
     assert torch.equal(idx4.cpu()[:, 0], torch.arange(50)) and (s4 - 1).abs().max() < 1e-6
+
+
+# ---- fine stage ------------------------------------------------------------------------------------
+def test_match_vs_reference_superglue_fixture(golden_dir):
+    """t2p_match (GNN 6 x [self, cross], final_proj, 50 Sinkhorn iterations, mutual NN + threshold) against the outputs of
+    the reference's own models/superglue.py::SuperGlue: matches bit-exact, P / scores within 1e-4."""
+    import weights as W
+    import text2pos_amd as t2p
+    from text2pos_amd import ops, packing
+    from oracle import model as OM
+    g = np.load(os.path.join(golden_dir, "fine.npz"))
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed_dim = 128
+            self.superglue = t2p.superglue_matcher.SuperGlue({"descriptor_dim": 128, "GNN_layers": ["self", "cross"] * 6})
+            self.mlp_offsets = torch.nn.Sequential(torch.nn.Linear(128, 64), torch.nn.ReLU(), torch.nn.Linear(64, 2))
+    h = Holder()
+    W.fill_state_dict(h.superglue, 13)
+    w = ops.make_match_weights(packing.pack_match_weights(h, "cuda:0"))
+    out = ops.match(*_to_dev(g["sg.desc0"], g["sg.desc1"]), w, 50, 0.2)
+    assert np.array_equal(out["matches0"].cpu().numpy(), g["sg.matches0"])
+    assert np.array_equal(out["matches1"].cpu().numpy(), g["sg.matches1"])
+    assert np.abs(out["P"].cpu().numpy() - g["sg.P"]).max() < TOL
+    assert np.abs(out["matching_scores0"].cpu().numpy() - g["sg.matching_scores0"]).max() < TOL
+    assert np.abs(out["matching_scores1"].cpu().numpy() - g["sg.matching_scores1"]).max() < TOL
+    # offsets = Linear(ReLU(Linear(hint)))
+    with torch.no_grad():
+        want = h.mlp_offsets(torch.from_numpy(g["sg.desc1"]))
+    assert (out["offsets"].cpu() - want).abs().max().item() < 1e-5
+
+
+def test_fine_model_golden_and_oracle(fine_pair_gpu, golden_dir):
+    """SuperGlueMatch.forward_packed (embed_dim 128: objects-only encoder + text encoder + matcher) against the fixture
+    produced by the reference's SuperGlueMatch.forward glue, and against the oracle on a second batch."""
+    from text2pos_amd import synthetic as S
+    prod, orc = fine_pair_gpu
+    g = np.load(os.path.join(golden_dir, "fine.npz"))
+    hints = [list(h) for h in g["m.hints"]]
+    with torch.no_grad():
+        r = prod.forward_packed(*_to_dev(g["m.xyz"], g["m.rgb"], g["m.center"], g["m.mean_rgb"]), g["m.cell_ptr"], hints)
+    assert np.abs(r.object_encodings.cpu().numpy() - g["m.object_encodings"]).max() < TOL
+    assert np.abs(r.hint_encodings.cpu().numpy() - g["m.hint_encodings"]).max() < TOL
+    assert np.abs(r.P.cpu().numpy() - g["m.P"]).max() < TOL
+    assert np.abs(r.offsets.cpu().numpy() - g["m.offsets"]).max() < TOL
+    assert np.array_equal(r.matches0.cpu().numpy(), g["m.matches0"]) and np.array_equal(r.matches1.cpu().numpy(), g["m.matches1"])
+    assert np.abs(r.matching_scores1.cpu().numpy() - g["m.matching_scores1"]).max() < TOL
+    # a second batch: 3 samples x 16 objects, other hints
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(707, 3, fixed_n=16)
+    flat = S.make_texts(808, 0, 18, n_hints=1)
+    hints = [flat[0:6], flat[6:12], flat[12:18]]
+    want = orc.forward_packed(xyz, rgb, center, mean_rgb, cell_ptr, hints)
+    with torch.no_grad():
+        got = prod.forward_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr, hints)
+    assert (got.P.cpu() - want["P"]).abs().max().item() < TOL
+    assert torch.equal(got.matches0.cpu(), want["matches0"]) and torch.equal(got.matches1.cpu(), want["matches1"])
+    assert (got.offsets.cpu() - want["offsets"]).abs().max().item() < TOL
+
+
+def test_fine_model_object_list_entry_point(fine_pair_gpu):
+    """forward(objects, hints, object_points) with Object3d lists and per-sample point batches == forward_packed."""
+    from text2pos_amd import data as D, synthetic as S
+    prod, _ = fine_pair_gpu
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(909, 2, fixed_n=16)
+    objects, points = [], []
+    for c in range(2):
+        lo, hi = cell_ptr[c], cell_ptr[c + 1]
+        objects.append([D.Object3d(i, i, np.tile(center[i].astype(np.float64), (2, 1)),
+                                   np.tile(mean_rgb[i].astype(np.float64), (2, 1)), "box") for i in range(lo, hi)])
+        points.append(D.Batch(x=torch.from_numpy(rgb[lo:hi].reshape(-1, 3).copy()), pos=torch.from_numpy(xyz[lo:hi].reshape(-1, 3).copy()),
+                              batch=torch.arange(hi - lo).repeat_interleave(256)))
+    flat = S.make_texts(1010, 0, 12, n_hints=1)
+    hints = [flat[:6], flat[6:]]
+    with torch.no_grad():
+        a = prod(objects, hints, points)
+        b = prod.forward_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr, hints)
+    assert torch.equal(a.P, b.P) and torch.equal(a.matches0, b.matches0) and torch.equal(a.offsets, b.offsets)

@@ -271,3 +271,23 @@ def test_evaluation_metrics_match_reference_fixture(golden_dir):
     one = E.calc_sample_accuracies(poses[0], [cells_dict[c] for c in db_ids[z["top_idx"][0]]], 0.5 * np.ones((10, 2)), top_k, threshs)
     assert set(one) == set(top_k) and all(isinstance(v, bool) for d in one.values() for v in d.values())
     assert 0.0 < z["hit"][2] < 1.0 and z["recall"][2, 2] >= z["recall"][0, 0]      # the fixture is not degenerate
+
+
+def test_fine_state_dict_layout_matches_reference_keys(vocab):
+    """SuperGlueMatch keeps the reference's parameter names and shapes (models/superglue_matcher.py:64-83,
+    models/superglue.py:53-64,97-129,203-221), so whole checkpoints interchange."""
+    import text2pos_amd as t2p
+    from oracle import model as OM
+    m = t2p.SuperGlueMatch(vocab["classes"], vocab["colors"], vocab["words"],
+                           OM.default_args(embed_dim=128, num_layers=6, sinkhorn_iters=50))
+    sd = m.state_dict()
+    want = {"superglue.bin_score": (), "superglue.final_proj.weight": (128, 128, 1), "superglue.final_proj.bias": (128,),
+            "superglue.gnn.layers.11.attn.merge.weight": (128, 128, 1), "superglue.gnn.layers.0.attn.proj.2.bias": (128,),
+            "superglue.gnn.layers.5.mlp.0.weight": (256, 256, 1), "superglue.gnn.layers.5.mlp.1.running_var": (256,),
+            "superglue.gnn.layers.5.mlp.3.weight": (128, 256, 1), "superglue.kenc.encoder.0.weight": (32, 3, 1),
+            "superglue.kenc.encoder.12.bias": (128,), "mlp_offsets.0.weight": (64, 128), "mlp_offsets.2.weight": (2, 64),
+            "object_encoder.mlp_merge.0.0.weight": (128, 384), "language_encoder.lstm.weight_hh_l0_reverse": (512, 128)}
+    for k, shape in want.items():
+        assert k in sd and tuple(sd[k].shape) == shape, k
+    assert len([k for k in sd if k.startswith("superglue.gnn.layers.")]) == 12 * (8 + 2 + 5 + 2)
+    assert not any(".mlp.2." in k for k in sd if "gnn" in k)  # mlp.2 is the ReLU

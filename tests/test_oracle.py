@@ -153,3 +153,47 @@ def test_oracle_model_unit_norm_and_determinism(oracle_model):
     a = oracle_model.encode_objects_packed(xyz, rgb, c, m, ptr)
     b = oracle_model.encode_objects_packed(xyz, rgb, c, m, ptr)
     assert torch.equal(a, b) and torch.allclose(a.norm(dim=1), torch.ones(2), atol=1e-6)
+
+
+# ---- fine stage ------------------------------------------------------------------------------------
+def test_superglue_matches_reference_fixture(vocab, golden_dir):
+    """oracle/fine.py::OracleSuperGlue vs the reference's own models/superglue.py::SuperGlue (executed for the fixture):
+    default depth, 50 Sinkhorn iterations, matches bit-exact, P within 1e-5."""
+    import weights as W
+    import text2pos_amd as t2p
+    from oracle import fine as OF
+    g = np.load(os.path.join(golden_dir, "fine.npz"))
+    ref_shaped = t2p.superglue_matcher.SuperGlue({"descriptor_dim": 128, "GNN_layers": ["self", "cross"] * 6})
+    W.fill_state_dict(ref_shaped, 13)
+    sg = OF.OracleSuperGlue(128, 6, 50).eval()
+    sg.load_reference_state(ref_shaped.state_dict(), prefix="")
+    with torch.no_grad():
+        r = sg(torch.from_numpy(g["sg.desc0"]), torch.from_numpy(g["sg.desc1"]))
+    assert (g["sg.matches0"] >= 0).sum() >= 15 and (g["sg.matches0"] < 0).sum() > 0   # the fixture has both outcomes
+    assert np.array_equal(r["matches0"].numpy(), g["sg.matches0"])
+    assert np.array_equal(r["matches1"].numpy(), g["sg.matches1"])
+    assert np.abs(r["P"].numpy() - g["sg.P"]).max() < 1e-5
+    assert np.abs(r["matching_scores0"].numpy() - g["sg.matching_scores0"]).max() < 1e-5
+    assert np.abs(r["matching_scores1"].numpy() - g["sg.matching_scores1"]).max() < 1e-5
+
+
+def test_fine_model_matches_reference_glue_fixture(fine_pair_cpu, golden_dir):
+    """OracleSuperGlueMatch vs the reference's SuperGlueMatch.forward glue (embed_dim 128, 2 x 16 objects, 2 x 6 hints)."""
+    _, orc = fine_pair_cpu
+    g = np.load(os.path.join(golden_dir, "fine.npz"))
+    hints = [list(h) for h in g["m.hints"]]
+    r = orc.forward_packed(g["m.xyz"], g["m.rgb"], g["m.center"], g["m.mean_rgb"], g["m.cell_ptr"], hints)
+    assert np.abs(r["object_encodings"].numpy() - g["m.object_encodings"]).max() < 1e-5
+    assert np.abs(r["hint_encodings"].numpy() - g["m.hint_encodings"]).max() < 1e-5
+    assert np.abs(r["P"].numpy() - g["m.P"]).max() < 1e-5
+    assert np.abs(r["offsets"].numpy() - g["m.offsets"]).max() < 1e-5
+    assert np.array_equal(r["matches0"].numpy(), g["m.matches0"]) and np.array_equal(r["matches1"].numpy(), g["m.matches1"])
+    assert np.abs(r["matching_scores1"].numpy() - g["m.matching_scores1"]).max() < 1e-5
+
+
+def test_get_pos_in_cell():
+    from oracle import fine as OF
+    centers = np.array([[0.1, 0.2], [0.5, 0.5], [0.9, 0.4]])
+    offs = np.array([[0.1, 0.0], [0.0, -0.1]])
+    assert np.allclose(OF.get_pos_in_cell(centers, np.array([-1, 1, 0]), offs), [(0.5 + 0.9 + 0.1) / 2, (0.4 + 0.4) / 2])
+    assert np.allclose(OF.get_pos_in_cell(centers, np.array([-1, -1, -1]), offs), [0.5, 0.5])

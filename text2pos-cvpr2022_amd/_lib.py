@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -31,12 +31,19 @@ class CellConfig(C.Structure):
                 ("use_class", C.c_int32), ("use_color", C.c_int32), ("use_position", C.c_int32),
                 ("self_loops", C.c_int32), ("knn_k", C.c_int32), ("variation", C.c_int32),
                 ("radius", C.c_float * 3), ("chunk_objects", C.c_int32), ("precision", C.c_int32),
-                ("class_embed", C.c_int32), ("color_embed", C.c_int32), ("class_idx", c_void), ("color_idx", c_void)]
+                ("class_embed", C.c_int32), ("color_embed", C.c_int32), ("class_idx", c_void), ("color_idx", c_void),
+                ("objects_only", C.c_int32)]
 
 
 class CellTrace(C.Structure):
     _fields_ = [("fps_idx", c_void * 3), ("nbr", c_void * 3), ("cnt", c_void * 3), ("sa_out", c_void * 3),
                 ("features0", c_void), ("features2", c_void), ("obj_emb", c_void), ("knn_idx", c_void)]
+
+
+class MatchWeights(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("cross", c_void)] + \
+               [(n, c_void) for n in ("wqkv", "bqkv", "wm", "bm", "w1", "b1", "w2", "b2", "wf", "bf")] + \
+               [("bin_score", C.c_float)] + [(n, c_void) for n in ("wo1", "bo1", "wo2", "bo2")]
 
 
 class TextWeights(C.Structure):
@@ -59,6 +66,10 @@ SYMBOLS = {
                                c_void, C.c_size_t, c_void]),
     "t2p_pack_objects": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, c_void, c_void, c_void, c_void,
                                    c_void]),
+    "t2p_match_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "t2p_match": (C.c_int, [c_void, c_void, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(MatchWeights),
+                            C.c_int32, C.c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void, C.c_size_t,
+                            c_void]),
     "t2p_profile_enable": (None, [C.c_int]),
     "t2p_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),
     "t2p_sample_group": (C.c_int, [c_void, C.c_int64, C.c_int32, c_float_p, C.POINTER(c_void), C.POINTER(c_void),

@@ -141,8 +141,13 @@ int check_cfg(const t2p_cell_config* cfg) {
         set_error("encode_cells: n_pts=%d not built (256; the GA max-pool tile assumes 32 points per object)", cfg->n_pts);
         return T2P_E_UNSUPPORTED;
     }
-    if (cfg->embed_dim != 256) {
-        set_error("encode_cells: embed_dim=%d not built (256)", cfg->embed_dim);
+    if (cfg->objects_only) {
+        if (cfg->embed_dim < 64 || cfg->embed_dim > 512 || cfg->embed_dim % 64 != 0) {
+            set_error("encode_cells: objects_only supports embed_dim in {64, 128, ..., 512}, got %d", cfg->embed_dim);
+            return T2P_E_UNSUPPORTED;
+        }
+    } else if (cfg->embed_dim != 256) {
+        set_error("encode_cells: embed_dim=%d not built for the cell head (256)", cfg->embed_dim);
         return T2P_E_UNSUPPORTED;
     }
     T2P_CHECK_ARG(cfg->variation == 0 || cfg->variation == 1, "encode_cells: variation=%d (0 = max, 1 = mean)",
@@ -315,6 +320,10 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         T2P_TRY(launch_gemm(ws.cat, ldcat, W.merge_w, W.merge_b, ws.emb, D, 0, n, ldcat, D, 1, st));
         emb = ws.emb;
     }
+    if (cfg.objects_only) {  // the fine stage consumes ObjectEncoder.forward's output as is
+        T2P_TRY(copy_trace(tr->obj_emb + trace_obj0 * D, emb, (size_t)n * D, st));
+        return 0;
+    }
     // ---- cell head: normalize, DynamicEdgeConv(k, max), global max pool, lin, normalize -------------------------
     T2P_TRY(launch_rownorm(emb, D, n, D, ws.embn, D, 0, st));
     T2P_TRY(launch_gemm(ws.embn, D, W.g_wp, W.g_bp, ws.P, D, 0, n, D, D, 0, st));
@@ -429,8 +438,11 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
                      void* workspace, size_t workspace_bytes, t2p_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     T2P_TRY(check_cfg(cfg));
-    T2P_CHECK_ARG(w != nullptr && cell_ptr_host != nullptr && cell_ptr != nullptr && out != nullptr,
-                  "encode_cells: NULL argument");
+    T2P_CHECK_ARG(w != nullptr && cell_ptr_host != nullptr && cell_ptr != nullptr, "encode_cells: NULL argument");
+    if (cfg->objects_only)
+        T2P_CHECK_ARG(trace != nullptr && trace->obj_emb != nullptr, "encode_cells: objects_only needs trace->obj_emb");
+    else
+        T2P_CHECK_ARG(out != nullptr, "encode_cells: out is NULL");
     T2P_CHECK_ARG(!cfg->class_embed || w->class_embedding != nullptr, "encode_cells: class_embedding weights missing");
     T2P_CHECK_ARG(!cfg->color_embed || w->color_embedding != nullptr, "encode_cells: color_embedding weights missing");
     if (cfg->precision == 1)
@@ -468,7 +480,7 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
         }
         const int64_t P3 = (int64_t)cfg->n_pts * 3;
         T2P_TRY(encode_chunk(xyz + o_lo * P3, rgb + o_lo * P3, center + (int64_t)o_lo * 3, mean_rgb + (int64_t)o_lo * 3,
-                             cell_ptr + c0, o_lo, n, nb, max_cell, *w, *cfg, out + c0 * cfg->embed_dim, trace, o_lo, ws,
+                             cell_ptr + c0, o_lo, n, nb, max_cell, *w, *cfg, out ? out + c0 * cfg->embed_dim : nullptr, trace, o_lo, ws,
                              st));
         c0 = c1;
     }

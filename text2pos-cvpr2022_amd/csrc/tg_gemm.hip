@@ -15,8 +15,8 @@ constexpr int LDA_S = BM + 2;  // As[k][m], +2 keeps the transposing ds_write_b3
 constexpr int LDB_S = BN + 4;  // Ws[k][n]
 
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ W,
-                                              const float* __restrict__ bias, float* __restrict__ C, int ldc, int c0,
-                                              int64_t M, int K, int N, int relu) {
+                                              const float* __restrict__ bias, float* C, int ldc, int c0,
+                                              int64_t M, int K, int N, int relu, const float* R, int ldr) {
     __shared__ float As[BK * LDA_S];
     __shared__ __attribute__((aligned(16))) float Ws[BK * LDB_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                 if (row < M) {
                     float v = acc[i][j][e] + bv;
                     if (relu) v = fmaxf(v, 0.f);
+                    if (R) v += R[row * (int64_t)ldr + col];  // residual (may alias C: same element, same thread)
                     C[row * (int64_t)ldc + c0 + col] = v;
                 }
             }
@@ -101,14 +102,14 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 }  // namespace
 
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int c0, int64_t M,
-                int K, int N, int relu, hipStream_t st) {
+                int K, int N, int relu, hipStream_t st, const float* resid, int ldr) {
     T2P_CHECK_ARG(K % 4 == 0 && N % 8 == 0 && lda % 4 == 0, "gemm: K=%d must be a multiple of 4, N=%d of 8, lda=%d of 4",
                   K, N, lda);
     T2P_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: A and W must be 16-byte aligned");
     if (M == 0) return 0;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     ProfScope ps_("tg_gemm", st);
-    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, c0, M, K, N, relu);
+    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, c0, M, K, N, relu, resid, ldr);
     T2P_CHECK_LAUNCH("gemm");
     return 0;
 }

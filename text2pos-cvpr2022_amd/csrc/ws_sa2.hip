@@ -232,6 +232,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
         int64_t flush_g = -1, flush_g1 = -1;
         int flush_buf = 0, flush_buf1 = 0;
         int trace_n = 0;
+        (void)trace_n;
         // DEFER (K <= 128, registers to spare): the atomics of batch t-1 ride between the MFMAs of batch t, fed from a
         // copy of its results; one more batch passes before a finished object may be flushed.
         constexpr bool DEFER = K <= 128;

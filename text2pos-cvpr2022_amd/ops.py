@@ -131,7 +131,7 @@ def sim_topk(queries: torch.Tensor, cells: torch.Tensor, k: int, index_offset: i
 # ---------------------------------------------------------------------------------------------------------------
 def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features=("class", "color", "position"),
                      self_loops=True, knn_k=8, variation=0, radius=(0.2, 0.3, 0.4), chunk_objects=0,
-                     precision="f16x3", class_idx=None, color_idx=None) -> L.CellConfig:
+                     precision="f16x3", class_idx=None, color_idx=None, objects_only=False) -> L.CellConfig:
     """class_idx / color_idx: int32 device tensors [n_obj] enabling the --class_embed / --color_embed ablations."""
     cfg = L.CellConfig()
     cfg.n_pts, cfg.embed_dim, cfg.pointnet_features = int(n_pts), int(embed_dim), int(pointnet_features)
@@ -141,6 +141,7 @@ def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features
     cfg.self_loops, cfg.knn_k, cfg.variation = int(bool(self_loops)), int(knn_k), int(variation)
     cfg.radius = (C.c_float * 3)(*[float(r) for r in radius])
     cfg.chunk_objects = int(chunk_objects)
+    cfg.objects_only = int(bool(objects_only))
     if precision not in ("fp32", "f16x3"):
         raise RuntimeError(f"precision must be 'fp32' or 'f16x3', got {precision!r}")
     cfg.precision = 1 if precision == "f16x3" else 0
@@ -210,9 +211,15 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
     if cell_ptr_dev.numel() != n_cells + 1:
         raise RuntimeError("encode_cells: host and device cell_ptr differ in length")
     D = cfg.embed_dim
-    out = torch.empty((n_cells, D), dtype=torch.float32, device=dev)
+    out = None if cfg.objects_only else torch.empty((n_cells, D), dtype=torch.float32, device=dev)
     trace, tr = None, None
-    if want_trace:
+    if cfg.objects_only:  # ObjectEncoder.forward only: the [n_obj, D] result comes back through the trace slot
+        if want_trace:
+            raise RuntimeError("encode_cells: objects_only returns the object embeddings only")
+        tr = L.CellTrace()
+        obj_emb = torch.empty((n_obj, D), dtype=torch.float32, device=dev)
+        tr.obj_emb = obj_emb.data_ptr()
+    elif want_trace:
         tr = L.CellTrace()
         trace = dict(fps_idx=[], nbr=[], cnt=[], sa_out=[])
         nd = n_pts
@@ -242,9 +249,12 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
     ws = workspace(dev, nbytes, "encode_cells")
     rc = L.lib().t2p_encode_cells(_ptr(xyz), _ptr(rgb), _ptr(center), _ptr(mean_rgb),
                                   cp.ctypes.data_as(C.c_void_p), _ptr(cell_ptr_dev), n_obj, n_cells, C.byref(weights),
-                                  C.byref(cfg), _ptr(out), C.byref(tr) if tr is not None else None, _ptr(ws),
+                                  C.byref(cfg), _ptr(out) if out is not None else None,
+                                  C.byref(tr) if tr is not None else None, _ptr(ws),
                                   ws.numel(), _stream(dev))
     L.check(rc, "t2p_encode_cells")
+    if cfg.objects_only:
+        return obj_emb
     return (out, trace) if want_trace else out
 
 
@@ -266,6 +276,45 @@ def pack_objects(raw_xyz, raw_rgb, obj_ptr, sample_idx):
     L.check(L.lib().t2p_pack_objects(_ptr(raw_xyz), _ptr(raw_rgb), _ptr(obj_ptr), _ptr(sample_idx), n_obj, n_pts,
                                      _ptr(xyz), _ptr(rgb), _ptr(center), _ptr(mean_rgb), _stream(dev)), "t2p_pack_objects")
     return xyz, rgb, center, mean_rgb
+
+
+def make_match_weights(packed: Dict[str, object]) -> L.MatchWeights:
+    """packed: packing.pack_match_weights(...)"""
+    w = L.MatchWeights()
+    cross = np.ascontiguousarray(packed["cross"], dtype=np.int32)
+    w.n_layers = int(cross.shape[0])
+    w.cross = cross.ctypes.data_as(C.c_void_p)
+    for name in ("wqkv", "bqkv", "wm", "bm", "w1", "b1", "w2", "b2", "wf", "bf", "wo1", "bo1", "wo2", "bo2"):
+        t = packed[name]
+        _need(t, name, torch.float32)
+        setattr(w, name, t.data_ptr())
+    w.bin_score = float(packed["bin_score"])
+    w._keepalive = (cross, packed)
+    return w
+
+
+def match(desc0, desc1, weights: L.MatchWeights, sinkhorn_iters: int, threshold: float = 0.2):
+    """desc0 [B, M, D] object encodings, desc1 [B, N, D] hint encodings (fp32, L2-normalised, on the GPU).
+    Returns dict(P [B, M+1, N+1], matches0 [B, M] int64, matches1 [B, N] int64, matching_scores0/1, offsets [B, N, 2])."""
+    _need(desc0, "desc0", torch.float32, 3)
+    dev = desc0.device
+    _need(desc1, "desc1", torch.float32, 3, dev)
+    b, m, d = desc0.shape
+    n = desc1.shape[1]
+    if desc1.shape[0] != b or desc1.shape[2] != d:
+        raise RuntimeError(f"match: desc0 {tuple(desc0.shape)} / desc1 {tuple(desc1.shape)} disagree")
+    out = dict(P=torch.empty((b, m + 1, n + 1), dtype=torch.float32, device=dev),
+               matches0=torch.empty((b, m), dtype=torch.int64, device=dev),
+               matches1=torch.empty((b, n), dtype=torch.int64, device=dev),
+               matching_scores0=torch.empty((b, m), dtype=torch.float32, device=dev),
+               matching_scores1=torch.empty((b, n), dtype=torch.float32, device=dev),
+               offsets=torch.empty((b, n, 2), dtype=torch.float32, device=dev))
+    ws = workspace(dev, L.lib().t2p_match_workspace_bytes(b, m, n, d), "match")
+    rc = L.lib().t2p_match(_ptr(desc0), _ptr(desc1), b, m, n, d, C.byref(weights), int(sinkhorn_iters), float(threshold),
+                           _ptr(out["P"]), _ptr(out["matches0"]), _ptr(out["matches1"]), _ptr(out["matching_scores0"]),
+                           _ptr(out["matching_scores1"]), _ptr(out["offsets"]), _ptr(ws), ws.numel(), _stream(dev))
+    L.check(rc, "t2p_match")
+    return out
 
 
 def make_text_weights(embedding, w_ih, w_hh, bias) -> L.TextWeights:

@@ -55,7 +55,8 @@ def pack_f16x3(w_kmajor: torch.Tensor) -> torch.Tensor:
 
 
 def pack_cell_weights(model, device) -> Dict[str, object]:
-    """model: CellRetrievalNetwork (this package).  Returns name -> fp32 device tensor(s) for ops.make_cell_weights."""
+    """model: CellRetrievalNetwork or SuperGlueMatch (this package; the latter has no cell head).  Returns name -> fp32
+    device tensor(s) for ops.make_cell_weights."""
     oe, pn = model.object_encoder, model.object_encoder.pointnet
     p: Dict[str, object] = {}
     sa_w1, sa_b1, sa_w2, sa_b2 = [], [], [], []
@@ -87,18 +88,55 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
         p[pre + "_w2"], p[pre + "_b2"] = kmajor(w2).to(device), f32(b2).to(device)
     w, b = fold_linear_bn(oe.mlp_merge[0])
     p.update(merge_w=kmajor(w).to(device), merge_b=f32(b).to(device))
+    p.update(class_embedding=f32(oe.class_embedding.weight.detach()).to(device),
+             color_embedding=f32(oe.color_embedding.weight.detach()).to(device))
+    if not hasattr(model, "graph1"):  # fine stage: ObjectEncoder only
+        return p
     # DynamicEdgeConv nn on [x_i | x_j - x_i]:  W1a x_i + W1b (x_j - x_i) = (W1a - W1b) x_i + W1b x_j
     d = model.embed_dim
     w1, b1 = fold_linear_bn(model.graph1.nn[0])
     w2, b2 = fold_linear_bn(model.graph1.nn[1])
     p.update(g_wp=kmajor(w1[:, :d] - w1[:, d:]).to(device), g_bp=f32(b1).to(device), g_wq=kmajor(w1[:, d:]).to(device),
              g_w2=kmajor(w2).to(device), g_b2=f32(b2).to(device))
-    p.update(class_embedding=f32(oe.class_embedding.weight.detach()).to(device),
-             color_embedding=f32(oe.color_embedding.weight.detach()).to(device))
     w1, b1 = fold_linear_bn(model.lin[0])
     w2, b2 = fold_linear_bn(model.lin[1])
     p.update(lin_w1=kmajor(w1).to(device), lin_b1=f32(b1).to(device), lin_w2=kmajor(w2).to(device),
              lin_b2=f32(b2).to(device))
+    return p
+
+
+def pack_match_weights(model, device) -> Dict[str, object]:
+    """model: SuperGlueMatch (this package).  Conv1d(k=1) weights [out, in, 1] -> k-major [in][out]; eval BatchNorm of
+    AttentionalPropagation.mlp folded into its first conv (float64 on the host)."""
+    sg = model.superglue
+    cols = {k: [] for k in ("wqkv", "bqkv", "wm", "bm", "w1", "b1", "w2", "b2")}
+    conv = lambda c: (c.weight.detach().double().squeeze(-1), c.bias.detach().double())
+    for layer in sg.gnn.layers:
+        ws, bs = zip(*[conv(c) for c in layer.attn.proj])
+        cols["wqkv"].append(torch.cat([w.t() for w in ws], dim=1))   # [D][3D]: q | k | v
+        cols["bqkv"].append(torch.cat(bs))
+        w, b = conv(layer.attn.merge)
+        cols["wm"].append(w.t())
+        cols["bm"].append(b)
+        w, b = conv(layer.mlp[0])
+        bn = layer.mlp[1]
+        sc = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        cols["w1"].append((w * sc[:, None]).t())
+        cols["b1"].append((b - bn.running_mean.detach().double()) * sc + bn.bias.detach().double())
+        w, b = conv(layer.mlp[3])
+        cols["w2"].append(w.t())
+        cols["b2"].append(b)
+    d = model.embed_dim
+    empty = {"wqkv": (0, d, 3 * d), "bqkv": (0, 3 * d), "wm": (0, d, d), "bm": (0, d), "w1": (0, 2 * d, 2 * d),
+             "b1": (0, 2 * d), "w2": (0, 2 * d, d), "b2": (0, d)}
+    p: Dict[str, object] = {k: (f32(torch.stack(v)) if v else torch.zeros(empty[k], dtype=torch.float32)).to(device)
+                            for k, v in cols.items()}
+    w, b = conv(sg.final_proj)
+    p.update(wf=f32(w.t()).to(device), bf=f32(b).to(device), bin_score=float(sg.bin_score.detach()))
+    l1, l2 = model.mlp_offsets[0], model.mlp_offsets[2]
+    p.update(wo1=f32(l1.weight.detach().double().t()).to(device), bo1=f32(l1.bias.detach().double()).to(device),
+             wo2=f32(l2.weight.detach().double().t()).to(device), bo2=f32(l2.bias.detach().double()).to(device))
+    p["cross"] = [1 if n == "cross" else 0 for n in sg.gnn.names]
     return p
 
 

@@ -1,0 +1,179 @@
+"""Drop-in for the reference's fine model: same constructor, `forward(objects, hints, object_points)` and state_dict
+layout as models/superglue_matcher.py::SuperGlueMatch (incl. the un-used `superglue.kenc.*` parameters, so that whole
+checkpoints load with strict=True), with the arithmetic executed by libt2p_hip.so on an MI355X:
+
+  ObjectEncoder.forward (models/object_encoder.py:61-142)   -> t2p_encode_cells(objects_only)   (csrc/api.hip)
+  LanguageEncoder per hint sentence (models/modules.py:59-92) -> t2p_encode_text                (csrc/lstm.hip)
+  SuperGlue.forward + mlp_offsets (models/superglue.py:239-330, models/superglue_matcher.py:116) -> t2p_match (csrc/match.hip)
+
+Callers that drop in unchanged: evaluation/pipeline.py:189-191 (run_fine) and training/fine.py's eval loop.
+Forward-only, eval mode (SURVEY.md 8(f) #4 is the training row).
+"""
+from copy import deepcopy
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from .data import pack_cells
+from .modules import LanguageEncoder, tokenize
+from .object_encoder import ObjectEncoder
+
+MATCH_THRESHOLD = 0.2  # models/superglue_matcher.py:80
+
+
+def _conv_mlp(channels: List[int]) -> nn.Sequential:
+    """Parameter layout of models/superglue.py::MLP (Conv1d k=1 [+ BatchNorm1d + ReLU])."""
+    layers = []
+    for i in range(1, len(channels)):
+        layers.append(nn.Conv1d(channels[i - 1], channels[i], kernel_size=1, bias=True))
+        if i < len(channels) - 1:
+            layers += [nn.BatchNorm1d(channels[i]), nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+class _Holder(nn.Module):
+    """Parameter container: the arithmetic of these sub-modules runs inside t2p_match."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("runs fused inside SuperGlueMatch.forward (HIP)")
+
+
+class SuperGlue(_Holder):
+    """Parameters of models/superglue.py::SuperGlue under the same keys."""
+
+    def __init__(self, config: dict):
+        super().__init__()
+        d = config["descriptor_dim"]
+        self.config = dict(config)
+        self.kenc = _Holder()
+        self.kenc.encoder = _conv_mlp([3, 32, 64, 128, 256, d])  # KeypointEncoder: constructed, never used (:234)
+        self.gnn = _Holder()
+        self.gnn.names = list(config["GNN_layers"])
+        layers = []
+        for _ in self.gnn.names:
+            layer = _Holder()
+            layer.attn = _Holder()
+            layer.attn.merge = nn.Conv1d(d, d, kernel_size=1)
+            layer.attn.proj = nn.ModuleList([deepcopy(layer.attn.merge) for _ in range(3)])
+            layer.mlp = _conv_mlp([2 * d, 2 * d, d])
+            nn.init.constant_(layer.mlp[-1].bias, 0.0)
+            layers.append(layer)
+        self.gnn.layers = nn.ModuleList(layers)
+        self.final_proj = nn.Conv1d(d, d, kernel_size=1, bias=True)
+        self.register_parameter("bin_score", nn.Parameter(torch.tensor(1.0)))
+
+
+class MatchOutputs(dict):
+    """Attribute access like the reference's EasyDict (models/superglue_matcher.py:118-127)."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class SuperGlueMatch(nn.Module):
+    def __init__(self, known_classes: List[str], known_colors: List[str], known_words: List[str], args,
+                 add_self_loops: bool = True, precision: str = "f16x3"):
+        super().__init__()
+        self.embed_dim = args.embed_dim
+        self.num_layers = args.num_layers
+        self.sinkhorn_iters = args.sinkhorn_iters
+        self.use_features = args.use_features
+        self.args = args
+        self.add_self_loops = add_self_loops
+        self.precision = precision
+        d = self.embed_dim
+        self.object_encoder = ObjectEncoder(d, known_classes, known_colors, args)
+        self.language_encoder = LanguageEncoder(known_words, d, bi_dir=True)
+        self.mlp_offsets = nn.Sequential(nn.Linear(d, d // 2), nn.ReLU(), nn.Linear(d // 2, 2))  # get_mlp_offset (:29-48)
+        self.superglue = SuperGlue({"descriptor_dim": d, "GNN_layers": ["self", "cross"] * self.num_layers,
+                                    "sinkhorn_iterations": self.sinkhorn_iters, "match_threshold": MATCH_THRESHOLD})
+        self._opack = None
+        self._mpack = None
+
+    # ---- cached weight images -------------------------------------------------------------------------------------
+    def _object_pack(self):
+        ver = (packing.params_version(self.object_encoder), str(self.device))
+        if self._opack is None or self._opack[0] != ver:
+            tensors = packing.pack_cell_weights(self, self.device)
+            self._opack = (ver, tensors, ops.make_cell_weights(tensors))
+        return self._opack[2]
+
+    def _match_pack(self):
+        ver = (packing.params_version(self.superglue), packing.params_version(self.mlp_offsets), str(self.device))
+        if self._mpack is None or self._mpack[0] != ver:
+            tensors = packing.pack_match_weights(self, self.device)
+            self._mpack = (ver, tensors, ops.make_match_weights(tensors))
+        return self._mpack[2]
+
+    def _check_forward_only(self):
+        if self.training:
+            raise NotImplementedError("training-mode forward (batch-statistics BatchNorm) is not built; call .eval()")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the HIP path is forward-only; call it under torch.no_grad()")
+
+    # ---- forward ----------------------------------------------------------------------------------------------------
+    def forward_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, hints: List[List[str]], class_idx=None,
+                       color_idx=None):
+        """Device-resident packed objects (see CellRetrievalNetwork.encode_objects_packed); every sample must hold the
+        same number of objects (the dataset pads to args.pad_size, dataloading/kitti360pose/eval.py:147-149) and the
+        same number of hints."""
+        self._check_forward_only()
+        cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int32)
+        b = cp.shape[0] - 1
+        sizes = cp[1:] - cp[:-1]
+        if b < 1 or (sizes != sizes[0]).any() or len(hints) != b or any(len(h) != len(hints[0]) for h in hints):
+            raise RuntimeError("SuperGlueMatch: samples must agree in their number of objects and of hints "
+                               "(torch.stack / reshape in models/superglue_matcher.py:94-102 need it too)")
+        n_obj, n_hints, d = int(sizes[0]), len(hints[0]), self.embed_dim
+        a = self.args
+        if bool(getattr(a, "class_embed", False)) != (class_idx is not None) or \
+                bool(getattr(a, "color_embed", False)) != (color_idx is not None):
+            raise RuntimeError("args.class_embed / args.color_embed need class_idx / color_idx")
+        cfg = ops.make_cell_config(n_pts=xyz.shape[1], embed_dim=d, pointnet_features=a.pointnet_features,
+                                   use_features=tuple(a.use_features), self_loops=self.add_self_loops,
+                                   radius=self.object_encoder.pointnet.radii, precision=self.precision,
+                                   class_idx=class_idx, color_idx=color_idx, objects_only=True)
+        dev = self.device
+        obj = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, torch.from_numpy(cp).to(dev), self._object_pack(), cfg)
+        obj = ops.rownorm(obj).view(b, n_obj, d)                                    # F.normalize (:103)
+        flat = [s for h in hints for s in h]
+        hint = self.language_encoder(flat, normalize=True).view(b, n_hints, d)      # :94-97
+        out = ops.match(obj.contiguous(), hint.contiguous(), self._match_pack(), self.sinkhorn_iters, MATCH_THRESHOLD)
+        return MatchOutputs(P=out["P"], matches0=out["matches0"], matches1=out["matches1"], offsets=out["offsets"],
+                            matching_scores0=out["matching_scores0"], matching_scores1=out["matching_scores1"],
+                            object_encodings=obj, hint_encodings=hint)
+
+    def forward(self, objects, hints, object_points):
+        """objects: List[List[Object3d]] (B samples x pad_size objects), hints: List[List[str]] (B x num_hints),
+        object_points: List[Batch] -> outputs with P, matches0, matches1, offsets, matching_scores0/1
+        (models/superglue_matcher.py:87-128)."""
+        self._check_forward_only()
+        n_pts = int(getattr(self.args, "pointnet_numpoints", 256))
+        zero_color = "color" not in self.args.use_features
+        xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, n_pts, zero_color)
+        dev = self.device
+        to = lambda t: t.to(dev, non_blocking=True)
+        oe, class_idx, color_idx = self.object_encoder, None, None
+        if getattr(self.args, "class_embed", False):
+            class_idx = to(torch.tensor([oe.known_classes.get(o.label, 0) for objs in objects for o in objs],
+                                        dtype=torch.int32))
+        if getattr(self.args, "color_embed", False):
+            color_idx = to(torch.tensor([oe.known_colors[o.get_color_text()] for objs in objects for o in objs],
+                                        dtype=torch.int32))
+        return self.forward_packed(to(xyz), to(rgb), to(center), to(mean_rgb), cell_ptr, hints, class_idx, color_idx)
+
+    @property
+    def device(self):
+        return next(self.mlp_offsets.parameters()).device
+
+    def get_device(self):
+        return self.device
+
+
+def get_pos_in_cell(objects, matches0, offsets) -> np.ndarray:
+    """Pose estimate relative to the cell: mean over the matched objects of (object centre xy + offset of its hint);
+    the cell centre without matches (models/superglue_matcher.py:139-161)."""
+    preds = [objects[o].get_center()[0:2] + offsets[h] for o, h in enumerate(matches0) if h != -1]
+    return np.mean(preds, axis=0) if len(preds) > 0 else np.array((0.5, 0.5))
