@@ -291,3 +291,65 @@ def test_fine_state_dict_layout_matches_reference_keys(vocab):
         assert k in sd and tuple(sd[k].shape) == shape, k
     assert len([k for k in sd if k.startswith("superglue.gnn.layers.")]) == 12 * (8 + 2 + 5 + 2)
     assert not any(".mlp.2." in k for k in sd if "gnn" in k)  # mlp.2 is the ReLU
+
+
+def test_run_fine_bookkeeping_matches_per_sample_loop():
+    """evaluation.run_fine (batched) == the reference's per-query loop (evaluation/pipeline.py:205-270) written out with
+    get_pos_in_cell + calc_sample_accuracies, for a stub model with fixed matches / offsets."""
+    from types import SimpleNamespace as NS
+    from text2pos_amd import data as D, evaluation as E
+    from text2pos_amd.superglue_matcher import get_pos_in_cell
+    rng = np.random.default_rng(3)
+    cells = {}
+    for i in range(12):
+        objs = [D.Object3d(j, j, rng.random((20, 3)), rng.random((20, 3)), "box") for j in range(int(rng.integers(3, 20)))]
+        x, y = float(rng.integers(0, 5)) * 30.0, float(rng.integers(0, 5)) * 30.0
+        c = D.Cell(i, "2013_05_28_drive_0003_sync" if i % 4 else "2013_05_28_drive_0010_sync", objs, 30.0,
+                   np.array([x, y, 0.0, x + 30.0, y + 30.0, 10.0]))
+        cells[c.id] = c
+    ids = list(cells)
+    desc = [NS(direction="north", object_color_text="gray", object_label="road")] * 6
+    poses = [D.Pose(rng.random(3), rng.random(3) * 150.0, ids[int(rng.integers(0, 12))], "s", desc) for _ in range(7)]
+    for p in poses:
+        p.cell_id = p.cell_id  # "<scene>_<idx>"
+    retrievals = [[ids[int(k)] for k in rng.choice(12, 3, replace=False)] for _ in poses]
+    calls = []
+
+    def model(objects, hints, points):
+        b = len(objects)
+        assert all(len(o) == 16 for o in objects) and all(len(h) == 6 for h in hints) and len(points) == b
+        g = np.random.default_rng(100 + len(calls))
+        m0 = g.integers(-1, 6, size=(b, 16))
+        calls.append(b)
+        return NS(matches0=m0, offsets=g.standard_normal((b, 6, 2)) * 0.1)
+
+    tf = D.Compose([D.FixedPoints(32, generator=np.random.default_rng(0)), D.NormalizeScale()])
+    top_k, threshs = [1, 3], [5, 10, 15]
+    got = E.run_fine(model, poses, cells, retrievals, tf, 16, top_k, threshs, queries_per_call=4)
+    assert calls == [12, 9]
+    # replay the same stub outputs through the per-sample formulation
+    calls.clear()
+    outs = [model([[None] * 16] * 12, [[None] * 6] * 12, [None] * 12), model([[None] * 16] * 9, [[None] * 6] * 9, [None] * 9)]
+    m0 = np.concatenate([o.matches0 for o in outs]).reshape(7, 3, 16)
+    off = np.concatenate([o.offsets for o in outs]).reshape(7, 3, 6, 2)
+    acc = [{k: {t: [] for t in threshs} for k in top_k} for _ in range(2)]
+    acc_conf = {1: {t: [] for t in threshs}}
+    for q, pose in enumerate(poses):
+        top_cells = [cells[c] for c in retrievals[q]]
+        padded = [list(c.objects)[:16] + [D.Object3d.create_padding()] * max(0, 16 - len(c.objects)) for c in top_cells]
+        pm = np.array([get_pos_in_cell(padded[c], m0[q, c], np.zeros((6, 2))) for c in range(3)])
+        po = np.array([get_pos_in_cell(padded[c], m0[q, c], off[q, c]) for c in range(3)])
+        for a, pos in zip(acc, (pm, po)):
+            r = E.calc_sample_accuracies(pose, top_cells, pos, top_k, threshs)
+            for k in top_k:
+                for t in threshs:
+                    a[k][t].append(r[k][t])
+        ci = int(np.argmax(np.sum(m0[q] >= 0, axis=1)))
+        r = E.calc_sample_accuracies(pose, top_cells[ci: ci + 1], pm[ci: ci + 1], [1], threshs)
+        for t in threshs:
+            acc_conf[1][t].append(r[1][t])
+    for k in top_k:
+        for t in threshs:
+            assert abs(got[0][k][t] - np.mean(acc[0][k][t])) < 1e-12 and abs(got[1][k][t] - np.mean(acc[1][k][t])) < 1e-12
+    for t in threshs:
+        assert abs(got[2][1][t] - np.mean(acc_conf[1][t])) < 1e-12

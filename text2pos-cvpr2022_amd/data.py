@@ -37,6 +37,13 @@ class Object3d:
     def __repr__(self):
         return f"Object3d: {self.label}"
 
+    @classmethod
+    def create_padding(cls, rng=np.random):
+        """Padding object of the fine stage (datapreparation/kitti360pose/imports.py:74-83): 8 points within 1 mm of
+        the origin, black, label "pad"."""
+        return cls(-1, -1, rng.rand(8, 3) * 0.001 if rng is np.random else rng.random((8, 3)) * 0.001,
+                   np.zeros((8, 3)), "pad")
+
 
 class Cell:
     def __init__(self, idx, scene_name, objects: List[Object3d], cell_size, bbox_w):

@@ -5,9 +5,12 @@ Mirrors the bookkeeping of the reference's evaluation loop:
   * calc_sample_accuracies (recall@k within thresholds, cross-scene masking, world-coordinate prediction)
                                               evaluation/utils.py:31-54, driven from evaluation/pipeline.py:122-137
   * print_accuracies table                    evaluation/utils.py:57-69
+  * run_fine (query x top-k cells through the fine model, pose from matches + offsets, three accuracy tables)
+                                              evaluation/pipeline.py:172-279, dataloading/kitti360pose/eval.py:117-189
 The top-k indices come from `retrieve_topk` (csrc/sim_topk.hip), so `eval_retrieval` is the drop-in for the part of
 `eval_epoch` that follows the two encoding loops.
 """
+from copy import copy
 from typing import Dict, List, Sequence
 
 import numpy as np
@@ -92,3 +95,59 @@ def print_accuracies(accs, name=""):
     for k in top_k:
         print("\t" + "/".join([f"{accs[k][t]:0.2f}" for t in threshs]), end="")
     print("\n\n", flush=True)
+
+
+def create_hint_description(pose) -> List[str]:
+    """One sentence per description of the pose (dataloading/kitti360pose/base.py:57-66)."""
+    return [f"The pose is {d.direction} of a {d.object_color_text} {d.object_label}." for d in pose.descriptions]
+
+
+def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Sequence[str]], transform, pad_size: int,
+             top_k, threshs, queries_per_call: int = 64):
+    """Fine localisation of every query against its max(top_k) retrieved cells (evaluation/pipeline.py:172-279).
+    `model(objects, hints, object_points)` is SuperGlueMatch (or anything returning .matches0 [B, pad] / .offsets
+    [B, hints, 2]); unlike the reference, which calls the model once per query (10 samples), `queries_per_call` queries
+    share a call.  Returns (accuracies_mean, accuracies_offset, accuracies_mean_conf)."""
+    from .data import Object3d, batch_object_points
+    from .superglue_matcher import get_pos_in_cell
+    kmax = max(top_k)
+    assert all(len(r) == kmax for r in retrievals), "retrievals must be trimmed to max(top_k)"
+    padded = {}
+
+    def pad(cell_id):  # objects of a cell cut / padded to pad_size (dataloading/kitti360pose/eval.py:141-149)
+        if cell_id not in padded:
+            objs = list(cells_dict[cell_id].objects)[:pad_size]
+            while len(objs) < pad_size:
+                objs.append(Object3d.create_padding())
+            padded[cell_id] = objs
+        return padded[cell_id]
+
+    nq = len(poses)
+    pos_mean = np.zeros((nq, kmax, 2))
+    pos_off = np.zeros((nq, kmax, 2))
+    conf = np.zeros((nq, kmax), dtype=np.int64)
+    for q0 in range(0, nq, queries_per_call):
+        q1 = min(q0 + queries_per_call, nq)
+        objects, hints, points = [], [], []
+        for q in range(q0, q1):
+            h = create_hint_description(poses[q])
+            for cid in retrievals[q]:
+                objs = pad(cid)
+                objects.append(objs)
+                hints.append(h)
+                points.append(batch_object_points(objs, transform))
+        out = model(objects, hints, points)
+        m0 = np.asarray(out.matches0.detach().cpu() if hasattr(out.matches0, "detach") else out.matches0)
+        off = np.asarray(out.offsets.detach().cpu() if hasattr(out.offsets, "detach") else out.offsets)
+        for i, objs in enumerate(objects):
+            q, c = q0 + i // kmax, i % kmax
+            pos_mean[q, c] = get_pos_in_cell(objs, m0[i], np.zeros_like(off[i]))
+            pos_off[q, c] = get_pos_in_cell(objs, m0[i], off[i])
+            conf[q, c] = int(np.sum(m0[i] >= 0))
+    acc_mean = localisation_accuracies(poses, retrievals, cells_dict, top_k, threshs, pos_mean)
+    acc_off = localisation_accuracies(poses, retrievals, cells_dict, top_k, threshs, pos_off)
+    # the single most confident candidate (most matched objects; first on ties), evaluated as top-1
+    best = np.argmax(conf, axis=1)
+    acc_conf = localisation_accuracies(poses, [[r[b]] for r, b in zip(retrievals, best)], cells_dict, [1], threshs,
+                                       pos_mean[np.arange(nq), best][:, None, :])
+    return acc_mean, acc_off, acc_conf

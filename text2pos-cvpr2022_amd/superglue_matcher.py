@@ -114,19 +114,26 @@ class SuperGlueMatch(nn.Module):
             raise NotImplementedError("the HIP path is forward-only; call it under torch.no_grad()")
 
     # ---- forward ----------------------------------------------------------------------------------------------------
-    def forward_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, hints: List[List[str]], class_idx=None,
-                       color_idx=None):
+    def forward_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, hints, class_idx=None, color_idx=None):
         """Device-resident packed objects (see CellRetrievalNetwork.encode_objects_packed); every sample must hold the
         same number of objects (the dataset pads to args.pad_size, dataloading/kitti360pose/eval.py:147-149) and the
-        same number of hints."""
+        same number of hints.  hints: List[List[str]], or pre-tokenised (tokens int32 [B * num_hints, T],
+        lengths int32 [B * num_hints]) device tensors (modules.tokenize) to keep the host out of the call."""
         self._check_forward_only()
         cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int32)
         b = cp.shape[0] - 1
         sizes = cp[1:] - cp[:-1]
-        if b < 1 or (sizes != sizes[0]).any() or len(hints) != b or any(len(h) != len(hints[0]) for h in hints):
+        tokenised = isinstance(hints, tuple)
+        if tokenised:
+            if hints[0].shape[0] % b != 0:
+                raise RuntimeError("SuperGlueMatch: token rows must be a multiple of the number of samples")
+        elif len(hints) != b or any(len(h) != len(hints[0]) for h in hints):
+            raise RuntimeError("SuperGlueMatch: every sample needs the same number of hints")
+        if b < 1 or (sizes != sizes[0]).any():
             raise RuntimeError("SuperGlueMatch: samples must agree in their number of objects and of hints "
                                "(torch.stack / reshape in models/superglue_matcher.py:94-102 need it too)")
-        n_obj, n_hints, d = int(sizes[0]), len(hints[0]), self.embed_dim
+        n_obj, d = int(sizes[0]), self.embed_dim
+        n_hints = hints[0].shape[0] // b if tokenised else len(hints[0])
         a = self.args
         if bool(getattr(a, "class_embed", False)) != (class_idx is not None) or \
                 bool(getattr(a, "color_embed", False)) != (color_idx is not None):
@@ -138,8 +145,11 @@ class SuperGlueMatch(nn.Module):
         dev = self.device
         obj = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, torch.from_numpy(cp).to(dev), self._object_pack(), cfg)
         obj = ops.rownorm(obj).view(b, n_obj, d)                                    # F.normalize (:103)
-        flat = [s for h in hints for s in h]
-        hint = self.language_encoder(flat, normalize=True).view(b, n_hints, d)      # :94-97
+        if tokenised:
+            hint = self.language_encoder.encode_tokens(hints[0], hints[1], normalize=True).view(b, n_hints, d)
+        else:
+            flat = [s for h in hints for s in h]
+            hint = self.language_encoder(flat, normalize=True).view(b, n_hints, d)  # :94-97
         out = ops.match(obj.contiguous(), hint.contiguous(), self._match_pack(), self.sinkhorn_iters, MATCH_THRESHOLD)
         return MatchOutputs(P=out["P"], matches0=out["matches0"], matches1=out["matches1"], offsets=out["offsets"],
                             matching_scores0=out["matching_scores0"], matching_scores1=out["matching_scores1"],
