@@ -496,3 +496,37 @@ def test_fine_model_object_list_entry_point(fine_pair_gpu):
         a = prod(objects, hints, points)
         b = prod.forward_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr, hints)
     assert torch.equal(a.P, b.P) and torch.equal(a.matches0, b.matches0) and torch.equal(a.offsets, b.offsets)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,m,n,d,layers", [(7, 9, 4, 64, 1), (1, 16, 6, 256, 0), (33, 3, 11, 128, 2)])
+def test_match_other_shapes_vs_oracle(b, m, n, d, layers):
+    """t2p_match at other token counts / widths / depths (incl. no GNN at all, models/superglue.py:205-208) vs the oracle."""
+    import weights as W
+    import text2pos_amd as t2p
+    from text2pos_amd import ops, packing
+    from oracle import fine as OF
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed_dim = d
+            self.superglue = t2p.superglue_matcher.SuperGlue({"descriptor_dim": d, "GNN_layers": ["self", "cross"] * layers})
+            self.mlp_offsets = torch.nn.Sequential(torch.nn.Linear(d, d // 2), torch.nn.ReLU(), torch.nn.Linear(d // 2, 2))
+    h = Holder()
+    W.fill_state_dict(h.superglue, 21)
+    sg = OF.OracleSuperGlue(d, layers, 20).eval()
+    sg.load_reference_state(h.superglue.state_dict(), prefix="")
+    rng = np.random.default_rng(b * 100 + m)
+    d0 = rng.standard_normal((b, m, d)).astype(np.float32)
+    d1 = rng.standard_normal((b, n, d)).astype(np.float32)
+    d1[:, : min(m, n)] = d0[:, : min(m, n)] + 0.1 * rng.standard_normal((b, min(m, n), d)).astype(np.float32)
+    d0 /= np.linalg.norm(d0, axis=-1, keepdims=True)
+    d1 /= np.linalg.norm(d1, axis=-1, keepdims=True)
+    with torch.no_grad():
+        want = sg(torch.from_numpy(d0), torch.from_numpy(d1))
+    out = ops.match(*_to_dev(d0, d1), ops.make_match_weights(packing.pack_match_weights(h, "cuda:0")), 20, 0.2)
+    assert (out["P"].cpu() - want["P"]).abs().max().item() < TOL
+    assert torch.equal(out["matches0"].cpu(), want["matches0"]) and torch.equal(out["matches1"].cpu(), want["matches1"])
+    assert (out["matching_scores0"].cpu() - want["matching_scores0"]).abs().max().item() < TOL
+    assert abs(float(out["P"].sum()) - b * (m + n)) < 1e-2 * b      # couplings sum to M + N per sample
