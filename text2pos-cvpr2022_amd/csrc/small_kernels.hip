@@ -9,30 +9,34 @@
 namespace t2p {
 namespace {
 
-__global__ void k_sa1_point_table(const float* __restrict__ rgb, const float* __restrict__ xyz, int64_t n_rows,
-                                  const float* __restrict__ w, const float* __restrict__ bias, int H,
-                                  float* __restrict__ out) {
-    int64_t total = n_rows * H;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        int64_t row = e / H;
-        int h = (int)(e - row * H);
-        const float* c = rgb + row * 3;
-        const float* p = xyz + row * 3;
-        float acc = bias[h];
-        acc = fmaf(c[0], w[0 * H + h], acc);
-        acc = fmaf(c[1], w[1 * H + h], acc);
-        acc = fmaf(c[2], w[2 * H + h], acc);
-        acc = fmaf(p[0], w[3 * H + h], acc);
-        acc = fmaf(p[1], w[4 * H + h], acc);
-        acc = fmaf(p[2], w[5 * H + h], acc);
-        out[e] = acc;
+// SA1 layer-1 point table A_j = W1 [rgb_j | xyz_j] + b1 (K = 6): H/4 threads per point, each holding its 4 output columns
+// of W1 and b1 in registers; 16-byte stores, 32-bit indices (rows of a chunk fit easily).
+__global__ __launch_bounds__(256) void k_sa1_point_table(const float* __restrict__ rgb, const float* __restrict__ xyz,
+                                                         uint32_t n_rows, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int H, float* __restrict__ out) {
+    const uint32_t tpr = (uint32_t)H >> 2, rpb = 256u / tpr;
+    const uint32_t hq = threadIdx.x % tpr;
+    f32x4 wk[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) wk[k] = *(const f32x4*)(w + k * H + hq * 4);
+    const f32x4 bv = *(const f32x4*)(bias + hq * 4);
+    for (uint32_t row = blockIdx.x * rpb + threadIdx.x / tpr; row < n_rows; row += gridDim.x * rpb) {
+        const float* c = rgb + (size_t)row * 3;
+        const float* p = xyz + (size_t)row * 3;
+        const float in[6] = {c[0], c[1], c[2], p[0], p[1], p[2]};
+        f32x4 v = bv;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaf(in[k], wk[k][e], v[e]);
+        *(f32x4*)(out + (size_t)row * H + hq * 4) = v;
     }
 }
 
 // Centroid table B_i = W1p pos_i (one row of H floats per centroid) plus the [xyz | 0 x 29] tail of the centroid's SA
 // output row.  H/4 threads per row, 16-byte stores; pure write bandwidth (no per-element index arithmetic).
 __global__ __launch_bounds__(256) void k_pos_table(const float* __restrict__ src, int ld_src, int col0,
-                                                   const uint8_t* __restrict__ idx, int64_t n_rows, int n_dense,
+                                                   const uint8_t* __restrict__ idx, uint32_t n_rows, int n_dense,
                                                    int n_cent, const float* __restrict__ wp, int H,
                                                    float* __restrict__ out, float* __restrict__ tail, int ld_tail,
                                                    int tail_col0) {
@@ -40,10 +44,10 @@ __global__ __launch_bounds__(256) void k_pos_table(const float* __restrict__ src
     const int rpb = 256 / tpr;              // rows per block pass
     const int hq = threadIdx.x % tpr;
     f32x4 w0 = *(const f32x4*)(wp + hq * 4), w1 = *(const f32x4*)(wp + H + hq * 4), w2 = *(const f32x4*)(wp + 2 * H + hq * 4);
-    for (int64_t row = (int64_t)blockIdx.x * rpb + threadIdx.x / tpr; row < n_rows; row += (int64_t)gridDim.x * rpb) {
-        const int64_t o = row / n_cent;
-        const int loc = idx ? (int)idx[row] : (int)(row - o * n_cent);
-        const float* p = src + (o * n_dense + loc) * (int64_t)ld_src + col0;
+    for (uint32_t row = blockIdx.x * rpb + threadIdx.x / tpr; row < n_rows; row += gridDim.x * rpb) {
+        const uint32_t o = row / (uint32_t)n_cent;   // 32-bit: a chunk has < 2^31 centroid rows (checked by the launcher)
+        const uint32_t loc = idx ? (uint32_t)idx[row] : row - o * (uint32_t)n_cent;
+        const float* p = src + ((size_t)o * n_dense + loc) * (size_t)ld_src + col0;
         const float px = p[0], py = p[1], pz = p[2];
         f32x4 v;
 #pragma unroll
@@ -53,9 +57,9 @@ __global__ __launch_bounds__(256) void k_pos_table(const float* __restrict__ src
             a = fmaf(pz, w2[e], a);
             v[e] = a;
         }
-        *(f32x4*)(out + row * H + hq * 4) = v;
+        *(f32x4*)(out + (size_t)row * H + hq * 4) = v;
         if (tail != nullptr && hq < 8)
-            *(f32x4*)(tail + row * ld_tail + tail_col0 + hq * 4) = hq == 0 ? f32x4{px, py, pz, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(tail + (size_t)row * ld_tail + tail_col0 + hq * 4) = hq == 0 ? f32x4{px, py, pz, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -155,43 +159,71 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int di
 }
 
 // colour / position encoders of ObjectEncoder (models/object_encoder.py:40-41,124-135): 3 -> 64 -> D, each layer
-// Linear+BN+ReLU, then F.normalize.  One wavefront per object: lane = hidden unit, then D/64 outputs per lane.
+// Linear+BN+ReLU, then F.normalize.  A block owns 32 objects: the hidden layer goes to LDS, every thread then owns one
+// (or two) output columns for all 32 objects, so a W2 element is fetched once per 32 objects (one wave per object
+// re-read the whole 64 x D matrix per object: 12 GB of L2 traffic per call at 192 k objects).
+constexpr int kMlp3Rows = 32;
 __global__ __launch_bounds__(256) void k_mlp3_norm(const float* __restrict__ in3, int64_t n_rows,
                                                    const float* __restrict__ w1, const float* __restrict__ b1,
                                                    const float* __restrict__ w2, const float* __restrict__ b2, int D,
                                                    float* __restrict__ out, int ld_out, int col0) {
-    __shared__ float hid[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
-    const bool ok = row < n_rows;
-    float hval = 0.f;
-    if (ok) {
-        const float* x = in3 + row * 3;
-        float a = b1[lane];
-        a = fmaf(x[0], w1[lane], a);
-        a = fmaf(x[1], w1[64 + lane], a);
-        a = fmaf(x[2], w1[128 + lane], a);
-        hval = fmaxf(a, 0.f);
+    __shared__ float hid[kMlp3Rows][64];
+    __shared__ float ss[4][kMlp3Rows];   // per-wave partial sums of squares, combined in a fixed order (deterministic)
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * kMlp3Rows;
+    for (int i = tid; i < kMlp3Rows * 64; i += 256) {
+        const int r = i >> 6, u = i & 63;
+        float h = 0.f;
+        if (row0 + r < n_rows) {
+            const float* x = in3 + (row0 + r) * 3;
+            float a = b1[u];
+            a = fmaf(x[0], w1[u], a);
+            a = fmaf(x[1], w1[64 + u], a);
+            a = fmaf(x[2], w1[128 + u], a);
+            h = fmaxf(a, 0.f);
+        }
+        hid[r][u] = h;
     }
-    hid[wv][lane] = hval;
     __syncthreads();
-    if (!ok) return;
-    float o[8];
-    float ss = 0.f;
-    const int per = D / 64;
-    for (int j = 0; j < per; j++) {
-        const int c = j * 64 + lane;
-        float a = b2[c];
-        for (int k = 0; k < 64; k++) a = fmaf(hid[wv][k], w2[k * D + c], a);
-        a = fmaxf(a, 0.f);
-        o[j] = a;
-        ss = fmaf(a, a, ss);
-    }
+    float o[2][kMlp3Rows];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-    const float nrm = sqrtf(ss);
-    const float den = nrm > 1e-12f ? nrm : 1e-12f;
-    for (int j = 0; j < per; j++) out[row * ld_out + col0 + j * 64 + lane] = o[j] / den;
+    for (int j = 0; j < 2; j++) {
+        const int c = tid + 256 * j;
+        if (c >= D) break;
+        const float bv = b2[c];
+#pragma unroll
+        for (int r = 0; r < kMlp3Rows; r++) o[j][r] = bv;
+        for (int k = 0; k < 64; k++) {
+            const float w = w2[k * D + c];
+#pragma unroll
+            for (int r = 0; r < kMlp3Rows; r++) o[j][r] = fmaf(hid[r][k], w, o[j][r]);
+        }
+#pragma unroll
+        for (int r = 0; r < kMlp3Rows; r++) o[j][r] = fmaxf(o[j][r], 0.f);
+    }
+    // row norms: per-wave butterfly, one partial per wave and row
+#pragma unroll
+    for (int r = 0; r < kMlp3Rows; r++) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (tid + 256 * j < D) v = fmaf(o[j][r], o[j][r], v);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((tid & 63) == 0) ss[tid >> 6][r] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int c = tid + 256 * j;
+        if (c >= D) break;
+#pragma unroll
+        for (int r = 0; r < kMlp3Rows; r++) {
+            if (row0 + r >= n_rows) break;
+            const float nrm = sqrtf((ss[0][r] + ss[1][r]) + (ss[2][r] + ss[3][r]));
+            out[(row0 + r) * ld_out + col0 + c] = o[j][r] / (nrm > 1e-12f ? nrm : 1e-12f);
+        }
+    }
 }
 
 // On-device version of dataloading/kitti360pose/utils.py::batch_object_points + the per-object means of
@@ -286,8 +318,9 @@ int launch_sa1_point_table(const float* rgb, const float* xyz, int64_t n_rows, c
                            int H, float* out, hipStream_t st) {
     if (n_rows == 0) return 0;
     ProfScope ps_("sa1_point_table", st);
-    hipLaunchKernelGGL(k_sa1_point_table, dim3(grid_for(n_rows * H, 256)), dim3(256), 0, st, rgb, xyz, n_rows, w,
-                       bias, H, out);
+    T2P_CHECK_ARG(H % 4 == 0 && H >= 4 && H <= 1024 && 256 % (H / 4) == 0 && n_rows < 0x7fffffffLL, "sa1_point_table: H=%d", H);
+    hipLaunchKernelGGL(k_sa1_point_table, dim3(grid_for(n_rows * (H / 4), 256)), dim3(256), 0, st, rgb, xyz,
+                       (uint32_t)n_rows, w, bias, H, out);
     T2P_CHECK_LAUNCH("sa1_point_table");
     return 0;
 }
@@ -299,8 +332,9 @@ int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx,
     ProfScope ps_("pos_table", st);
     T2P_CHECK_ARG(H % 4 == 0 && H >= 32 && H <= 1024 && 256 % (H / 4) == 0, "pos_table: H=%d", H);
     const int64_t n_rows = n_obj * n_cent;
+    T2P_CHECK_ARG(n_rows < 0x7fffffffLL, "pos_table: chunk too large");
     hipLaunchKernelGGL(k_pos_table, dim3(grid_for(n_rows * (H / 4), 256)), dim3(256), 0, st, src, ld_src, col0, idx,
-                       n_rows, n_dense, n_cent, wp, H, out, tail, ld_tail, tail_col0);
+                       (uint32_t)n_rows, n_dense, n_cent, wp, H, out, tail, ld_tail, tail_col0);
     T2P_CHECK_LAUNCH("pos_table");
     return 0;
 }
@@ -338,7 +372,7 @@ int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const fl
     T2P_CHECK_ARG(D % 64 == 0 && D <= 512, "mlp3_norm: D=%d must be a multiple of 64, <= 512", D);
     if (n_rows == 0) return 0;
     ProfScope ps_("mlp3_norm", st);
-    hipLaunchKernelGGL(k_mlp3_norm, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, in3, n_rows, w1, b1, w2, b2, D,
+    hipLaunchKernelGGL(k_mlp3_norm, dim3((unsigned)((n_rows + kMlp3Rows - 1) / kMlp3Rows)), dim3(256), 0, st, in3, n_rows, w1, b1, w2, b2, D,
                        out, ld_out, col0);
     T2P_CHECK_LAUNCH("mlp3_norm");
     return 0;
