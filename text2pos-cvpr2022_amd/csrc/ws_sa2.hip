@@ -26,14 +26,18 @@ int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st
 namespace {
 
 constexpr int kSub = 512;
-constexpr int NT = 512;
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
-template <int K, int N, int WN, int RT>
+// NW = waves per workgroup.  8: one workgroup per CU (two waves per SIMD that share every barrier).  4: TWO independent
+// workgroups per CU (one wave per SIMD each): the two waves of a SIMD then belong to different workgroups, drift apart
+// and cover each other's non-MFMA phases; needs <= 80 KB of LDS, which the single-buffered accumulator allows for K <= 128.
+template <int K, int N, int WN, int RT, int NW>
 struct Cfg2 {
-    static constexpr int WM = 8 / WN;
+    static constexpr int NT = 64 * NW;
+    static constexpr int ACC_BUFS = NW == 8 ? 2 : 1;
+    static constexpr int WM = NW / WN;
     static constexpr int NTW = N / (32 * WN);
     static constexpr int TR = WM * RT * 32;
     static constexpr int F4_PER_ROW = K / 4;
@@ -46,7 +50,7 @@ struct Cfg2 {
     static constexpr int NG = S16 * RT;      // MFMA groups per batch and wave
     static constexpr int NCH = 3 * ITERS;    // staging chunks per batch and thread
     static constexpr size_t lds_bytes() {
-        return (size_t)2 * 2 * PLANE * 2 + (size_t)2 * ACC_INTS * 4 + 4 * TR + kSub * 2 + kSub * 4;
+        return (size_t)2 * 2 * PLANE * 2 + (size_t)ACC_BUFS * ACC_INTS * 4 + 4 * TR + kSub * 2 + kSub * 4;
     }
 };
 
@@ -72,13 +76,14 @@ struct BatchIt {
         else issue(it_g, meta_g, k, dbuf);                                                     \
     }
 
-template <int K, int N, int WN, int RT>
-__global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
-    using C = Cfg2<K, N, WN, RT>;
+template <int K, int N, int WN, int RT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p) {
+    using C = Cfg2<K, N, WN, RT, NW>;
+    constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     _Float16* hidh = (_Float16*)lds;                            // [2][hi plane | lo plane]
     int* acc_lds = (int*)(hidh + 2 * 2 * C::PLANE);             // [2][ACC_INTS]
-    uint8_t* dstl = (uint8_t*)(acc_lds + 2 * C::ACC_INTS);      // [4][TR] destination (centroid) of every staged row
+    uint8_t* dstl = (uint8_t*)(acc_lds + C::ACC_BUFS * C::ACC_INTS);      // [4][TR] destination (centroid) of every staged row
     uint16_t* nr = (uint16_t*)(dstl + 4 * C::TR);               // [kSub]
     int* sbase = (int*)(nr + kSub);                             // [kSub]
 
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
 #pragma unroll
     for (int nt = 0; nt < C::NTW; nt++) bias[nt] = p.bias[wn * C::NTW * 32 + nt * 32 + l31];
 
-    for (int i = tid; i < 2 * C::ACC_INTS; i += NT) acc_lds[i] = 0;
+    for (int i = tid; i < C::ACC_BUFS * C::ACC_INTS; i += NT) acc_lds[i] = 0;
 
     const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
     const int rgrp = (tid / C::F4_PER_ROW) * C::ITERS;  // first of this thread's 4 staged rows inside a batch
@@ -264,6 +269,8 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
             if (flush_g >= 0) {  // the object finished in the previous batch drains to HBM
                 flush(flush_g, flush_buf);
                 flush_g = -1;
+                // one accumulator buffer: the next object's atomics (issued inside this batch) must not overtake the drain
+                if constexpr (C::ACC_BUFS == 1) __syncthreads();
             }
 
             const int buf = t & 1, sbuf = buf ^ 1, dbuf = (t + 2) & 3;
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
             }
             STAMP(3);
             SB();
-            const int abuf = it_c.gi & 1;
+            const int abuf = C::ACC_BUFS == 2 ? (it_c.gi & 1) : 0;
             const bool obj_done = it_c.r0 + C::TR >= it_c.n;
             if constexpr (DEFER) {
 #pragma unroll
@@ -387,7 +394,10 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
             STAMP(7);
             trace_n++;
         }
-        if (flush_g >= 0) flush(flush_g, flush_buf);
+        if (flush_g >= 0) {
+            flush(flush_g, flush_buf);
+            if constexpr (C::ACC_BUFS == 1) __syncthreads();
+        }
         if constexpr (DEFER) {  // drain: atomics of the last batch, then its object
             uint32_t four[RT][4];
             const uint8_t* dl = dstl + ((t_end + 3) & 3) * C::TR;
@@ -402,10 +412,11 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa2(SaParams p) {
     }
 }
 
-template <int K, int N, int WN, int RT>
+template <int K, int N, int WN, int RT, int NW>
 int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
-    using C = Cfg2<K, N, WN, RT>;
-    auto kern = k_ws_sa2<K, N, WN, RT>;
+    using C = Cfg2<K, N, WN, RT, NW>;
+    static_assert(NW == 8 || K <= 128, "the 4-wave form relies on the deferred atomics (K <= 128)");
+    auto kern = k_ws_sa2<K, N, WN, RT, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -420,12 +431,13 @@ int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
     T2P_CHECK_ARG(p.n_obj < (1 << 30) && p.n_obj * p.n_dense * (int64_t)K * 4 < 0xffffffffLL &&
                       p.n_obj * p.n_cent * (int64_t)K * 4 < 0xffffffffLL,
                   "ws_sa: chunk too large for 32-bit table offsets");
-    int n_wg = num_cus();
+    int n_wg = num_cus() * (NW == 8 ? 1 : 2);
+    if (n_wg > 1024) n_wg = 1024;
     if (n_wg > p.n_obj) n_wg = (int)p.n_obj;
     int rc = launch_sa_balance(p, C::TR, n_wg, st);
     if (rc != 0) return rc;
     ProfScope ps_(name, st);
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NT), C::lds_bytes(), st, p);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(C::NT), C::lds_bytes(), st, p);
     T2P_CHECK_LAUNCH("ws_sa2");
 #if T2P_TRACE
     {
@@ -455,9 +467,11 @@ int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
 }  // namespace
 
 int launch_ws_sa2(int H, int Cout, const SaParams& p, hipStream_t st) {
-    if (H == 32 && Cout == 64) return launch_cfg2<32, 64, 2, 2>(p, st, "ws_edge_sa_k32_n64");
-    if (H == 128 && Cout == 128) return launch_cfg2<128, 128, 4, 1>(p, st, "ws_edge_sa_k128_n128");
-    if (H == 256 && Cout == 256) return launch_cfg2<256, 256, 8, 1>(p, st, "ws_edge_sa_k256_n256");
+    // SA1: two 4-wave workgroups per CU measured 4 % faster than one 8-wave workgroup; SA2: no difference (kept 8-wave,
+    // whose double-buffered accumulator drains under the MFMAs); SA3 cannot (128 weight registers per 32 columns).
+    if (H == 32 && Cout == 64) return launch_cfg2<32, 64, 2, 2, 4>(p, st, "ws_edge_sa_k32_n64");
+    if (H == 128 && Cout == 128) return launch_cfg2<128, 128, 4, 1, 8>(p, st, "ws_edge_sa_k128_n128");
+    if (H == 256 && Cout == 256) return launch_cfg2<256, 256, 8, 1, 8>(p, st, "ws_edge_sa_k256_n256");
     set_error("ws_sa2: no instantiation for H=%d C=%d", H, Cout);
     return T2P_E_UNSUPPORTED;
 }
