@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 3
+#define T2P_ABI_VERSION 4
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -95,6 +95,12 @@ typedef struct t2p_cell_weights {
      * w[k = half*K/2 + 8*step + e][n = 32*tile + lane]  (packing.py::pack_f16x3). */
     const void* sa_w2_x3[3];
     const void* ga_w2_x3;
+    /* The SA layer-2 images (sa_w2_x3) use the scaled single-accumulator form instead: w' = s w with s = sa_w2_scale[l]
+     * a power of two (so that |w'| uses fp16's range), hi = fp16(w'), lo = fp16(w' - hi) (no 2048 factor: MFMA honours
+     * fp16 denormals), the three products hi.hi + hi.lo + lo.hi share ONE fp32 accumulator that starts at
+     * sa_b2_x3[l] = s b2; the kernel divides by s when it drains an object (packing.py::pack_f16x3_scaled). */
+    const float* sa_b2_x3[3];
+    float sa_w2_scale[3];
     const void* sa_w1_x3[3]; /* levels 1 and 2 only (level 0 has K = 6 and runs on the VALU); [0] is ignored */
     const void* ga_w1_x3;
     /* ObjectEncoder.class_embedding / color_embedding (object_encoder.py:31-38), used by the --class_embed /

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -22,7 +22,8 @@ class CellWeights(C.Structure):
               "lin2_b", "pn_w", "pn_b", "col_w1", "col_b1", "col_w2", "col_b2", "pos_w1", "pos_b1", "pos_w2", "pos_b2",
               "merge_w", "merge_b", "g_wp", "g_bp", "g_wq", "g_w2", "g_b2", "lin_w1", "lin_b1", "lin_w2", "lin_b2"])
     _fields_ = ([(n, c_void * 3) for n in _names[0]] + [(n, c_void) for n in _names[1]] +
-                [("sa_w2_x3", c_void * 3), ("ga_w2_x3", c_void), ("sa_w1_x3", c_void * 3), ("ga_w1_x3", c_void),
+                [("sa_w2_x3", c_void * 3), ("ga_w2_x3", c_void), ("sa_b2_x3", c_void * 3), ("sa_w2_scale", C.c_float * 3),
+                 ("sa_w1_x3", c_void * 3), ("ga_w1_x3", c_void),
                  ("class_embedding", c_void), ("color_embedding", c_void)])
 
 

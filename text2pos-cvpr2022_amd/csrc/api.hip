@@ -230,7 +230,8 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.Bc = ws.B[l];
         p.W = W.sa_w2[l];
         p.W_x3 = cfg.precision == 1 ? W.sa_w2_x3[l] : nullptr;
-        p.bias = W.sa_b2[l];
+        p.bias = cfg.precision == 1 ? W.sa_b2_x3[l] : W.sa_b2[l];
+        p.out_scale = cfg.precision == 1 ? 1.0f / W.sa_w2_scale[l] : 1.0f;
         p.out = ws.F[l];
         p.ldo = Geo::LD[l];
         p.rows = ws.gt.rows[l];
@@ -446,7 +447,9 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
     T2P_CHECK_ARG(!cfg->class_embed || w->class_embedding != nullptr, "encode_cells: class_embedding weights missing");
     T2P_CHECK_ARG(!cfg->color_embed || w->color_embedding != nullptr, "encode_cells: color_embedding weights missing");
     if (cfg->precision == 1)
-        T2P_CHECK_ARG(w->sa_w2_x3[0] && w->sa_w2_x3[1] && w->sa_w2_x3[2] && w->sa_w1_x3[1] && w->sa_w1_x3[2] &&
+        T2P_CHECK_ARG(w->sa_w2_x3[0] && w->sa_w2_x3[1] && w->sa_w2_x3[2] && w->sa_b2_x3[0] && w->sa_b2_x3[1] &&
+                          w->sa_b2_x3[2] && w->sa_w2_scale[0] > 0.f && w->sa_w2_scale[1] > 0.f && w->sa_w2_scale[2] > 0.f &&
+                          w->sa_w1_x3[1] && w->sa_w1_x3[2] &&
                           w->ga_w1_x3 && w->ga_w2_x3,
                       "encode_cells: precision = f16x3 needs the packed *_x3 weight images");
     T2P_CHECK_ARG(n_cells >= 0 && n_obj >= 0, "encode_cells: negative size");

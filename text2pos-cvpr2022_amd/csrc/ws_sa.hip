@@ -15,9 +15,6 @@
 #ifndef T2P_LDS_PREFETCH
 #define T2P_LDS_PREFETCH 1
 #endif
-#ifndef T2P_SA_V1
-#define T2P_SA_V1 0
-#endif
 #include "t2p_common.h"
 
 namespace t2p {
@@ -251,7 +248,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
             float* o = p.out + g * nc * (int64_t)p.ldo;
             for (int i = tid; i < nc * N; i += NT) {
                 const int c = i / N, col = i % N;
-                o[c * (int64_t)p.ldo + col] = __int_as_float(a[i]);
+                o[c * (int64_t)p.ldo + col] = __int_as_float(a[i]) * p.out_scale;
                 a[i] = 0;
             }
         };
@@ -482,14 +479,9 @@ int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st
 
 int launch_ws_sa(int H, int Cout, const SaParams& p, hipStream_t st) {
     T2P_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.Bc) & 15) == 0, "ws_sa: tables must be 16-byte aligned");
-    if (p.W_x3 != nullptr) {  // f16x3 split-precision path
+    if (p.W_x3 != nullptr) {  // f16x3 split-precision path: the interleaved kernel (ws_sa2.hip)
         T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_sa: packed f16x3 weights must be 16-byte aligned");
-#if !T2P_SA_V1
         return launch_ws_sa2(H, Cout, p, st);
-#endif
-        if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2, 1>(p, st, "ws_edge_sa_k32_n64");
-        if (H == 128 && Cout == 128) return launch_sa_cfg<128, 128, 4, 1, 1>(p, st, "ws_edge_sa_k128_n128");
-        if (H == 256 && Cout == 256) return launch_sa_cfg<256, 256, 8, 1, 1>(p, st, "ws_edge_sa_k256_n256");
     } else {
         if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2, 0>(p, st, "ws_edge_sa_k32_n64");
         if (H == 128 && Cout == 128) return launch_sa_cfg<128, 128, 4, 1, 0>(p, st, "ws_edge_sa_k128_n128");

@@ -8,7 +8,7 @@
 //     registers -> ReLU(A_j - B_i) -> fp16 hi/lo planes in the other LDS buffer), gathers of batch t+2 (re-issued into
 //     each register quad as soon as its t+1 content is staged), row metadata of batch t+3;
 //   * the staging / gather work is cut into 12 chunks that are placed BETWEEN the MFMAs of the 16 (or 8, or 4) MFMA
-//     groups -- in the shadow of the accx -> accx accumulator dependency -- with __builtin_amdgcn_sched_barrier fences,
+//     groups with __builtin_amdgcn_sched_barrier fences,
 //     so VALU, LDS, the texture path and the matrix pipe work at the same time inside every wave instead of taking
 //     turns between barriers (measured on the phase-per-barrier kernel: MFMA, gather and staging time simply added up);
 //   * all loads are unconditional: padding rows read row 0 of their object and are routed to the accumulator's dummy
@@ -106,9 +106,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
                 w_lo[nt][s] = __builtin_bit_cast(half8, b);
             }
     }
-    float bias[C::NTW];
+    f32x16 biasv[C::NTW];  // bias (pre-multiplied by the weight scale) broadcast over the 16 rows of a lane: the C operand
+#pragma unroll              // of every batch's first MFMA, so the accumulator needs no per-batch initialisation
+    for (int nt = 0; nt < C::NTW; nt++) {
+        const float bv = p.bias[wn * C::NTW * 32 + nt * 32 + l31];
 #pragma unroll
-    for (int nt = 0; nt < C::NTW; nt++) bias[nt] = p.bias[wn * C::NTW * 32 + nt * 32 + l31];
+        for (int e = 0; e < 16; e++) biasv[nt][e] = bv;
+    }
 
     for (int i = tid; i < C::ACC_BUFS * C::ACC_INTS; i += NT) acc_lds[i] = 0;
 
@@ -191,11 +195,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
             ph.y = __builtin_bit_cast(uint32_t, vh23);
             *(uint2*)(dsth + (rgrp + k) * C::LDHH + c4 * 4) = ph;
         };
-        // second half: lo = fp16((v - hi) * 2048) -> lo plane
+        // second half: lo = fp16(v - hi) -> lo plane (no scale factor: the matrix cores honour fp16 denormals)
         auto stage_b = [&](int buf, int k) {
             _Float16* dsth = hidh + buf * 2 * C::PLANE;
-            const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((vv[0] - (float)vh01[0]) * 2048.f, (vv[1] - (float)vh01[1]) * 2048.f);
-            const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((vv[2] - (float)vh23[0]) * 2048.f, (vv[3] - (float)vh23[1]) * 2048.f);
+            const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz(vv[0] - (float)vh01[0], vv[1] - (float)vh01[1]);
+            const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz(vv[2] - (float)vh23[0], vv[3] - (float)vh23[1]);
             uint2 pl;
             pl.x = __builtin_bit_cast(uint32_t, l01);
             pl.y = __builtin_bit_cast(uint32_t, l23);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
             float* o = p.out + g * nc * (int64_t)p.ldo;
             for (int i = tid; i < nc * N; i += NT) {
                 const int c = i / N, col = i % N;
-                o[c * (int64_t)p.ldo + col] = __int_as_float(a[i]);
+                o[c * (int64_t)p.ldo + col] = __int_as_float(a[i]) * p.out_scale;  // weight image scale (power of 2)
                 a[i] = 0;
             }
         };
@@ -275,16 +279,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
 
             const int buf = t & 1, sbuf = buf ^ 1, dbuf = (t + 2) & 3;
             BatchIt it_n = it_m;
-            f32x16 acc[RT][C::NTW], accx[RT][C::NTW];
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                for (int nt = 0; nt < C::NTW; nt++)
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        acc[rt][nt][e] = bias[nt];
-                        accx[rt][nt][e] = 0.f;
-                    }
+            f32x16 acc[RT][C::NTW];  // ONE accumulator for hi.hi + hi.lo + lo.hi (same scale); it starts at the bias block
             STAMP(1);
             // destination bytes of this lane's 16 accumulator rows (4 quads of 4 consecutive rows per row tile); written
             // two batches ago, fetched here so that the atomics behind the MFMAs do not start with an LDS round trip
@@ -311,8 +306,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
                 }
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++) {
-                    acc[rt][nt] = MFMA16(a_hi, w_hi[nt][s], acc[rt][nt]);
-                    accx[rt][nt] = MFMA16(a_hi, w_lo[nt][s], accx[rt][nt]);
+                    acc[rt][nt] = MFMA16(a_hi, w_hi[nt][s], s == 0 ? biasv[nt] : acc[rt][nt]);
+                    acc[rt][nt] = MFMA16(a_hi, w_lo[nt][s], acc[rt][nt]);
                 }
                 SB();
                 if (j == 0) load_meta(it_m, meta_m);  // M(t+3); issued behind the first MFMAs so nothing waits on it
@@ -324,7 +319,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
                 SB();
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++)
-                    accx[rt][nt] = MFMA16(a_lo, w_hi[nt][s], accx[rt][nt]);
+                    acc[rt][nt] = MFMA16(a_lo, w_hi[nt][s], acc[rt][nt]);
                 a_hi = n_hi;
                 a_lo = n_lo;
                 if (j == C::NG / 2 - 1) {
@@ -340,9 +335,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++)
-#pragma unroll
-                        for (int e = 0; e < 16; e++) res[rt][nt][e] = fmaf(accx[rt][nt][e], 1.f / 2048.f, acc[rt][nt][e]);
+                    for (int nt = 0; nt < C::NTW; nt++) res[rt][nt] = acc[rt][nt];
                 prev_abuf = abuf;
                 // the object whose atomics ran in this batch may be flushed next; the one that just ended waits a batch
                 flush_g = flush_g1;
@@ -350,12 +343,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
                 flush_g1 = obj_done ? (int64_t)(ga + it_c.gi) : -1;
                 flush_buf1 = abuf;
             } else {
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++)
-#pragma unroll
-                        for (int e = 0; e < 16; e++) acc[rt][nt][e] = fmaf(accx[rt][nt][e], 1.f / 2048.f, acc[rt][nt][e]);
                 STAMP(4);
                 load_four();
                 // max-aggregation: integer atomic max into the object's LDS accumulator (the max against +0 is the ReLU)

@@ -174,6 +174,11 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
                 if t is not None:
                     _need(t, name, torch.int16)
             setattr(w, name, (C.c_void_p * 3)(*[0 if t is None else t.data_ptr() for t in x3]))
+    if packed.get("sa_b2_x3") is not None:
+        for t in packed["sa_b2_x3"]:
+            _need(t, "sa_b2_x3", torch.float32)
+        w.sa_b2_x3 = (C.c_void_p * 3)(*[t.data_ptr() for t in packed["sa_b2_x3"]])
+        w.sa_w2_scale = (C.c_float * 3)(*[float(v) for v in packed["sa_w2_scale"]])
     for name in ("ga_w1_x3", "ga_w2_x3"):
         g = packed.get(name)
         if g is not None:

@@ -7,6 +7,7 @@ Sequential(Linear, BatchNorm1d, ReLU) -> keys `<mlp>.<layer>.0.{weight,bias}` an
 """
 from typing import Dict, List, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -54,6 +55,28 @@ def pack_f16x3(w_kmajor: torch.Tensor) -> torch.Tensor:
     return torch.stack(planes).view(torch.int16).contiguous()
 
 
+def f16x3_scale(w: torch.Tensor) -> float:
+    """Largest power of two s with max|s w| <= 2^14 (fp16 overflows at 65504), clipped to [2^-8, 2^15]."""
+    m = float(w.detach().abs().max())
+    if m == 0.0:
+        return 1.0
+    e = int(np.floor(np.log2(2.0 ** 14 / m)))
+    return float(2.0 ** max(-8, min(15, e)))
+
+
+def pack_f16x3_scaled(w_kmajor: torch.Tensor, scale: float) -> torch.Tensor:
+    """Single-accumulator form used by the SA edge kernel (csrc/ws_sa2.hip): w' = scale * w (a power of two: exact),
+    hi = fp16(w'), lo = fp16(w' - hi) WITHOUT the 2048 factor (the matrix cores honour fp16 denormals, and w' uses fp16's
+    range, so lo keeps 11 significant bits).  Same register-order layout as pack_f16x3."""
+    k, n = w_kmajor.shape
+    assert k % 32 == 0 and n % 32 == 0, (k, n)
+    w = w_kmajor.detach().double().cpu() * scale
+    hi = w.to(torch.float16)
+    lo = (w - hi.double()).to(torch.float16)
+    planes = [t.view(2, k // 16, 8, n // 32, 32).permute(3, 1, 0, 4, 2).contiguous() for t in (hi, lo)]
+    return torch.stack(planes).view(torch.int16).contiguous()
+
+
 def pack_cell_weights(model, device) -> Dict[str, object]:
     """model: CellRetrievalNetwork or SuperGlueMatch (this package; the latter has no cell head).  Returns name -> fp32
     device tensor(s) for ops.make_cell_weights."""
@@ -69,7 +92,10 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
         sa_w2.append(kmajor(w2).to(device))
         sa_b2.append(f32(b2).to(device))
     p.update(sa_w1=sa_w1, sa_b1=sa_b1, sa_w2=sa_w2, sa_b2=sa_b2)
-    p["sa_w2_x3"] = [pack_f16x3(t).to(device) for t in sa_w2]
+    scales = [f16x3_scale(t) for t in sa_w2]
+    p["sa_w2_scale"] = scales
+    p["sa_w2_x3"] = [pack_f16x3_scaled(t, sc).to(device) for t, sc in zip(sa_w2, scales)]
+    p["sa_b2_x3"] = [f32(b.double() * sc).to(device) for b, sc in zip(sa_b2, scales)]
     p["sa_w1_x3"] = [None] + [pack_f16x3(t).to(device) for t in sa_w1[1:]]
     w1, b1 = fold_linear_bn(pn.ga.mlp[0])
     w2, b2 = fold_linear_bn(pn.ga.mlp[1])
