@@ -50,7 +50,7 @@ struct Cfg2 {
     static constexpr int NG = S16 * RT;      // MFMA groups per batch and wave
     static constexpr int NCH = 3 * ITERS;    // staging chunks per batch and thread
     static constexpr size_t lds_bytes() {
-        return (size_t)2 * 2 * PLANE * 2 + (size_t)ACC_BUFS * ACC_INTS * 4 + 4 * TR + kSub * 2 + kSub * 4;
+        return (size_t)2 * 2 * PLANE * 2 + (size_t)ACC_BUFS * ACC_INTS * 4 + 4 * TR * 2 + kSub * 2 + kSub * 4;
     }
 };
 
@@ -62,6 +62,17 @@ struct Cfg2 {
 #else
 #define STAMP(i)
 #endif
+
+// v - (float)h[SEL] with the conversion folded into the FMA (VOP3P mixed-precision FMA, op_sel picks the half)
+template <int SEL>
+__device__ __forceinline__ float sub_half(float v, fp16x2 h) {
+    float r;
+    if constexpr (SEL == 0)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    else
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
 
 struct BatchIt {
     int gi, r0, n;
@@ -83,8 +94,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     _Float16* hidh = (_Float16*)lds;                            // [2][hi plane | lo plane]
     int* acc_lds = (int*)(hidh + 2 * 2 * C::PLANE);             // [2][ACC_INTS]
-    uint8_t* dstl = (uint8_t*)(acc_lds + C::ACC_BUFS * C::ACC_INTS);      // [4][TR] destination (centroid) of every staged row
-    uint16_t* nr = (uint16_t*)(dstl + 4 * C::TR);               // [kSub]
+    // [4][TR] destination of every staged row as the BYTE offset of its accumulator row (centroid * N * 4 <= 0x8000):
+    // the atomics then need one add per address (SDWA picks the 16-bit half), not extract + multiply + add
+    uint16_t* dstl = (uint16_t*)(acc_lds + C::ACC_BUFS * C::ACC_INTS);
+    uint16_t* nr = dstl + 4 * C::TR;                            // [kSub]
     int* sbase = (int*)(nr + kSub);                             // [kSub]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
                 sa[k] = *(const f32x4*)((const char*)p.A + (srow * (uint32_t)(K * 4) + c4b));
                 sb[k] = *(const f32x4*)((const char*)p.Bc + ((g * (uint32_t)nc + dl) * (uint32_t)(K * 4) + c4b));
             }
-            if (c4 == 0) dstl[dbuf * C::TR + rgrp + k] = pad ? (uint8_t)nc : (uint8_t)dl;
+            if (c4 == 0) dstl[dbuf * C::TR + rgrp + k] = (uint16_t)((pad ? (uint32_t)nc : dl) * (uint32_t)(N * 4));
         };
         // staging of row k, first half: v = relu(A_j - B_i), hi = fp16(v) toward zero -> hi plane
         auto stage_a = [&](int buf, int k) {
@@ -198,8 +211,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
         // second half: lo = fp16(v - hi) -> lo plane (no scale factor: the matrix cores honour fp16 denormals)
         auto stage_b = [&](int buf, int k) {
             _Float16* dsth = hidh + buf * 2 * C::PLANE;
-            const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz(vv[0] - (float)vh01[0], vv[1] - (float)vh01[1]);
-            const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz(vv[2] - (float)vh23[0], vv[3] - (float)vh23[1]);
+            // v - float(hi) in one VALU op each: v_fma_mix_f32 reads the fp16 half directly (hi * -1 + v, exact)
+            const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(vv[0], vh01), sub_half<1>(vv[1], vh01));
+            const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(vv[2], vh23), sub_half<1>(vv[3], vh23));
             uint2 pl;
             pl.x = __builtin_bit_cast(uint32_t, l01);
             pl.y = __builtin_bit_cast(uint32_t, l23);
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
         for (int k = 0; k < 4; k++) issue(it_s, meta_g, k, 1);
         load_meta(it_g, meta_g);
         fix_meta(it_g, meta_g);
-        for (int i = tid; i < C::TR; i += NT) dstl[3 * C::TR + i] = (uint8_t)nc;  // "batch -1": every row is padding
+        for (int i = tid; i < C::TR; i += NT) dstl[3 * C::TR + i] = (uint16_t)(nc * N * 4);  // "batch -1": all padding
         __syncthreads();
 
         int64_t flush_g = -1, flush_g1 = -1;
@@ -256,14 +270,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
                     for (int e = 0; e < 16; e++) res[rt][nt][e] = 0.f;
         }
         // atomics e0 .. e1-1 (flattened over row tile, column tile, accumulator register) of a finished batch
-        auto atomics = [&](const f32x16 (&v)[DEFER ? RT : 1][DEFER ? C::NTW : 1], const uint32_t (&four)[RT][4], int abuf,
+        auto atomics = [&](const f32x16 (&v)[DEFER ? RT : 1][DEFER ? C::NTW : 1], const uint2 (&four)[RT][4], int abuf,
                            int e0, int e1) {
             int* accb = acc_lds + abuf * C::ACC_INTS;
 #pragma unroll
             for (int idx = e0; idx < e1; idx++) {
                 const int rt = idx / (C::NTW * 16), nt = (idx / 16) % C::NTW, e = idx % 16;
-                const int doff = (int)((four[rt][e >> 2] >> (8 * (e & 3))) & 0xFF) * N;
-                atomicMax(accb + wn * C::NTW * 32 + nt * 32 + l31 + doff, __float_as_int(v[rt][nt][e]));
+                const uint32_t pair = (e & 2) ? four[rt][e >> 2].y : four[rt][e >> 2].x;
+                const uint32_t off = (e & 1) ? (pair >> 16) : (pair & 0xFFFFu);
+                atomicMax((int*)((char*)(accb + wn * C::NTW * 32 + nt * 32 + l31) + off), __float_as_int(v[rt][nt][e]));
             }
         };
         int t_end = 0;
@@ -283,14 +298,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
             STAMP(1);
             // destination bytes of this lane's 16 accumulator rows (4 quads of 4 consecutive rows per row tile); written
             // two batches ago, fetched here so that the atomics behind the MFMAs do not start with an LDS round trip
-            uint32_t four[RT][4];
+            uint2 four[RT][4];
             constexpr bool HOIST = DEFER;  // K = 256 has no registers to spare (weights alone take 128)
             auto load_four = [&]() {
-                const uint8_t* dl = dstl + ((DEFER ? t + 3 : t) & 3) * C::TR;
+                const uint16_t* dl = dstl + ((DEFER ? t + 3 : t) & 3) * C::TR;
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) four[rt][q] = *(const uint32_t*)(dl + (wm * RT + rt) * 32 + 8 * q + 4 * h);
+                    for (int q = 0; q < 4; q++) four[rt][q] = *(const uint2*)(dl + (wm * RT + rt) * 32 + 8 * q + 4 * h);
             };
             if constexpr (HOIST) load_four();
             const _Float16* hrow = hidh + buf * 2 * C::PLANE + ((wm * RT) * 32 + l31) * C::LDHH + h * (K / 2);
@@ -351,17 +366,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
                 for (int rt = 0; rt < RT; rt++) {
                     const int trow0 = (wm * RT + rt) * 32;
                     if (it_c.r0 + trow0 >= it_c.n) continue;
-                    int doff[16];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) doff[4 * q + e] = (int)((four[rt][q] >> (8 * e)) & 0xFF) * N;
-                    }
 #pragma unroll
                     for (int nt = 0; nt < C::NTW; nt++) {
-                        int* col = accb + wn * C::NTW * 32 + nt * 32 + l31;
+                        char* col = (char*)(accb + wn * C::NTW * 32 + nt * 32 + l31);
 #pragma unroll
-                        for (int e = 0; e < 16; e++) atomicMax(col + doff[e], __float_as_int(acc[rt][nt][e]));
+                        for (int e = 0; e < 16; e++) {
+                            const uint32_t pair = (e & 2) ? four[rt][e >> 2].y : four[rt][e >> 2].x;
+                            atomicMax((int*)(col + ((e & 1) ? (pair >> 16) : (pair & 0xFFFFu))), __float_as_int(acc[rt][nt][e]));
+                        }
                     }
                 }
                 STAMP(5);
@@ -386,12 +398,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
             if constexpr (C::ACC_BUFS == 1) __syncthreads();
         }
         if constexpr (DEFER) {  // drain: atomics of the last batch, then its object
-            uint32_t four[RT][4];
-            const uint8_t* dl = dstl + ((t_end + 3) & 3) * C::TR;
+            uint2 four[RT][4];
+            const uint16_t* dl = dstl + ((t_end + 3) & 3) * C::TR;
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) four[rt][q] = *(const uint32_t*)(dl + (wm * RT + rt) * 32 + 8 * q + 4 * h);
+                for (int q = 0; q < 4; q++) four[rt][q] = *(const uint2*)(dl + (wm * RT + rt) * 32 + 8 * q + 4 * h);
             atomics(res, four, prev_abuf, 0, RT * C::NTW * 16);
             __syncthreads();
             if (flush_g1 >= 0) flush(flush_g1, flush_buf1);
