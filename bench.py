@@ -171,13 +171,21 @@ def main():
     d_tok, d_len = torch.from_numpy(tok).to(dev), torch.from_numpy(lens).to(dev)
     del xyz, rgb
 
+    side = torch.cuda.Stream(device=dev)   # the text branch is independent of the cell branch: its (latency-bound)
+                                           # biLSTM runs on a second HIP stream underneath the cell kernels
+
     def step():
         with torch.no_grad():
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                queries = model.language_encoder.encode_tokens(d_tok, d_len, normalize=True)
             cells = model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
                                                 chunk_objects=args.chunk_objects)
             if world > 1:
                 cells = TD.all_gather_rows(cells, n_cells_total)       # the one exchange step (RCCL over xGMI)
-            queries = model.language_encoder.encode_tokens(d_tok, d_len, normalize=True)
+            main.wait_stream(side)
+            queries.record_stream(main)
             return ops.sim_topk(queries, cells, TOPK)
 
     def barrier():
