@@ -264,6 +264,55 @@ def golden_fine(S):
     return out
 
 
+def golden_scene():
+    """A toy KITTI360Pose scene written by the REFERENCE's own classes (datapreparation/kitti360pose/imports.py), once under
+    the current module path and once under the legacy `datapreparation.kitti360` path that dataloading/__init__.py:8-10
+    keeps loadable: tests/golden/scene/{cells,poses}/{toy,toy_legacy}.pkl (pure data: 3 cells, 4 poses)."""
+    import pickle
+    import datapreparation.kitti360pose.imports as I
+    rng = np.random.default_rng(7)
+    cells = []
+    for i in range(3):
+        objs = [I.Object3d(j, 100 + j, rng.random((12, 3)), rng.random((12, 3)), ["box", "road", "pole"][j % 3]) for j in range(2 + i)]
+        cells.append(I.Cell(i, "toy0", objs, 30.0, np.array([30.0 * i, 0.0, 0.0, 30.0 * i + 30.0, 30.0, 10.0])))
+    poses = []
+    for q in range(4):
+        cell = cells[q % 3]
+        descs = []
+        for h in range(6):
+            o = cell.objects[h % len(cell.objects)]
+            dp = I.DescriptionPoseCell(o, ["north", "south", "east", "west", "on-top"][h % 5], rng.random(3), rng.random(3), rng.random(3))
+            descs.append(I.DescriptionBestCell.from_matched(dp, o.id, rng.random(3), rng.random(3), rng.random(3)) if h % 2 == 0
+                         else I.DescriptionBestCell.from_unmatched(dp))
+        poses.append(I.Pose(rng.random(3), np.array([30.0 * (q % 3) + 12.0, 14.0, 0.0]), cell.id, "toy0", descs))
+    base = os.path.join(HERE, "scene")
+    for sub, obj in (("cells", cells), ("poses", poses)):
+        os.makedirs(os.path.join(base, sub), exist_ok=True)
+        with open(os.path.join(base, sub, "toy.pkl"), "wb") as f:
+            pickle.dump(obj, f, protocol=4)
+    # legacy module path: what a file written before the package was renamed looks like
+    import datapreparation.kitti360pose as pkg
+    sys.modules["datapreparation.kitti360"] = pkg
+    sys.modules["datapreparation.kitti360.imports"] = I
+    classes = [I.Object3d, I.Cell, I.Pose, I.DescriptionPoseCell, I.DescriptionBestCell]
+    for c in classes:
+        c.__module__ = "datapreparation.kitti360.imports"
+    try:
+        for sub, obj in (("cells", cells), ("poses", poses)):
+            with open(os.path.join(base, sub, "toy_legacy.pkl"), "wb") as f:
+                pickle.dump(obj, f, protocol=4)
+    finally:
+        for c in classes:
+            c.__module__ = "datapreparation.kitti360pose.imports"
+    return dict(cell_ids=np.array([c.id for c in cells]), n_objects=np.array([len(c.objects) for c in cells]),
+                centers=np.array([c.get_center() for c in cells]), obj0_center=cells[0].objects[0].get_center(),
+                obj0_color=np.array(cells[0].objects[0].get_color_text()), pose_w=np.array([p.pose_w for p in poses]),
+                pose_cell=np.array([p.cell_id for p in poses]),
+                hint0=np.array(f"The pose is {poses[0].descriptions[0].direction} of a "
+                               f"{poses[0].descriptions[0].object_color_text} {poses[0].descriptions[0].object_label}."),
+                matched=np.array([[d.is_matched for d in p.descriptions] for p in poses]))
+
+
 def main():
     install_standins()
     import importlib
@@ -278,6 +327,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "retrieval.npz"), **golden_retrieval())
     np.savez_compressed(os.path.join(HERE, "eval_metrics.npz"), **golden_eval())
     np.savez_compressed(os.path.join(HERE, "fine.npz"), **golden_fine(S))
+    np.savez_compressed(os.path.join(HERE, "scene_expect.npz"), **golden_scene())
     for f in ("text_encoder.npz", "cell_encoder.npz", "retrieval.npz", "eval_metrics.npz", "fine.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 

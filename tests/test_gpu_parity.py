@@ -530,3 +530,49 @@ def test_match_other_shapes_vs_oracle(b, m, n, d, layers):
     assert torch.equal(out["matches0"].cpu(), want["matches0"]) and torch.equal(out["matches1"].cpu(), want["matches1"])
     assert (out["matching_scores0"].cpu() - want["matching_scores0"]).abs().max().item() < TOL
     assert abs(float(out["P"].sum()) - b * (m + n)) < 1e-2 * b      # couplings sum to M + N per sample
+
+
+def test_pipeline_end_to_end_on_a_synthetic_scene(tmp_path, vocab):
+    """io.save_scene -> io.load_scenes -> pipeline.evaluate (coarse retrieval + fine localisation) on a synthetic scene
+    with random weights: the glue must agree with the lower-level pieces it is made of."""
+    import text2pos_amd as t2p
+    from text2pos_amd import data as D, evaluation as E, io as IO, pipeline as PL, synthetic as S
+    rng = np.random.default_rng(11)
+    cells, poses = [], []
+    dirs = ["north", "south", "east", "west", "on-top"]
+    for i in range(24):
+        objs = []
+        for j in range(int(rng.integers(6, 20))):
+            c = rng.random(3) * np.array([1.0, 1.0, 0.3])
+            objs.append(D.Object3d(j, 1000 * i + j, c + 0.05 * rng.standard_normal((int(rng.integers(30, 400)), 3)),
+                                   np.clip(rng.random(3) + 0.05 * rng.standard_normal((1, 3)), 0, 1).repeat(1, 0) * np.ones((1, 3)),
+                                   S.LABELS[int(rng.integers(0, len(S.LABELS)))]))
+            objs[-1].rgb = np.repeat(objs[-1].rgb, len(objs[-1].xyz), axis=0)
+        x, y = 30.0 * (i % 6), 30.0 * (i // 6)
+        cells.append(D.Cell(i, "toy1", objs, 30.0, np.array([x, y, 0.0, x + 30.0, y + 30.0, 10.0])))
+    for q in range(40):
+        c = cells[int(rng.integers(0, 24))]
+        descs = [D.DescriptionBestCell(dirs[int(rng.integers(0, 5))], o.get_color_text(), o.label, o.id, True)
+                 for o in [c.objects[int(k)] for k in rng.integers(0, len(c.objects), 6)]]
+        poses.append(D.Pose(rng.random(3), c.bbox_w[0:3] + rng.random(3) * 30.0, c.id, "toy1", descs))
+    IO.save_scene(str(tmp_path), "toy1", cells, poses)
+    sc = IO.load_scenes(str(tmp_path), ["toy1"])
+    assert len(sc.all_cells) == 24 and len(sc.all_poses) == 40
+    torch.manual_seed(5)
+    coarse = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args()).to("cuda:0").eval()
+    fa = S.default_args()
+    fa.embed_dim, fa.num_layers, fa.sinkhorn_iters = 128, 2, 20
+    fine = t2p.SuperGlueMatch(vocab["classes"], vocab["colors"], vocab["words"], fa).to("cuda:0").eval()
+    out = PL.evaluate(coarse, fine, sc, PL.default_transform(256, 1), top_k=(1, 3, 5), threshs=(5, 10, 15), pad_size=16,
+                      queries_per_call=16)
+    assert len(out["retrievals"]) == 40 and all(len(r) == 5 for r in out["retrievals"])
+    for name in ("localisation", "fine_mean", "fine_offset"):
+        assert set(out[name].keys()) == {1, 3, 5} and all(0.0 <= out[name][k][t] <= 1.0 for k in (1, 3, 5) for t in (5, 10, 15))
+        assert out[name][5][15] >= out[name][1][15] - 1e-12 and out[name][1][15] >= out[name][1][5] - 1e-12   # monotone in k and thresh
+    assert set(out["fine_mean_conf"].keys()) == {1}
+    # hit@k of the glue == hit@k recomputed from the retrievals it returned
+    for k in (1, 3, 5):
+        assert abs(out["hit"][k] - np.mean([p.cell_id in r[:k] for p, r in zip(sc.all_poses, out["retrievals"])])) < 1e-12
+    # same T.FixedPoints seed -> same retrievals (the pipeline is deterministic given the draw)
+    out2 = PL.run_coarse(coarse, sc, PL.default_transform(256, 1), (1, 3, 5), (5, 10, 15))
+    assert out2[0] == out["retrievals"]

@@ -1,5 +1,6 @@
 """CPU tests of the host logic and of the C-ABI library's loadability (no compute calls without a GPU)."""
 import os
+import sys
 import re
 
 import numpy as np
@@ -353,3 +354,60 @@ def test_run_fine_bookkeeping_matches_per_sample_loop():
             assert abs(got[0][k][t] - np.mean(acc[0][k][t])) < 1e-12 and abs(got[1][k][t] - np.mean(acc[1][k][t])) < 1e-12
     for t in threshs:
         assert abs(got[2][1][t] - np.mean(acc_conf[1][t])) < 1e-12
+
+
+@pytest.mark.parametrize("scene", ["toy", "toy_legacy"])
+def test_scene_pickles_written_by_the_reference_load_without_it(golden_dir, scene):
+    """tests/golden/scene/*: pickles dumped by the reference's own Cell / Pose / Object3d / Description* classes, under the
+    current and the legacy module path (dataloading/__init__.py:8-10); io.load_scenes restores them onto data.py."""
+    from text2pos_amd import data as D, io as IO
+    assert "datapreparation" not in sys.modules
+    g = np.load(os.path.join(golden_dir, "scene_expect.npz"))
+    sc = IO.load_scenes(os.path.join(golden_dir, "scene"), [scene])
+    assert [c.id for c in sc.all_cells] == list(g["cell_ids"]) and [len(c.objects) for c in sc.all_cells] == list(g["n_objects"])
+    assert all(isinstance(c, D.Cell) and isinstance(c.objects[0], D.Object3d) for c in sc.all_cells)
+    assert np.allclose(np.array([c.get_center() for c in sc.all_cells]), g["centers"])
+    o = sc.all_cells[0].objects[0]
+    assert np.allclose(o.get_center(), g["obj0_center"]) and o.get_color_text() == str(g["obj0_color"])
+    assert np.allclose(np.array([p.pose_w for p in sc.all_poses]), g["pose_w"]) and [p.cell_id for p in sc.all_poses] == list(g["pose_cell"])
+    assert sc.hint_descriptions[0][0] == str(g["hint0"]) and len(sc.hint_descriptions[0]) == 6
+    assert np.array_equal(np.array([[d.is_matched for d in p.descriptions] for p in sc.all_poses]), g["matched"])
+    assert "pose" in sc.get_known_words() and "pad" in sc.get_known_classes()
+    assert sc.texts[0].count("The pose is") == 6
+
+
+def test_whole_module_checkpoint_converts_without_its_classes(tmp_path):
+    """A `torch.save(model)` pickle whose classes are not importable (the reference's models.*, torch_geometric.*) still
+    yields its state_dict (evaluation/pipeline.py:313-314 loads such files)."""
+    import types
+    from text2pos_amd import io as IO
+    code = """
+import torch.nn as nn
+class PointConv(nn.Module):
+    def __init__(self, local_nn):
+        super().__init__(); self.local_nn = local_nn
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = PointConv(nn.Sequential(nn.Sequential(nn.Linear(6, 8), nn.BatchNorm1d(8), nn.ReLU())))
+        self.lin = nn.Linear(8, 4)
+        self.args = {'embed_dim': 4}
+"""
+    for name in ("models", "models.cell_retrieval"):
+        sys.modules[name] = types.ModuleType(name)
+    try:
+        exec(code, sys.modules["models.cell_retrieval"].__dict__)
+        Net = sys.modules["models.cell_retrieval"].Net
+        Net.__module__ = "models.cell_retrieval"
+        sys.modules["models.cell_retrieval"].PointConv.__module__ = "models.cell_retrieval"
+        torch.manual_seed(3)
+        net = Net()
+        want = {k: v.clone() for k, v in net.state_dict().items()}
+        torch.save(net, tmp_path / "whole.pth")
+        torch.save(net.state_dict(), tmp_path / "sd.pth")
+    finally:
+        del sys.modules["models.cell_retrieval"], sys.modules["models"]
+    for f in ("whole.pth", "sd.pth"):
+        got = IO.load_reference_checkpoint(str(tmp_path / f))
+        assert list(got.keys()) == list(want.keys())
+        assert all(torch.equal(got[k], want[k]) for k in want)

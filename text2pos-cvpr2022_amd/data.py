@@ -15,6 +15,10 @@ COLORS = np.array([[47.2579917, 49.75368454, 42.4153065], [136.32696657, 136.952
                    [87.49822126, 91.69058836, 80.14558512], [213.91030679, 216.25033052, 207.24611073],
                    [110.39218852, 112.91977458, 103.68638249], [27.47505158, 28.43996795, 25.16840296],
                    [66.65951839, 70.22342483, 60.20395996], [171.00852191, 170.05737735, 155.00130334]]) / 255.0
+# class names of KITTI360Pose in CLASS_TO_INDEX order (datapreparation/kitti360pose/utils.py:48-71)
+KNOWN_CLASSES = ["building", "pole", "traffic light", "traffic sign", "garage", "stop", "smallpole", "lamp", "trash bin",
+                 "vending machine", "box", "road", "sidewalk", "parking", "wall", "fence", "guard rail", "bridge", "tunnel",
+                 "vegetation", "terrain", "pad"]
 COLOR_NAMES = ["dark-green", "gray", "gray-green", "bright-gray", "gray", "black", "green", "beige"]
 CLASS_NAMES = ["building", "pole", "traffic light", "traffic sign", "garage", "stop", "smallpole", "lamp", "trash bin",
                "vending machine", "box", "road", "sidewalk", "parking", "wall", "fence", "guard rail", "bridge", "tunnel",
@@ -58,6 +62,29 @@ class Pose:
     def __init__(self, pose_in_cell, pose_w, cell_id, scene_name, descriptions=None, described_by=None):
         self.pose, self.pose_w, self.cell_id = pose_in_cell, np.asarray(pose_w), cell_id
         self.scene_name, self.descriptions, self.described_by = scene_name, descriptions, described_by
+
+    def __repr__(self):
+        return f"Pose at {self.pose_w} in {self.cell_id}"
+
+
+class DescriptionPoseCell:
+    """Attribute container of datapreparation/kitti360pose/imports.py:86-115 (unpickled as is)."""
+
+    def __repr__(self):
+        return f"Pose is {self.direction} of a {self.object_color_text} {self.object_label}"
+
+
+class DescriptionBestCell:
+    """One hint of a pose in the context of its best cell (datapreparation/kitti360pose/imports.py:119-176): the
+    coarse / fine stages read `direction`, `object_color_text`, `object_label` (hint sentence) and `object_id`,
+    `best_offset_center`, `is_matched` (training only)."""
+
+    def __init__(self, direction=None, object_color_text=None, object_label=None, object_id=-1, is_matched=False):
+        self.direction, self.object_color_text, self.object_label = direction, object_color_text, object_label
+        self.object_id, self.is_matched = object_id, is_matched
+
+    def __repr__(self):
+        return f"Pose is {self.direction} of a {self.object_color_text} {self.object_label}"
 
 
 class Data:

@@ -14,6 +14,7 @@ from copy import copy
 from typing import Dict, List, Sequence
 
 import numpy as np
+import torch
 
 from .retrieval import retrieve_topk
 
@@ -136,7 +137,8 @@ def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Seque
                 objects.append(objs)
                 hints.append(h)
                 points.append(batch_object_points(objs, transform))
-        out = model(objects, hints, points)
+        with torch.no_grad():  # evaluation/pipeline.py:171
+            out = model(objects, hints, points)
         m0 = np.asarray(out.matches0.detach().cpu() if hasattr(out.matches0, "detach") else out.matches0)
         off = np.asarray(out.offsets.detach().cpu() if hasattr(out.offsets, "detach") else out.offsets)
         for i, objs in enumerate(objects):

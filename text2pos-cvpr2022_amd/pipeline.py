@@ -1,0 +1,119 @@
+"""End-to-end evaluation: coarse retrieval, then fine localisation of every query against its top-k cells
+(the reference's evaluation/pipeline.py:60-137 run_coarse, :172-279 run_fine, :282-342 main), on the MI355X path.
+
+    python -m text2pos_amd.pipeline --base_path ./data/k360_30-10_scG_pd10_pc4_spY_all/ \\
+        --path_coarse ./checkpoints/coarse.pth --path_fine ./checkpoints/fine.pth [--scenes 2013_05_28_drive_0010_sync ...]
+
+Checkpoints are the reference's whole-module pickles (io.load_reference_checkpoint) or plain state_dicts.
+BASELINE.json configs[4]; one process per GPU shards the cells exactly like bench.py (distributed.sharded_retrieval).
+"""
+import argparse
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import data as D
+from . import evaluation as E
+from . import io as IO
+from .retrieval import retrieve_topk
+
+# validation scenes of KITTI360Pose (datapreparation/kitti360pose/utils.py: SCENE_NAMES_VAL)
+SCENE_NAMES_VAL = ["2013_05_28_drive_0010_sync"]
+
+
+def default_transform(n_pts: int = 256, seed: Optional[int] = None):
+    """evaluation/pipeline.py:290-293: FixedPoints(pointnet_numpoints) + NormalizeScale (no augmentation)."""
+    return D.Compose([D.FixedPoints(n_pts, generator=np.random.default_rng(seed)), D.NormalizeScale()])
+
+
+@torch.no_grad()
+def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], threshs: Sequence[int], cells_per_call: int = 64,
+               texts_per_call: int = 1024):
+    """Encode every cell and every query, rank in float64, report hit@k / close-by@k and recall within the thresholds
+    when the retrieved cell's centre is the estimate.  Returns (retrievals, accuracies dict)."""
+    cells, poses = scenes.all_cells, scenes.all_poses
+    enc = []
+    for lo in range(0, len(cells), cells_per_call):
+        chunk = cells[lo: lo + cells_per_call]
+        objects = [list(c.objects) for c in chunk]
+        enc.append(model.encode_objects(objects, [D.batch_object_points(o, transform) for o in objects]))
+    cell_enc = torch.cat(enc)
+    texts = scenes.texts
+    text_enc = torch.cat([model.encode_text(texts[lo: lo + texts_per_call]) for lo in range(0, len(texts), texts_per_call)])
+    kmax = int(max(top_k))
+    idx, _ = retrieve_topk(cell_enc, text_enc, kmax)
+    idx = np.asarray(idx.cpu()) if hasattr(idx, "cpu") else np.asarray(idx)
+    db_ids = [c.id for c in cells]
+    centers = np.array([c.get_center()[0:2] for c in cells])
+    cell_size = float(cells[0].cell_size)
+    acc, acc_close, _ = E.retrieval_accuracies(idx, db_ids, [p.cell_id for p in poses],
+                                               np.array([p.pose_w for p in poses]), centers, cell_size, list(top_k))
+    retrievals = [[db_ids[j] for j in row[:kmax]] for row in idx]
+    loc = E.localisation_accuracies(poses, retrievals, scenes.cells_dict, list(top_k), list(threshs))
+    return retrievals, dict(hit=acc, close=acc_close, localisation=loc)
+
+
+@torch.no_grad()
+def evaluate(model_coarse, model_fine, scenes: IO.Scenes, transform, top_k=(1, 5, 10), threshs=(5, 10, 15), pad_size=16,
+             queries_per_call: int = 64) -> Dict[str, object]:
+    retrievals, out = run_coarse(model_coarse, scenes, transform, top_k, threshs)
+    out["retrievals"] = retrievals
+    if model_fine is not None:
+        mean, off, conf = E.run_fine(model_fine, scenes.all_poses, scenes.cells_dict, retrievals, transform, pad_size,
+                                     list(top_k), list(threshs), queries_per_call)
+        out.update(fine_mean=mean, fine_offset=off, fine_mean_conf=conf)
+    return out
+
+
+def _model_args(embed_dim, num_layers=6, sinkhorn_iters=50, use_features=("class", "color", "position")):
+    return SimpleNamespace(embed_dim=embed_dim, use_features=list(use_features), variation=0, class_embed=False,
+                           color_embed=False, pointnet_layers=3, pointnet_variation=0, pointnet_numpoints=256,
+                           pointnet_path=None, pointnet_freeze=False, pointnet_features=2, num_layers=num_layers,
+                           sinkhorn_iters=sinkhorn_iters)
+
+
+def main(argv: Optional[List[str]] = None):
+    from . import CellRetrievalNetwork, SuperGlueMatch
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--base_path", required=True)
+    ap.add_argument("--path_coarse", required=True)
+    ap.add_argument("--path_fine", default=None)
+    ap.add_argument("--scenes", nargs="*", default=SCENE_NAMES_VAL)
+    ap.add_argument("--top_k", type=int, nargs="+", default=[1, 5, 10])
+    ap.add_argument("--threshs", type=int, nargs="+", default=[5, 10, 15])
+    ap.add_argument("--pad_size", type=int, default=16)
+    ap.add_argument("--coarse_embed_dim", type=int, default=256)
+    ap.add_argument("--fine_embed_dim", type=int, default=128)
+    ap.add_argument("--fine_num_layers", type=int, default=6)
+    ap.add_argument("--sinkhorn_iters", type=int, default=50)
+    ap.add_argument("--use_features", nargs="+", default=["class", "color", "position"])
+    ap.add_argument("--seed", type=int, default=0, help="seed of the T.FixedPoints draw")
+    a = ap.parse_args(argv)
+    scenes = IO.load_scenes(a.base_path, a.scenes)
+    print(f"{len(scenes.all_cells)} cells, {len(scenes.all_poses)} poses from {a.scenes}")
+    words, classes = scenes.get_known_words(), scenes.get_known_classes()
+    dev = torch.device("cuda", 0)
+    coarse = CellRetrievalNetwork(classes, D.COLOR_NAMES, words, _model_args(a.coarse_embed_dim, use_features=a.use_features))
+    coarse.load_state_dict(IO.load_reference_checkpoint(a.path_coarse))
+    coarse = coarse.to(dev).eval()
+    fine = None
+    if a.path_fine:
+        fine = SuperGlueMatch(classes, D.COLOR_NAMES, words, _model_args(a.fine_embed_dim, a.fine_num_layers, a.sinkhorn_iters,
+                                                                          a.use_features))
+        fine.load_state_dict(IO.load_reference_checkpoint(a.path_fine))
+        fine = fine.to(dev).eval()
+    out = evaluate(coarse, fine, scenes, default_transform(256, a.seed), a.top_k, a.threshs, a.pad_size)
+    print("Retrieval accuracies (hit@k):", out["hit"], " close-by@k:", out["close"])
+    print("Coarse (cell centre):")
+    E.print_accuracies(out["localisation"])
+    if fine is not None:
+        for name in ("fine_mean", "fine_offset", "fine_mean_conf"):
+            print(name + ":")
+            E.print_accuracies(out[name])
+    return out
+
+
+if __name__ == "__main__":
+    main()
