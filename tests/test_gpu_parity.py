@@ -333,6 +333,40 @@ def test_encode_cells_chunking_is_invisible(hip_model):
     assert torch.equal(one, many)
 
 
+def test_encode_cells_full_size_properties(hip_model):
+    """Size-independent properties at a BASELINE-sized slice (3,000 cells = 48 k objects, several internal chunks and
+    every workgroup of the persistent kernels busy): unit norms, bit-determinism, chunking invisible, cells independent
+    of their neighbours in the batch (any permutation of the cells permutes the rows, bit for bit), and a
+    world-size-4 shard of the batch reproduces its rows."""
+    from text2pos_amd import distributed as TD, synthetic as S
+    n_cells = 3000
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(20220002, n_cells)
+    args = _to_dev(xyz, rgb, center, mean_rgb)
+    with torch.no_grad():
+        a = hip_model.encode_objects_packed(*args, cell_ptr)
+        b = hip_model.encode_objects_packed(*args, cell_ptr, chunk_objects=5000)
+        c = hip_model.encode_objects_packed(*args, cell_ptr)
+    assert torch.equal(a, c) and torch.equal(a, b)
+    assert (a.norm(dim=1) - 1.0).abs().max().item() < 1e-5 and bool(torch.isfinite(a).all())
+    # permutation of the cells
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(n_cells)
+    sizes = (cell_ptr[1:] - cell_ptr[:-1])[perm]
+    new_ptr = np.zeros(n_cells + 1, dtype=np.int32)
+    new_ptr[1:] = np.cumsum(sizes)
+    obj_idx = np.concatenate([np.arange(cell_ptr[p], cell_ptr[p + 1]) for p in perm])
+    oi = torch.from_numpy(obj_idx).to(args[0].device)
+    with torch.no_grad():
+        p = hip_model.encode_objects_packed(*[t[oi].contiguous() for t in args], new_ptr)
+    assert torch.equal(p, a[torch.from_numpy(perm).to(a.device)])
+    # a shard of the batch (what rank 2 of 4 encodes in bench.py) equals the corresponding rows
+    lo, hi = TD.shard_range(n_cells, 2, 4)
+    o_lo, o_hi = int(cell_ptr[lo]), int(cell_ptr[hi])
+    with torch.no_grad():
+        s_ = hip_model.encode_objects_packed(*[t[o_lo:o_hi].contiguous() for t in args], cell_ptr[lo: hi + 1] - o_lo)
+    assert torch.equal(s_, a[lo:hi])
+
+
 def test_train_mode_and_grad_fail_loudly(hip_model):
     hip_model.train()
     try:
