@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 4
+#define T2P_ABI_VERSION 6
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -101,6 +101,15 @@ typedef struct t2p_cell_weights {
      * sa_b2_x3[l] = s b2; the kernel divides by s when it drains an object (packing.py::pack_f16x3_scaled). */
     const float* sa_b2_x3[3];
     float sa_w2_scale[3];
+    /* Scaled split images of the dense layers behind the trunk, for the LDS-tiled f16x3 GEMM
+     * (packing.py::pack_gemm_x3): uint16 [2 planes hi,lo][N][K rounded up to 32] holding s w[k][n], lo = s w - hi. */
+    const void* lin1_x3;
+    const void* lin2_x3;
+    const void* merge_x3;
+    const void* pn_x3;   /* mlp_pointnet */
+    const void* g_wp_x3; /* DynamicEdgeConv layer-1 tables P, Q */
+    const void* g_wq_x3;
+    float lin1_scale, lin2_scale, merge_scale, pn_scale, g_wp_scale, g_wq_scale;
     const void* sa_w1_x3[3]; /* levels 1 and 2 only (level 0 has K = 6 and runs on the VALU); [0] is ignored */
     const void* ga_w1_x3;
     /* ObjectEncoder.class_embedding / color_embedding (object_encoder.py:31-38), used by the --class_embed /

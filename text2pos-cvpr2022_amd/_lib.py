@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 4
+ABI_VERSION = 6
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -23,6 +23,9 @@ class CellWeights(C.Structure):
               "merge_w", "merge_b", "g_wp", "g_bp", "g_wq", "g_w2", "g_b2", "lin_w1", "lin_b1", "lin_w2", "lin_b2"])
     _fields_ = ([(n, c_void * 3) for n in _names[0]] + [(n, c_void) for n in _names[1]] +
                 [("sa_w2_x3", c_void * 3), ("ga_w2_x3", c_void), ("sa_b2_x3", c_void * 3), ("sa_w2_scale", C.c_float * 3),
+                 ("lin1_x3", c_void), ("lin2_x3", c_void), ("merge_x3", c_void), ("pn_x3", c_void), ("g_wp_x3", c_void),
+                 ("g_wq_x3", c_void), ("lin1_scale", C.c_float), ("lin2_scale", C.c_float), ("merge_scale", C.c_float),
+                 ("pn_scale", C.c_float), ("g_wp_scale", C.c_float), ("g_wq_scale", C.c_float),
                  ("sa_w1_x3", c_void * 3), ("ga_w1_x3", c_void),
                  ("class_embedding", c_void), ("color_embedding", c_void)])
 

@@ -288,8 +288,13 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         T2P_TRY(launch_ws(WS_DENSE_GROUPMAX, 512, 1024, q, st));
     }
     // ---- PointNet2 heads + ObjectEncoder ------------------------------------------------------------------------
-    T2P_TRY(launch_gemm(ws.f0, 1024, W.lin1_w, W.lin1_b, ws.f1, 512, 0, n, 1024, 512, 1, st));
-    T2P_TRY(launch_gemm(ws.f1, 512, W.lin2_w, W.lin2_b, ws.f2, 256, 0, n, 512, 256, 1, st));
+    if (cfg.precision == 1 && W.lin1_x3 && W.lin2_x3) {
+        T2P_TRY(launch_gemm_x3(ws.f0, 1024, W.lin1_x3, W.lin1_scale, W.lin1_b, ws.f1, 512, 0, n, 1024, 512, 1, st));
+        T2P_TRY(launch_gemm_x3(ws.f1, 512, W.lin2_x3, W.lin2_scale, W.lin2_b, ws.f2, 256, 0, n, 512, 256, 1, st));
+    } else {
+        T2P_TRY(launch_gemm(ws.f0, 1024, W.lin1_w, W.lin1_b, ws.f1, 512, 0, n, 1024, 512, 1, st));
+        T2P_TRY(launch_gemm(ws.f1, 512, W.lin2_w, W.lin2_b, ws.f2, 256, 0, n, 512, 256, 1, st));
+    }
     }  // run_pointnet
     const int nfeat = (cfg.use_class ? 1 : 0) + (cfg.use_color ? 1 : 0) + (cfg.use_position ? 1 : 0);
     const int ldcat = nfeat * D;
@@ -301,7 +306,10 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         const float* fin = cfg.pointnet_features == 0 ? ws.f0 : (cfg.pointnet_features == 1 ? ws.f1 : ws.f2);
         const int kin = cfg.pointnet_features == 0 ? 1024 : (cfg.pointnet_features == 1 ? 512 : 256);
         // mlp_pointnet into P (scratch), then F.normalize into the concat slot
-        T2P_TRY(launch_gemm(fin, kin, W.pn_w, W.pn_b, ws.P, D, 0, n, kin, D, 1, st));
+        if (cfg.precision == 1 && W.pn_x3)
+            T2P_TRY(launch_gemm_x3(fin, kin, W.pn_x3, W.pn_scale, W.pn_b, ws.P, D, 0, n, kin, D, 1, st));
+        else
+            T2P_TRY(launch_gemm(fin, kin, W.pn_w, W.pn_b, ws.P, D, 0, n, kin, D, 1, st));
         T2P_TRY(launch_rownorm(ws.P, D, n, D, ws.cat, ldcat, slot * D, st));
         slot++;
     }
@@ -318,7 +326,10 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     }
     const float* emb = ws.cat;  // single feature: embeddings[0] is returned un-merged (object_encoder.py:137-140)
     if (nfeat > 1) {
-        T2P_TRY(launch_gemm(ws.cat, ldcat, W.merge_w, W.merge_b, ws.emb, D, 0, n, ldcat, D, 1, st));
+        if (cfg.precision == 1 && W.merge_x3)
+            T2P_TRY(launch_gemm_x3(ws.cat, ldcat, W.merge_x3, W.merge_scale, W.merge_b, ws.emb, D, 0, n, ldcat, D, 1, st));
+        else
+            T2P_TRY(launch_gemm(ws.cat, ldcat, W.merge_w, W.merge_b, ws.emb, D, 0, n, ldcat, D, 1, st));
         emb = ws.emb;
     }
     if (cfg.objects_only) {  // the fine stage consumes ObjectEncoder.forward's output as is
@@ -327,8 +338,13 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     }
     // ---- cell head: normalize, DynamicEdgeConv(k, max), global max pool, lin, normalize -------------------------
     T2P_TRY(launch_rownorm(emb, D, n, D, ws.embn, D, 0, st));
-    T2P_TRY(launch_gemm(ws.embn, D, W.g_wp, W.g_bp, ws.P, D, 0, n, D, D, 0, st));
-    T2P_TRY(launch_gemm(ws.embn, D, W.g_wq, nullptr, ws.Q, D, 0, n, D, D, 0, st));
+    if (cfg.precision == 1 && W.g_wp_x3 && W.g_wq_x3) {
+        T2P_TRY(launch_gemm_x3(ws.embn, D, W.g_wp_x3, W.g_wp_scale, W.g_bp, ws.P, D, 0, n, D, D, 0, st));
+        T2P_TRY(launch_gemm_x3(ws.embn, D, W.g_wq_x3, W.g_wq_scale, nullptr, ws.Q, D, 0, n, D, D, 0, st));
+    } else {
+        T2P_TRY(launch_gemm(ws.embn, D, W.g_wp, W.g_bp, ws.P, D, 0, n, D, D, 0, st));
+        T2P_TRY(launch_gemm(ws.embn, D, W.g_wq, nullptr, ws.Q, D, 0, n, D, D, 0, st));
+    }
     T2P_TRY(launch_knn(ws.embn, D, ws.seg_ptr, (int)nb, max_cell, cfg.knn_k, ws.knn, st));
     {
         WsParams p{};

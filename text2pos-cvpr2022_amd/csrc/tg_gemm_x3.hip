@@ -1,0 +1,179 @@
+// LDS-tiled f16x3 GEMM with fused bias / ReLU epilogue for the big dense layers behind the PointNet++ trunk:
+//   lin1 (1024 -> 512), lin2 (512 -> 256)   models/pointcloud/pointnet2.py:89-90
+//   mlp_merge (3D -> D)                       models/object_encoder.py:137-138
+// C[M,N] = act(A[M,K] W[K,N] + bias) with A fp32 in HBM and W given as the scaled split image of
+// packing.py::pack_gemm_x3: w' = s w (s a power of two), hi = fp16(w'), lo = fp16(w' - hi), stored [plane][n][k]
+// (k contiguous) so that a 16-byte load is one MFMA B-operand fragment.  A is split on the fly (hi = fp16 toward zero,
+// lo = fp16(a - hi)); hi.hi + hi.lo + lo.hi share one fp32 accumulator (the matrix cores honour fp16 denormals), the
+// epilogue divides by s.  Same error class as an fp32 fma chain (~5e-7), 16/3 x the fp32-MFMA rate.
+// 128 x 128 x 32 tile, 4 waves x (2 x 2) v_mfma_f32_32x32x16_f16 blocks, double-buffered LDS, register-prefetched loads.
+#include "t2p_common.h"
+
+namespace t2p {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDT = BK + 8;               // halves per LDS row: 80 B keeps ds_read_b128 conflict-free
+constexpr int PLANE = BM * LDT;           // halves per plane of one operand tile
+constexpr size_t kLds = (size_t)2 /*buffers*/ * 2 /*A, W*/ * 2 /*hi, lo*/ * PLANE * sizeof(_Float16);
+
+template <int SEL>
+__device__ __forceinline__ float sub_half(float v, fp16x2 h) {
+    float r;
+    if constexpr (SEL == 0)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    else
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A, int lda, const _Float16* __restrict__ Wx,
+                                                    int kp /*padded K of the image*/, float inv_scale,
+                                                    const float* __restrict__ bias, float* C, int ldc, int c0, int64_t M,
+                                                    int K, int N, int relu, const float* R, int ldr) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
+    // buffer b: [A hi | A lo | W hi | W lo], each [128][LDT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l31 = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const _Float16* Whi = Wx;
+    const _Float16* Wlo = Wx + (size_t)N * kp;
+
+    // staging assignment: A: thread -> row tid/2, 16 consecutive k (4 x f32x4); W: thread -> column n = tid/2,
+    // 16 consecutive k of each plane (2 x 16 B per plane)
+    const int s_row = tid >> 1, s_k = (tid & 1) * 16;
+    const bool a_ok = (m0 + s_row) < M;
+    const bool w_ok = (n0 + s_row) < N;
+    const float* a_ptr = A + (m0 + s_row) * (int64_t)lda + s_k;
+    const _Float16* wh_ptr = Whi + (size_t)(n0 + s_row) * kp + s_k;
+    const _Float16* wl_ptr = Wlo + (size_t)(n0 + s_row) * kp + s_k;
+    f32x4 ra[4];
+    uint4 rwh[2], rwl[2];
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = k0 + s_k + 4 * i;
+            ra[i] = (a_ok && k < K) ? *(const f32x4*)(a_ptr + k0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            rwh[i] = w_ok ? *(const uint4*)(wh_ptr + k0 + 8 * i) : uint4{0, 0, 0, 0};   // the image is zero-padded in k
+            rwl[i] = w_ok ? *(const uint4*)(wl_ptr + k0 + 8 * i) : uint4{0, 0, 0, 0};
+        }
+    };
+    auto store_tile = [&](int buf) {
+        _Float16* base = sm + (size_t)buf * 4 * PLANE;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const f32x4 v = ra[i];
+            const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+            const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(v[0], h01), sub_half<1>(v[1], h01));
+            const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(v[2], h23), sub_half<1>(v[3], h23));
+            uint2 ph, pl;
+            ph.x = __builtin_bit_cast(uint32_t, h01); ph.y = __builtin_bit_cast(uint32_t, h23);
+            pl.x = __builtin_bit_cast(uint32_t, l01); pl.y = __builtin_bit_cast(uint32_t, l23);
+            *(uint2*)(base + s_row * LDT + s_k + 4 * i) = ph;
+            *(uint2*)(base + PLANE + s_row * LDT + s_k + 4 * i) = pl;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            *(uint4*)(base + 2 * PLANE + s_row * LDT + s_k + 8 * i) = rwh[i];
+            *(uint4*)(base + 3 * PLANE + s_row * LDT + s_k + 8 * i) = rwl[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
+        const bool more = k0 + BK < K;
+        if (more) load_tile(k0 + BK);
+        const _Float16* base = sm + (size_t)buf * 4 * PLANE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) {
+            half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const _Float16* p = base + (wr * 64 + i * 32 + l31) * LDT + ks * 16 + h * 8;
+                a_hi[i] = *(const half8*)p;
+                a_lo[i] = *(const half8*)(p + PLANE);
+                const _Float16* q = base + 2 * PLANE + (wc * 64 + i * 32 + l31) * LDT + ks * 16 + h * 8;
+                b_hi[i] = *(const half8*)q;
+                b_lo[i] = *(const half8*)(q + PLANE);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int col = n0 + wc * 64 + j * 32 + l31;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int64_t row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < M) {
+                    float v = fmaf(acc[i][j][e], inv_scale, bv);
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (R) v += R[row * (int64_t)ldr + col];
+                    C[row * (int64_t)ldc + c0 + col] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Wx: image of pack_gemm_x3 ([2][N][kp] fp16, kp = K rounded up to 32, zero padded), scale = its power-of-two factor.
+int launch_gemm_x3(const float* A, int lda, const void* Wx, float scale, const float* bias, float* C, int ldc, int c0,
+                   int64_t M, int K, int N, int relu, hipStream_t st, const float* resid, int ldr) {
+    T2P_CHECK_ARG(K % 4 == 0 && N % 8 == 0 && lda % 4 == 0 && scale > 0.f, "gemm_x3: K=%d %% 4, N=%d %% 8, lda=%d %% 4", K, N, lda);
+    T2P_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)Wx) & 15) == 0, "gemm_x3: A and W must be 16-byte aligned");
+    if (M == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        if (e != hipSuccess) {
+            set_error("gemm_x3: cannot reserve %zu B of LDS: %s", kLds, hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const int kp = (K + 31) / 32 * 32;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+    ProfScope ps_("tg_gemm_x3", st);
+    hipLaunchKernelGGL(k_gemm_x3, grid, dim3(256), kLds, st, A, lda, (const _Float16*)Wx, kp, 1.0f / scale, bias, C, ldc, c0,
+                       M, K, N, relu, resid, ldr);
+    T2P_CHECK_LAUNCH("gemm_x3");
+    return 0;
+}
+
+}  // namespace t2p

@@ -179,6 +179,12 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
             _need(t, "sa_b2_x3", torch.float32)
         w.sa_b2_x3 = (C.c_void_p * 3)(*[t.data_ptr() for t in packed["sa_b2_x3"]])
         w.sa_w2_scale = (C.c_float * 3)(*[float(v) for v in packed["sa_w2_scale"]])
+    for name in ("lin1", "lin2", "merge", "pn", "g_wp", "g_wq"):
+        img = packed.get(name + "_x3")
+        if img is not None:
+            _need(img, name + "_x3", torch.int16)
+            setattr(w, name + "_x3", img.data_ptr())
+            setattr(w, name + "_scale", float(packed[name + "_scale"]))
     for name in ("ga_w1_x3", "ga_w2_x3"):
         g = packed.get(name)
         if g is not None:

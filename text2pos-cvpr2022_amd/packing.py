@@ -77,6 +77,19 @@ def pack_f16x3_scaled(w_kmajor: torch.Tensor, scale: float) -> torch.Tensor:
     return torch.stack(planes).view(torch.int16).contiguous()
 
 
+def pack_gemm_x3(w_kmajor: torch.Tensor, scale: float) -> torch.Tensor:
+    """fp32 [K][N] k-major -> int16 [2][N][Kp] (Kp = K rounded up to 32, zero padded): the scaled split w' = scale w,
+    hi = fp16(w'), lo = fp16(w' - hi), n-major with k contiguous -- a 16-byte load is one MFMA B-operand fragment of
+    csrc/tg_gemm_x3.hip."""
+    k, n = w_kmajor.shape
+    kp = (k + 31) // 32 * 32
+    w = torch.zeros((n, kp), dtype=torch.float64)
+    w[:, :k] = w_kmajor.detach().double().cpu().t() * scale
+    hi = w.to(torch.float16)
+    lo = (w - hi.double()).to(torch.float16)
+    return torch.stack([hi, lo]).view(torch.int16).contiguous()
+
+
 def pack_cell_weights(model, device) -> Dict[str, object]:
     """model: CellRetrievalNetwork or SuperGlueMatch (this package; the latter has no cell head).  Returns name -> fp32
     device tensor(s) for ops.make_cell_weights."""
@@ -105,8 +118,13 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
     for name, lin in (("lin1", pn.lin1), ("lin2", pn.lin2)):
         p[name + "_w"] = kmajor(lin.weight.detach().double()).to(device)
         p[name + "_b"] = f32(lin.bias.detach().double()).to(device)
+    for name in ("lin1", "lin2"):
+        sc = f16x3_scale(p[name + "_w"])
+        p[name + "_scale"], p[name + "_x3"] = sc, pack_gemm_x3(p[name + "_w"], sc).to(device)
     w, b = fold_linear_bn(oe.mlp_pointnet[0])
     p.update(pn_w=kmajor(w).to(device), pn_b=f32(b).to(device))
+    p["pn_scale"] = f16x3_scale(p["pn_w"])
+    p["pn_x3"] = pack_gemm_x3(p["pn_w"], p["pn_scale"]).to(device)
     for pre, enc in (("col", oe.color_encoder), ("pos", oe.pos_encoder)):
         w1, b1 = fold_linear_bn(enc[0])
         w2, b2 = fold_linear_bn(enc[1])
@@ -114,6 +132,8 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
         p[pre + "_w2"], p[pre + "_b2"] = kmajor(w2).to(device), f32(b2).to(device)
     w, b = fold_linear_bn(oe.mlp_merge[0])
     p.update(merge_w=kmajor(w).to(device), merge_b=f32(b).to(device))
+    p["merge_scale"] = f16x3_scale(p["merge_w"])
+    p["merge_x3"] = pack_gemm_x3(p["merge_w"], p["merge_scale"]).to(device)
     p.update(class_embedding=f32(oe.class_embedding.weight.detach()).to(device),
              color_embedding=f32(oe.color_embedding.weight.detach()).to(device))
     if not hasattr(model, "graph1"):  # fine stage: ObjectEncoder only
@@ -124,6 +144,9 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
     w2, b2 = fold_linear_bn(model.graph1.nn[1])
     p.update(g_wp=kmajor(w1[:, :d] - w1[:, d:]).to(device), g_bp=f32(b1).to(device), g_wq=kmajor(w1[:, d:]).to(device),
              g_w2=kmajor(w2).to(device), g_b2=f32(b2).to(device))
+    for name in ("g_wp", "g_wq"):
+        p[name + "_scale"] = f16x3_scale(p[name])
+        p[name + "_x3"] = pack_gemm_x3(p[name], p[name + "_scale"]).to(device)
     w1, b1 = fold_linear_bn(model.lin[0])
     w2, b2 = fold_linear_bn(model.lin[1])
     p.update(lin_w1=kmajor(w1).to(device), lin_b1=f32(b1).to(device), lin_w2=kmajor(w2).to(device),
