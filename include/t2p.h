@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 6
+#define T2P_ABI_VERSION 7
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -207,6 +207,10 @@ typedef struct t2p_match_weights {
     const float *wf, *bf;                                   /* final_proj [D][D], [D] */
     float bin_score;
     const float *wo1, *bo1, *wo2, *bo2;                     /* mlp_offsets: [D][D/2], [D/2], [D/2][2], [2] */
+    /* Optional scaled split images (packing.py::pack_gemm_x3, one [2][N][Kp] image per layer, layers back to back) of
+     * the GNN / final_proj matrices for the f16x3 GEMM; NULL = fp32 MFMA.  One power-of-two scale per matrix family. */
+    const void *wqkv_x3, *wm_x3, *w1_x3, *w2_x3, *wf_x3;
+    float scale_qkv, scale_m, scale_1, scale_2, scale_f;
 } t2p_match_weights;
 
 size_t t2p_match_workspace_bytes(int64_t batch, int32_t n_obj, int32_t n_hints, int32_t embed_dim);

@@ -532,9 +532,9 @@ def test_fine_model_object_list_entry_point(fine_pair_gpu):
     assert torch.equal(a.P, b.P) and torch.equal(a.matches0, b.matches0) and torch.equal(a.offsets, b.offsets)
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 @pytest.mark.parametrize("b,m,n,d,layers", [(7, 9, 4, 64, 1), (1, 16, 6, 256, 0), (33, 3, 11, 128, 2)])
-def test_match_other_shapes_vs_oracle(b, m, n, d, layers):
+def test_match_other_shapes_vs_oracle(b, m, n, d, layers, precision):
     """t2p_match at other token counts / widths / depths (incl. no GNN at all, models/superglue.py:205-208) vs the oracle."""
     import weights as W
     import text2pos_amd as t2p
@@ -559,7 +559,7 @@ def test_match_other_shapes_vs_oracle(b, m, n, d, layers):
     d1 /= np.linalg.norm(d1, axis=-1, keepdims=True)
     with torch.no_grad():
         want = sg(torch.from_numpy(d0), torch.from_numpy(d1))
-    out = ops.match(*_to_dev(d0, d1), ops.make_match_weights(packing.pack_match_weights(h, "cuda:0")), 20, 0.2)
+    out = ops.match(*_to_dev(d0, d1), ops.make_match_weights(packing.pack_match_weights(h, "cuda:0", precision)), 20, 0.2)
     assert (out["P"].cpu() - want["P"]).abs().max().item() < TOL
     assert torch.equal(out["matches0"].cpu(), want["matches0"]) and torch.equal(out["matches1"].cpu(), want["matches1"])
     assert (out["matching_scores0"].cpu() - want["matching_scores0"]).abs().max().item() < TOL

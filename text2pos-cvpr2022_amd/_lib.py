@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -47,7 +47,9 @@ class CellTrace(C.Structure):
 class MatchWeights(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("cross", c_void)] + \
                [(n, c_void) for n in ("wqkv", "bqkv", "wm", "bm", "w1", "b1", "w2", "b2", "wf", "bf")] + \
-               [("bin_score", C.c_float)] + [(n, c_void) for n in ("wo1", "bo1", "wo2", "bo2")]
+               [("bin_score", C.c_float)] + [(n, c_void) for n in ("wo1", "bo1", "wo2", "bo2")] + \
+               [(n, c_void) for n in ("wqkv_x3", "wm_x3", "w1_x3", "w2_x3", "wf_x3")] + \
+               [(n, C.c_float) for n in ("scale_qkv", "scale_m", "scale_1", "scale_2", "scale_f")]
 
 
 class TextWeights(C.Structure):

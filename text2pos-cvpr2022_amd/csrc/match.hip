@@ -296,17 +296,34 @@ int t2p_match(const float* desc0, const float* desc1, int64_t batch, int32_t n_o
         const float* b1 = w->b1 + (size_t)l * 2 * D;
         const float* w2 = w->w2 + (size_t)l * 2 * D * D;
         const float* b2 = w->b2 + (size_t)l * D;
-        T2P_TRY(launch_gemm(ws.cat, 2 * D, wqkv, bqkv, ws.qkv, 3 * D, 0, rows, D, 3 * D, 0, st));
+        const bool x3 = w->wqkv_x3 != nullptr;
+        // image sizes in halves: [2][N][Kp]
+        auto img = [&](const void* base, int k, int n) {
+            return (const void*)((const uint16_t*)base + (size_t)l * 2 * n * ((k + 31) / 32 * 32));
+        };
+        if (x3)
+            T2P_TRY(launch_gemm_x3(ws.cat, 2 * D, img(w->wqkv_x3, D, 3 * D), w->scale_qkv, bqkv, ws.qkv, 3 * D, 0, rows, D, 3 * D, 0, st));
+        else
+            T2P_TRY(launch_gemm(ws.cat, 2 * D, wqkv, bqkv, ws.qkv, 3 * D, 0, rows, D, 3 * D, 0, st));
         {
             ProfScope ps_("match_attn", st);
             hipLaunchKernelGGL(attn, dim3((unsigned)batch), dim3(256), lds_attn, st, ws.qkv, M, N, w->cross[l], ws.msg);
             T2P_CHECK_LAUNCH("match_attn");
         }
-        T2P_TRY(launch_gemm(ws.msg, D, wm, bm, ws.cat, 2 * D, D, rows, D, D, 0, st));                 // message -> CAT[:, D:]
-        T2P_TRY(launch_gemm(ws.cat, 2 * D, w1, b1, ws.hid, 2 * D, 0, rows, 2 * D, 2 * D, 1, st));      // Conv + BN + ReLU
-        T2P_TRY(launch_gemm(ws.hid, 2 * D, w2, b2, ws.cat, 2 * D, 0, rows, 2 * D, D, 0, st, ws.cat, 2 * D));  // X += delta
+        if (x3) {
+            T2P_TRY(launch_gemm_x3(ws.msg, D, img(w->wm_x3, D, D), w->scale_m, bm, ws.cat, 2 * D, D, rows, D, D, 0, st));
+            T2P_TRY(launch_gemm_x3(ws.cat, 2 * D, img(w->w1_x3, 2 * D, 2 * D), w->scale_1, b1, ws.hid, 2 * D, 0, rows, 2 * D, 2 * D, 1, st));
+            T2P_TRY(launch_gemm_x3(ws.hid, 2 * D, img(w->w2_x3, 2 * D, D), w->scale_2, b2, ws.cat, 2 * D, 0, rows, 2 * D, D, 0, st, ws.cat, 2 * D));
+        } else {
+            T2P_TRY(launch_gemm(ws.msg, D, wm, bm, ws.cat, 2 * D, D, rows, D, D, 0, st));                 // message -> CAT[:, D:]
+            T2P_TRY(launch_gemm(ws.cat, 2 * D, w1, b1, ws.hid, 2 * D, 0, rows, 2 * D, 2 * D, 1, st));      // Conv + BN + ReLU
+            T2P_TRY(launch_gemm(ws.hid, 2 * D, w2, b2, ws.cat, 2 * D, 0, rows, 2 * D, D, 0, st, ws.cat, 2 * D));  // X += delta
+        }
     }
-    T2P_TRY(launch_gemm(ws.cat, 2 * D, w->wf, w->bf, ws.md, D, 0, rows, D, D, 0, st));
+    if (w->wf_x3 != nullptr)
+        T2P_TRY(launch_gemm_x3(ws.cat, 2 * D, w->wf_x3, w->scale_f, w->bf, ws.md, D, 0, rows, D, D, 0, st));
+    else
+        T2P_TRY(launch_gemm(ws.cat, 2 * D, w->wf, w->bf, ws.md, D, 0, rows, D, D, 0, st));
     {
         const size_t lds = ((size_t)(M + 1) * (N + 1) + (M + 1) + (N + 1) + 2 * (M + N) + D / 2 + 8) * sizeof(float);
         ProfScope ps_("match_final", st);

@@ -300,6 +300,11 @@ def make_match_weights(packed: Dict[str, object]) -> L.MatchWeights:
         _need(t, name, torch.float32)
         setattr(w, name, t.data_ptr())
     w.bin_score = float(packed["bin_score"])
+    if packed.get("wqkv_x3") is not None:   # f16x3 images of the GNN matrices
+        for name, sc in (("wqkv", "qkv"), ("wm", "m"), ("w1", "1"), ("w2", "2"), ("wf", "f")):
+            _need(packed[name + "_x3"], name + "_x3", torch.int16)
+            setattr(w, name + "_x3", packed[name + "_x3"].data_ptr())
+            setattr(w, "scale_" + sc, float(packed["scale_" + sc]))
     w._keepalive = (cross, packed)
     return w
 

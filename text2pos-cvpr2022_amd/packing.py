@@ -154,7 +154,7 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
     return p
 
 
-def pack_match_weights(model, device) -> Dict[str, object]:
+def pack_match_weights(model, device, precision: str = "f16x3") -> Dict[str, object]:
     """model: SuperGlueMatch (this package).  Conv1d(k=1) weights [out, in, 1] -> k-major [in][out]; eval BatchNorm of
     AttentionalPropagation.mlp folded into its first conv (float64 on the host)."""
     sg = model.superglue
@@ -186,6 +186,13 @@ def pack_match_weights(model, device) -> Dict[str, object]:
     p.update(wo1=f32(l1.weight.detach().double().t()).to(device), bo1=f32(l1.bias.detach().double()).to(device),
              wo2=f32(l2.weight.detach().double().t()).to(device), bo2=f32(l2.bias.detach().double()).to(device))
     p["cross"] = [1 if n == "cross" else 0 for n in sg.gnn.names]
+    if precision == "f16x3":
+        for name, sc in (("wqkv", "qkv"), ("wm", "m"), ("w1", "1"), ("w2", "2"), ("wf", "f")):
+            mats = p[name] if p[name].dim() == 3 else p[name][None]
+            scale = f16x3_scale(mats) if mats.numel() else 1.0
+            p["scale_" + sc] = scale
+            imgs = [pack_gemm_x3(m, scale) for m in mats.cpu()]
+            p[name + "_x3"] = (torch.stack(imgs) if imgs else torch.zeros((0,), dtype=torch.int16)).contiguous().to(device)
     return p
 
 

@@ -103,7 +103,7 @@ class SuperGlueMatch(nn.Module):
     def _match_pack(self):
         ver = (packing.params_version(self.superglue), packing.params_version(self.mlp_offsets), str(self.device))
         if self._mpack is None or self._mpack[0] != ver:
-            tensors = packing.pack_match_weights(self, self.device)
+            tensors = packing.pack_match_weights(self, self.device, self.precision)
             self._mpack = (ver, tensors, ops.make_match_weights(tensors))
         return self._mpack[2]
 
