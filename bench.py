@@ -169,6 +169,7 @@ def main():
     from text2pos_amd.modules import tokenize
     tok, lens = tokenize(S.make_texts(SEED, q_lo, q_hi), model.language_encoder.known_words)
     d_tok, d_len = torch.from_numpy(tok).to(dev), torch.from_numpy(lens).to(dev)
+    h_pinned = [torch.from_numpy(a).pin_memory() for a in (xyz, rgb, center, mean_rgb)] if rank == 0 else None
     del xyz, rgb
 
     side = torch.cuda.Stream(device=dev)   # the text branch is independent of the cell branch: its (latency-bound)
@@ -230,6 +231,25 @@ def main():
     phase_rates = {"cells_per_s": (c_hi - c_lo) / t_cells, "objects_per_s": n_obj / t_cells,
                    "queries_per_s": (q_hi - q_lo) / t_text, "retrieval_qps": (q_hi - q_lo) / t_topk,
                    "note": "this rank, each phase alone (encode cells / encode text / sim + top-k over this rank's cells)"}
+    # roofline fractions of the two other phases: text = 2,097,152 FLOP per token minus the input projection
+    # (a [V][4D] gate table here) = 2 dirs x 2 x 256 x 1024 per token on the fp32 matrix path; retrieval = 2 Nq Nc D on
+    # the fp64 matrix path (78.6 TFLOP/s dense)
+    n_tok = int(d_len.sum().item())
+    text_flops = 2.0 * 2 * 256 * 1024 * n_tok
+    sim_flops = 2.0 * (q_hi - q_lo) * cells_.shape[0] * 256
+    phase_rates["roofline"] = {
+        "text": {"bound": "mfma (fp32) / latency", "achieved_tflops": text_flops / t_text / 1e12, "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                 "frac": text_flops / t_text / 1e12 / FP32_MFMA_PEAK_TFLOPS, "tokens": n_tok},
+        "retrieval": {"bound": "mfma (fp64)", "achieved_tflops": sim_flops / t_topk / 1e12, "peak_tflops": 78.6,
+                      "frac": sim_flops / t_topk / 1e12 / 78.6}}
+    if rank == 0:  # PCIe-inclusive cell rate: pinned host arrays -> HBM -> embeddings (never `value`)
+        def with_h2d():
+            d = [t.to(dev, non_blocking=True) for t in h_pinned]
+            return model.encode_objects_packed(*d, cell_ptr, d_ptr, chunk_objects=args.chunk_objects)
+        with torch.no_grad():
+            t_h2d, _ = timed(with_h2d, 1)
+        phase_rates["cells_per_s_incl_h2d"] = (c_hi - c_lo) / t_h2d
+        phase_rates["h2d_bytes"] = int(sum(t.numel() * 4 for t in h_pinned))
 
     # sanity on the result of the last step (not timed): sorted scores, valid indices
     assert bool((score[:, :-1] >= score[:, 1:]).all()) and bool((idx >= 0).all()) and bool((idx < n_cells_total).all())
