@@ -98,7 +98,7 @@ size_t carve(Bump& b, int64_t n, int64_t nb, const t2p_cell_config& cfg, CellWs*
     Geo g(cfg.n_pts);
     const int D = cfg.embed_dim;
     const int nfeat = (cfg.use_class ? 1 : 0) + (cfg.use_color ? 1 : 0) + (cfg.use_position ? 1 : 0);
-    CellWs w;
+    CellWs w{};
     for (int l = 0; l < 3; l++) {
         w.gt.n_dense[l] = g.nd[l];
         w.gt.n_cent[l] = g.nc[l];
@@ -194,6 +194,22 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         const bool want_nbr = tr != nullptr && (tr->nbr[0] || tr->nbr[1] || tr->nbr[2] || tr->cnt[0] || tr->cnt[1] || tr->cnt[2]);
         if (!want_nbr)
             for (int l = 0; l < 3; l++) gt.nbr[l] = gt.cnt[l] = nullptr;
+        // the layer-1 tables that depend on geometry only are written by the same kernel: B_l = W1p_l pos_i (+ the
+        // [xyz | 0] tail of the F_l rows) for every level, and the K = 6 point table A_1 of level 0
+        for (int l = 0; l < 3; l++) {
+            const int cf = l == 0 ? 3 : Geo::C[l - 1];
+            gt.B[l] = ws.B[l];
+            gt.wp[l] = W.sa_w1[l] + (size_t)cf * Geo::H[l];
+            gt.H[l] = Geo::H[l];
+            gt.tail[l] = ws.F[l];
+            gt.ld_tail[l] = Geo::LD[l];
+            gt.tail_col0[l] = Geo::C[l];
+        }
+        gt.A1 = ws.A[0];
+        gt.w1 = W.sa_w1[0];
+        gt.b1 = W.sa_b1[0];
+        gt.rgb = rgb;
+        gt.H1 = Geo::H[0];
         T2P_TRY(launch_sample_group(xyz, n, cfg.n_pts, cfg.radius, gt, st));
     }
 
@@ -201,13 +217,12 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     for (int l = 0; l < 3; l++) {
         const int H = Geo::H[l], C = Geo::C[l];
         const int cf = l == 0 ? 3 : Geo::C[l - 1];  // feature columns in front of the xyz columns
+        (void)cf;
         const float* pos_src = l == 0 ? xyz : ws.F[l - 1];
         const int ld_pos = l == 0 ? 3 : Geo::LD[l - 1];
         const int pos_col0 = l == 0 ? 0 : Geo::C[l - 1];
         // layer-1 point table A_j = W1 [x_j | pos_j] + b1
-        if (l == 0) {
-            T2P_TRY(launch_sa1_point_table(rgb, xyz, n * g.nd[0], W.sa_w1[0], W.sa_b1[0], H, ws.A[0], st));
-        } else {
+        if (l != 0) {  // (level 0: written by k_sample_group)
             WsParams p{};
             p.A = ws.F[l - 1];
             p.lda = Geo::LD[l - 1];
@@ -221,9 +236,6 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
             p.M = n * g.nd[l];
             T2P_TRY(launch_ws(WS_DENSE_STORE, Geo::LD[l - 1], H, p, st));
         }
-        // centroid table B_i = W1p pos_i
-        T2P_TRY(launch_pos_table(pos_src, ld_pos, pos_col0, ws.gt.fps_idx[l], n, g.nd[l], g.nc[l],
-                                 W.sa_w1[l] + (size_t)cf * H, H, ws.B[l], ws.F[l], Geo::LD[l], C, st));
         // per-edge ReLU(A_j - B_i) -> layer 2 -> max per centroid
         SaParams p{};
         p.A = ws.A[l];
@@ -554,7 +566,7 @@ int t2p_sample_group(const float* xyz, int64_t n_obj, int32_t n_pts, const float
                      uint8_t* const* fps_idx, uint8_t* const* nbr, uint8_t* const* cnt, t2p_stream_t stream) {
     T2P_CHECK_ARG(xyz && radius_host && fps_idx && nbr && cnt, "sample_group: NULL argument");
     Geo g(n_pts);
-    GroupTables gt;
+    GroupTables gt{};
     gt.self_loops = 0;
     for (int l = 0; l < 3; l++) {
         gt.fps_idx[l] = fps_idx[l];

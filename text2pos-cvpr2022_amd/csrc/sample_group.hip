@@ -147,7 +147,52 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
+// Centroid table of one level + the [xyz | 0 x 29] tail of the SA output rows (was k_pos_table): H/4 lanes per centroid row,
+// the lane's 4 output columns of W1p in registers, 16-byte stores.  Same arithmetic order as the stand-alone kernel.
+__device__ __forceinline__ void emit_centroid_table(const float* qx, const float* qy, const float* qz, int n_c,
+                                                    const float* __restrict__ wp, int H, float* __restrict__ out,
+                                                    float* __restrict__ tail, int ld_tail, int tail_col0) {
+    const int lane = threadIdx.x;
+    const int tpr = H >> 2, rpp = 64 / tpr, hq = lane % tpr;
+    const f32x4 w0 = *(const f32x4*)(wp + hq * 4), w1 = *(const f32x4*)(wp + H + hq * 4), w2 = *(const f32x4*)(wp + 2 * H + hq * 4);
+    for (int c = lane / tpr; c < n_c; c += rpp) {
+        const float px = qx[c], py = qy[c], pz = qz[c];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float a = px * w0[e];
+            a = fmaf(py, w1[e], a);
+            a = fmaf(pz, w2[e], a);
+            v[e] = a;
+        }
+        *(f32x4*)(out + (size_t)c * H + hq * 4) = v;
+        if (tail != nullptr && hq < 8)
+            *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0 + hq * 4) = hq == 0 ? f32x4{px, py, pz, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// SA1 layer-1 point table of one object (was k_sa1_point_table): A_1[j] = W1 [rgb_j | xyz_j] + b1
+__device__ __forceinline__ void emit_point_table(const float* px, const float* py, const float* pz,
+                                                 const float* __restrict__ rgb, int n_pts, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, int H, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const int tpr = H >> 2, rpp = 64 / tpr, hq = lane % tpr;
+    f32x4 wk[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) wk[k] = *(const f32x4*)(w + k * H + hq * 4);
+    const f32x4 bv = *(const f32x4*)(bias + hq * 4);
+    for (int j = lane / tpr; j < n_pts; j += rpp) {
+        const float in[6] = {rgb[j * 3], rgb[j * 3 + 1], rgb[j * 3 + 2], px[j], py[j], pz[j]};
+        f32x4 v = bv;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaf(in[k], wk[k][e], v[e]);
+        *(f32x4*)(out + (size_t)j * H + hq * 4) = v;
+    }
+}
+
+__global__ __launch_bounds__(64, 3) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
                                                      float r0, float r1, float r2, GroupTables gt) {
     // dynamic LDS: coordinates of the 4 levels | FPS selection | compact rows | (only when the neighbour table is
     // wanted: nbr + cnt) -- the production path leaves the table out, which lifts occupancy from 8 to 11 waves per CU
@@ -169,6 +214,14 @@ __global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ x
             p0[(i % 3) * kMaxPts + i / 3] = v;
         }
         __syncthreads();
+        if (gt.A1 != nullptr) {
+            // the weight pointers are laundered per object: hipcc would otherwise hoist the (loop-invariant) weight loads
+            // of all four tables out of the object loop and keep ~100 registers alive across the FPS loops
+            const float *w1 = gt.w1, *b1 = gt.b1;
+            asm volatile("" : "+s"(w1), "+s"(b1));
+            emit_point_table(p0, p0 + kMaxPts, p0 + 2 * kMaxPts, gt.rgb + o * (int64_t)n_pts * 3, n_pts, w1, b1, gt.H1,
+                             gt.A1 + o * (int64_t)n_pts * gt.H1);
+        }
         float* pin[4][3] = {{p0, p0 + kMaxPts, p0 + 2 * kMaxPts},
                             {p1, p1 + kMaxPts / 2, p1 + kMaxPts},
                             {p2, p2 + kMaxPts / 4, p2 + kMaxPts / 2},
@@ -203,6 +256,14 @@ __global__ __launch_bounds__(64) void k_sample_group(const float* __restrict__ x
                 }
                 if (lane == 0) gt.n_rows[l][o] = (uint16_t)n_rows;
             }
+            if (gt.B[l] != nullptr) {
+                const float* wpl = gt.wp[l];
+                asm volatile("" : "+s"(wpl));
+                emit_centroid_table(pin[l + 1][0], pin[l + 1][1], pin[l + 1][2], n_c, wpl, gt.H[l],
+                                    gt.B[l] + o * (int64_t)n_c * gt.H[l],
+                                    gt.tail[l] ? gt.tail[l] + o * (int64_t)n_c * gt.ld_tail[l] : nullptr, gt.ld_tail[l],
+                                    gt.tail_col0[l]);
+            }
             uint8_t* g_sel = gt.fps_idx[l] + o * (int64_t)n_c;
             for (int i = lane; i < n_c; i += 64) g_sel[i] = sel_lds[i];
             if (want_nbr) {
@@ -225,6 +286,13 @@ int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float 
     int64_t grid = n_obj < (int64_t)num_cus() * 64 ? n_obj : (int64_t)num_cus() * 64;
     ProfScope ps_("sample_group", st);
     const bool want_nbr = gt.nbr[0] != nullptr;
+    for (int l = 0; l < 3; l++)
+        if (gt.B[l] != nullptr)
+            T2P_CHECK_ARG(gt.H[l] % 4 == 0 && gt.H[l] >= 32 && gt.H[l] <= 256 && 64 % (gt.H[l] / 4) == 0 && gt.wp[l],
+                          "sample_group: centroid table of level %d: H=%d", l, gt.H[l]);
+    if (gt.A1 != nullptr)
+        T2P_CHECK_ARG(gt.H1 % 4 == 0 && gt.H1 >= 4 && gt.H1 <= 256 && 64 % (gt.H1 / 4) == 0 && gt.w1 && gt.b1 && gt.rgb,
+                      "sample_group: point table: H=%d", gt.H1);
     T2P_CHECK_ARG(!want_nbr || (gt.nbr[1] && gt.nbr[2] && gt.cnt[0] && gt.cnt[1] && gt.cnt[2]),
                   "sample_group: neighbour tables must be given for all levels or none");
     size_t lds = sizeof(float) * 3 * (kMaxPts + kMaxPts / 2 + kMaxPts / 4 + kMaxPts / 8) + kMaxPts / 2 +

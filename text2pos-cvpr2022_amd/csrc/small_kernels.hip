@@ -1,5 +1,5 @@
-// Small HBM/latency-bound helper kernels of the cell branch: K<=6 layer-1 tables, row L2-normalisation,
-// per-cell pooling and the per-cell kNN graph.
+// Small HBM/latency-bound helper kernels of the cell branch: row L2-normalisation, colour / position MLPs,
+// per-cell pooling and the per-cell kNN graph (the K <= 6 layer-1 tables live in sample_group.hip).
 //
 // Reference call sites: F.normalize models/object_encoder.py:110-135, models/cell_retrieval.py:73,94,105;
 // gnn.global_max_pool / global_mean_pool models/cell_retrieval.py:98,102; knn inside gnn.DynamicEdgeConv
@@ -8,60 +8,6 @@
 
 namespace t2p {
 namespace {
-
-// SA1 layer-1 point table A_j = W1 [rgb_j | xyz_j] + b1 (K = 6): H/4 threads per point, each holding its 4 output columns
-// of W1 and b1 in registers; 16-byte stores, 32-bit indices (rows of a chunk fit easily).
-__global__ __launch_bounds__(256) void k_sa1_point_table(const float* __restrict__ rgb, const float* __restrict__ xyz,
-                                                         uint32_t n_rows, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, int H, float* __restrict__ out) {
-    const uint32_t tpr = (uint32_t)H >> 2, rpb = 256u / tpr;
-    const uint32_t hq = threadIdx.x % tpr;
-    f32x4 wk[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) wk[k] = *(const f32x4*)(w + k * H + hq * 4);
-    const f32x4 bv = *(const f32x4*)(bias + hq * 4);
-    for (uint32_t row = blockIdx.x * rpb + threadIdx.x / tpr; row < n_rows; row += gridDim.x * rpb) {
-        const float* c = rgb + (size_t)row * 3;
-        const float* p = xyz + (size_t)row * 3;
-        const float in[6] = {c[0], c[1], c[2], p[0], p[1], p[2]};
-        f32x4 v = bv;
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = fmaf(in[k], wk[k][e], v[e]);
-        *(f32x4*)(out + (size_t)row * H + hq * 4) = v;
-    }
-}
-
-// Centroid table B_i = W1p pos_i (one row of H floats per centroid) plus the [xyz | 0 x 29] tail of the centroid's SA
-// output row.  H/4 threads per row, 16-byte stores; pure write bandwidth (no per-element index arithmetic).
-__global__ __launch_bounds__(256) void k_pos_table(const float* __restrict__ src, int ld_src, int col0,
-                                                   const uint8_t* __restrict__ idx, uint32_t n_rows, int n_dense,
-                                                   int n_cent, const float* __restrict__ wp, int H,
-                                                   float* __restrict__ out, float* __restrict__ tail, int ld_tail,
-                                                   int tail_col0) {
-    const int tpr = H >> 2;                 // threads per row
-    const int rpb = 256 / tpr;              // rows per block pass
-    const int hq = threadIdx.x % tpr;
-    f32x4 w0 = *(const f32x4*)(wp + hq * 4), w1 = *(const f32x4*)(wp + H + hq * 4), w2 = *(const f32x4*)(wp + 2 * H + hq * 4);
-    for (uint32_t row = blockIdx.x * rpb + threadIdx.x / tpr; row < n_rows; row += gridDim.x * rpb) {
-        const uint32_t o = row / (uint32_t)n_cent;   // 32-bit: a chunk has < 2^31 centroid rows (checked by the launcher)
-        const uint32_t loc = idx ? (uint32_t)idx[row] : row - o * (uint32_t)n_cent;
-        const float* p = src + ((size_t)o * n_dense + loc) * (size_t)ld_src + col0;
-        const float px = p[0], py = p[1], pz = p[2];
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float a = px * w0[e];
-            a = fmaf(py, w1[e], a);
-            a = fmaf(pz, w2[e], a);
-            v[e] = a;
-        }
-        *(f32x4*)(out + (size_t)row * H + hq * 4) = v;
-        if (tail != nullptr && hq < 8)
-            *(f32x4*)(tail + (size_t)row * ld_tail + tail_col0 + hq * 4) = hq == 0 ? f32x4{px, py, pz, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-}
 
 // F.normalize(x, dim=-1): x / max(||x||_2, 1e-12); one wavefront per row.
 __global__ __launch_bounds__(256) void k_rownorm(const float* __restrict__ in, int ld_in, int64_t n_rows, int dim,
@@ -304,40 +250,8 @@ __global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, 
     }
 }
 
-inline unsigned grid_for(int64_t total, int block) {
-    int64_t g = (total + block - 1) / block;
-    int64_t cap = (int64_t)num_cus() * 16;
-    if (g > cap) g = cap;
-    if (g < 1) g = 1;
-    return (unsigned)g;
-}
 
 }  // namespace
-
-int launch_sa1_point_table(const float* rgb, const float* xyz, int64_t n_rows, const float* w, const float* bias,
-                           int H, float* out, hipStream_t st) {
-    if (n_rows == 0) return 0;
-    ProfScope ps_("sa1_point_table", st);
-    T2P_CHECK_ARG(H % 4 == 0 && H >= 4 && H <= 1024 && 256 % (H / 4) == 0 && n_rows < 0x7fffffffLL, "sa1_point_table: H=%d", H);
-    hipLaunchKernelGGL(k_sa1_point_table, dim3(grid_for(n_rows * (H / 4), 256)), dim3(256), 0, st, rgb, xyz,
-                       (uint32_t)n_rows, w, bias, H, out);
-    T2P_CHECK_LAUNCH("sa1_point_table");
-    return 0;
-}
-
-int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx, int64_t n_obj, int n_dense,
-                     int n_cent, const float* wp, int H, float* out, float* tail, int ld_tail, int tail_col0,
-                     hipStream_t st) {
-    if (n_obj == 0) return 0;
-    ProfScope ps_("pos_table", st);
-    T2P_CHECK_ARG(H % 4 == 0 && H >= 32 && H <= 1024 && 256 % (H / 4) == 0, "pos_table: H=%d", H);
-    const int64_t n_rows = n_obj * n_cent;
-    T2P_CHECK_ARG(n_rows < 0x7fffffffLL, "pos_table: chunk too large");
-    hipLaunchKernelGGL(k_pos_table, dim3(grid_for(n_rows * (H / 4), 256)), dim3(256), 0, st, src, ld_src, col0, idx,
-                       (uint32_t)n_rows, n_dense, n_cent, wp, H, out, tail, ld_tail, tail_col0);
-    T2P_CHECK_LAUNCH("pos_table");
-    return 0;
-}
 
 int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* out, int ld_out, int col0,
                    hipStream_t st) {

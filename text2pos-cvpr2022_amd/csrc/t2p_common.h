@@ -65,19 +65,23 @@ struct GroupTables {
     int self_loops;
     int n_dense[3];
     int n_cent[3];
+    // Optional layer-1 tables written by the same kernel (it is VALU-bound and leaves the memory pipes idle; as separate
+    // kernels these tables were pure HBM-write time).  B[l] = nullptr / A1 = nullptr: not wanted.
+    float* B[3];            // centroid tables  B_l[o*n_cent + c][H_l] = W1p_l pos_c
+    const float* wp[3];     // [3][H_l] position rows of the level's layer-1 weights
+    int H[3];
+    float* tail[3];         // SA output rows F_l: the [xyz | 0 x 29] tail at column tail_col0[l] (row stride ld_tail[l])
+    int ld_tail[3], tail_col0[3];
+    float* A1;              // SA1 point table A_1[o*n_pts + j][H1] = W1 [rgb_j | xyz_j] + b1
+    const float* w1;        // [6][H1]
+    const float* b1;
+    const float* rgb;       // [n_obj][n_pts][3]
+    int H1;
 };
 int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float radius[3], GroupTables gt,
                         hipStream_t st);
 
 // ---- tables.hip / small kernels ------------------------------------------------------------------------------
-// out[row, h] = bias[h] + sum_c rgb[row,c]*w[c][h] + xyz[row,c]*w[3+c][h]      (SA1 layer-1 point table, K = 6)
-int launch_sa1_point_table(const float* rgb, const float* xyz, int64_t n_rows, const float* w /*[6][H]*/,
-                           const float* bias, int H, float* out, hipStream_t st);
-// out[(o*n_cent + c), h] = sum_d pos(o, idx[o,c])[d] * wp[d][h] ; pos rows are read from `src` with leading
-// dimension ld_src at column offset col0 (row = o*n_dense + idx).  idx == nullptr -> identity (c).
-int launch_pos_table(const float* src, int ld_src, int col0, const uint8_t* idx, int64_t n_obj, int n_dense,
-                     int n_cent, const float* wp /*[3][H]*/, int H, float* out, float* tail /*nullable*/, int ld_tail,
-                     int tail_col0, hipStream_t st);
 // gather level-l centroid positions: out[(o*n_cent + c), 0..2]
 int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* out, int ld_out, int col0,
                    hipStream_t st);
