@@ -1,4 +1,5 @@
-// Set-abstraction edge kernel: per-edge ReLU(A_j - B_i) -> layer-2 GEMM -> max per centroid, for sa1/sa2/sa3
+// Set-abstraction edge kernel, exact-fp32 path (precision = "fp32": v_mfma_f32_32x32x2_f32 fma chains): per-edge
+// ReLU(A_j - B_i) -> layer-2 GEMM -> max per centroid, for sa1/sa2/sa3.  The default f16x3 path is ws_sa2.hip.
 // (reference: gnn.PointConv(local_nn)(x, (pos, pos[idx]), edge_index), models/pointcloud/pointnet2.py:31-35).
 //
 // Same arithmetic and register-resident weights as ws_gemm.hip (see the design notes there); this variant removes
@@ -12,30 +13,15 @@
 //     with double-buffered LDS staging tiles and one barrier per batch;
 //   * the per-object max accumulator is double-buffered in LDS too, so the finished object's [n_cent][C] block is
 //     written to HBM (and re-zeroed) underneath the MFMAs of the next object's first batch.
-#ifndef T2P_LDS_PREFETCH
-#define T2P_LDS_PREFETCH 1
-#endif
 #include "t2p_common.h"
 
 namespace t2p {
 namespace {
 
-#define LOADA(ptr) (*(const half8*)(ptr))
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-
 constexpr int kSub = 512;
 constexpr int NT = 512;   // threads per workgroup: 8 waves = 2 per SIMD, so one wave's VALU/LDS phases overlap the other's MFMAs  // objects whose row counts / self-loop bases are cached in LDS at a time
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-
-// X3 = 1: "f16x3" split-precision MFMA.  Both operands are split x = hi + lo/2048 with hi, lo in fp16 (hi = x rounded
-// toward zero, lo = (x - hi)*2048), and  h.w ~= hi.hi + (hi.lo' + lo'.hi)/2048  is accumulated in fp32 by three
-// v_mfma_f32_32x32x16_f16 per 16 k (the dropped lo.lo term is < 2^-20 relative).  The representation error of the
-// split (~5e-7 on unit-scale data, tests/test_host.py) is below the rounding error of an fp32 fma chain of this
-// length, at 16/3 = 5.3x the fp32-MFMA rate.
-template <int K, int N, int WN, int RT, int X3>
+template <int K, int N, int WN, int RT>
 struct SaCfg {
     static constexpr int WM = 8 / WN;
     static constexpr int NTW = N / (32 * WN);
@@ -48,13 +34,8 @@ struct SaCfg {
     static constexpr int TOTAL_F4 = TR * F4_PER_ROW;
     static constexpr int ITERS = TOTAL_F4 / NT;
     static_assert(TOTAL_F4 % NT == 0, "staging must divide evenly over the workgroup");
-    // X3: two fp16 planes (hi, lo) per buffer, row stride K + 8 halves (16-byte pad keeps ds_read_b128 conflict-free)
-    static constexpr int LDHH = K + 8;
-    static constexpr int PLANE = TR * LDHH;   // halves per plane
-    static constexpr int S16 = K / 16;        // MFMA k-steps: lane half h owns k in [h*K/2, (h+1)*K/2), 8 per step
-    static_assert(!X3 || K % 32 == 0, "f16x3 needs K % 32 == 0");
     static constexpr size_t lds_bytes() {
-        const size_t tile = X3 ? (size_t)2 * PLANE * 2 : (size_t)HID_FLOATS * 4;
+        const size_t tile = (size_t)HID_FLOATS * 4;
         return 2 * tile + (size_t)2 * ACC_INTS * 4 + 2 * TR + kSub * 2 + kSub * 4;
     }
 };
@@ -102,13 +83,12 @@ struct BatchIt {  // position in the flattened batch stream of a sub-range
     int n;        // rows of the object
 };
 
-template <int K, int N, int WN, int RT, int X3>
+template <int K, int N, int WN, int RT>
 __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
-    using C = SaCfg<K, N, WN, RT, X3>;
+    using C = SaCfg<K, N, WN, RT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* hid = lds;                                       // fp32: [2][HID_FLOATS]
-    _Float16* hidh = (_Float16*)lds;                        // f16x3: [2][hi plane | lo plane]
-    constexpr int TILE_FLOATS = X3 ? C::PLANE : C::HID_FLOATS;   // 2 planes of halves == PLANE floats
+    constexpr int TILE_FLOATS = C::HID_FLOATS;
     int* acc_lds = (int*)(lds + 2 * TILE_FLOATS);           // [2][ACC_INTS]
     uint8_t* dstl = (uint8_t*)(acc_lds + 2 * C::ACC_INTS);  // [2][TR] destination (centroid) of every staged row
     uint16_t* nr = (uint16_t*)(dstl + 2 * C::TR);           // [kSub] rows per object
@@ -119,28 +99,13 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
     const int nc = p.n_cent;
     const int maxr = nc * 33;
 
-    float w[X3 ? 1 : C::NTW][X3 ? 1 : C::KS];
-    half8 w_hi[X3 ? C::NTW : 1][X3 ? C::S16 : 1], w_lo[X3 ? C::NTW : 1][X3 ? C::S16 : 1];
-    if constexpr (X3) {
-        // host-packed register image: [plane][n-tile][step][lane half][32 lanes][8 halves]  (packing.py::pack_f16x3)
-        const uint4* wp = (const uint4*)p.W_x3;
-        constexpr int PLANE_U4 = (N / 32) * C::S16 * 64;
-#pragma unroll
-        for (int nt = 0; nt < C::NTW; nt++)
-#pragma unroll
-            for (int s = 0; s < C::S16; s++) {
-                const int idx = (((wn * C::NTW + nt) * C::S16 + s) * 2 + h) * 32 + l31;
-                const uint4 a = wp[idx], b = wp[PLANE_U4 + idx];
-                w_hi[nt][s] = __builtin_bit_cast(half8, a);
-                w_lo[nt][s] = __builtin_bit_cast(half8, b);
-            }
-    } else {
-#pragma unroll
+    float w[C::NTW][C::KS];
+    #pragma unroll
         for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
             for (int s = 0; s < C::KS; s++)
                 w[nt][s] = p.W[(int64_t)(h * C::KS + s) * N + wn * C::NTW * 32 + nt * 32 + l31];
-    }
+    
     float bias[C::NTW];
 #pragma unroll
     for (int nt = 0; nt < C::NTW; nt++) bias[nt] = p.bias[wn * C::NTW * 32 + nt * 32 + l31];
@@ -216,7 +181,6 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
         // W: h = relu(A_j - B_i) -> LDS tile, plus the destination byte of every row
         auto write_tile = [&](int buf, const metav& m) {
             float* dst = hid + buf * C::HID_FLOATS;
-            _Float16* dsth = hidh + buf * 2 * C::PLANE;
 #pragma unroll
             for (int k = 0; k < C::ITERS; k++) {
                 const int lr = rgrp + k;
@@ -224,19 +188,8 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = fmaxf(t[e], 0.f);
-                if constexpr (X3) {
-                    // hi = fp16(v) toward zero, lo = fp16((v - hi) * 2048): 4 values -> 8 bytes in each plane
-                    const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                    const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.f, (v[1] - (float)h01[1]) * 2048.f);
-                    const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * 2048.f, (v[3] - (float)h23[1]) * 2048.f);
-                    uint2 ph, pl;
-                    ph.x = __builtin_bit_cast(uint32_t, h01); ph.y = __builtin_bit_cast(uint32_t, h23);
-                    pl.x = __builtin_bit_cast(uint32_t, l01); pl.y = __builtin_bit_cast(uint32_t, l23);
-                    *(uint2*)(dsth + lr * C::LDHH + c4 * 4) = ph;
-                    *(uint2*)(dsth + C::PLANE + lr * C::LDHH + c4 * 4) = pl;
-                } else {
-                    *(f32x4*)(dst + lr * C::LDH + c4 * 4) = v;
-                }
+                                    *(f32x4*)(dst + lr * C::LDH + c4 * 4) = v;
+                
                 // destination of the row; padding rows go to the accumulator's dummy row n_cent
                 if (c4 == 0) dstl[buf * C::TR + lr] = m[k] == 0xFFFF ? (uint8_t)nc : (uint8_t)((m[k] >> 8) & 127);
             }
@@ -279,7 +232,6 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
 
             // C(t): MFMA block on tile t & 1
             f32x16 acc[RT][C::NTW];
-            f32x16 accx[X3 ? RT : 1][X3 ? C::NTW : 1];  // f16x3: cross terms (hi.lo' + lo'.hi), scaled by 2048
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -287,83 +239,12 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         acc[rt][nt][e] = bias[nt];  // bias rides in the accumulator
-                        if constexpr (X3) accx[rt][nt][e] = 0.f;
                     }
             const int buf = t & 1;
-            if constexpr (X3) {
-                const _Float16* hrow = hidh + buf * 2 * C::PLANE + ((wm * RT) * 32 + l31) * C::LDHH + h * (K / 2);
-#if T2P_LDS_PREFETCH
-                // operands of step s+1 are fetched before the MFMAs of step s (register double buffer); the scheduling
-                // barrier keeps hipcc from sinking the reads back to their first use
-                half8 a_hi[RT], a_lo[RT], n_hi[RT], n_lo[RT];
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-                    a_hi[rt] = LOADA(hrow + rt * 32 * C::LDHH);
-                    a_lo[rt] = LOADA(hrow + C::PLANE + rt * 32 * C::LDHH);
-                }
-#pragma unroll
-                for (int s = 0; s < C::S16; s++) {
-                    if (s + 1 < C::S16) {
-#pragma unroll
-                        for (int rt = 0; rt < RT; rt++) {
-                            n_hi[rt] = LOADA(hrow + rt * 32 * C::LDHH + (s + 1) * 8);
-                            n_lo[rt] = LOADA(hrow + C::PLANE + rt * 32 * C::LDHH + (s + 1) * 8);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                        for (int nt = 0; nt < C::NTW; nt++) {
-                            acc[rt][nt] = MFMA16(a_hi[rt], w_hi[nt][s], acc[rt][nt]);
-                            accx[rt][nt] = MFMA16(a_hi[rt], w_lo[nt][s], accx[rt][nt]);
-                        }
-#pragma unroll
-                    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                        for (int nt = 0; nt < C::NTW; nt++)
-                            accx[rt][nt] = MFMA16(a_lo[rt], w_hi[nt][s], accx[rt][nt]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int rt = 0; rt < RT; rt++) {
-                        a_hi[rt] = n_hi[rt];
-                        a_lo[rt] = n_lo[rt];
-                    }
-                }
-#else
-#pragma unroll
-                for (int s = 0; s < C::S16; s++) {
-                    half8 a_hi[RT], a_lo[RT];
-#pragma unroll
-                    for (int rt = 0; rt < RT; rt++) {
-                        a_hi[rt] = *(const half8*)(hrow + rt * 32 * C::LDHH + s * 8);
-                        a_lo[rt] = *(const half8*)(hrow + C::PLANE + rt * 32 * C::LDHH + s * 8);
-                    }
-#pragma unroll
-                    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                        for (int nt = 0; nt < C::NTW; nt++) {
-                            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_hi[nt][s], acc[rt][nt], 0, 0, 0);
-                            accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], w_lo[nt][s], accx[rt][nt], 0, 0, 0);
-                        }
-#pragma unroll
-                    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                        for (int nt = 0; nt < C::NTW; nt++)
-                            accx[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[rt], w_hi[nt][s], accx[rt][nt], 0, 0, 0);
-                }
-#endif
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++)
-#pragma unroll
-                        for (int e = 0; e < 16; e++) acc[rt][nt][e] = fmaf(accx[rt][nt][e], 1.f / 2048.f, acc[rt][nt][e]);
-            } else {
-                const float* hrow = hid + buf * C::HID_FLOATS + ((wm * RT) * 32 + l31) * C::LDH + h * C::KS;
+                            const float* hrow = hid + buf * C::HID_FLOATS + ((wm * RT) * 32 + l31) * C::LDH + h * C::KS;
                 constexpr int QC = 4;                 // k-quads (16 k-steps) fetched per LDS round
                 constexpr int NCH = C::KS / 4 / QC;   // chunks
-                static_assert(X3 || (C::KS / 4) % QC == 0, "K/8 must be a multiple of the LDS prefetch chunk");
+                static_assert((C::KS / 4) % QC == 0, "K/8 must be a multiple of the LDS prefetch chunk");
                 f32x4 a_cur[RT][QC], a_nxt[RT][QC];
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
@@ -393,7 +274,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
 #pragma unroll
                         for (int qi = 0; qi < QC; qi++) a_cur[rt][qi] = a_nxt[rt][qi];
                 }
-            }
+            
             // max-aggregation: every accumulator row goes straight to its destination's LDS slot with an integer atomic
             // max (non-returning; the signed-int max against +0 is also the ReLU).  No run detection, no branches:
             // padding rows carry destination n_cent = the accumulator's dummy row.
@@ -434,10 +315,10 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
     }
 }
 
-template <int K, int N, int WN, int RT, int X3>
+template <int K, int N, int WN, int RT>
 int launch_sa_cfg(const SaParams& p_in, hipStream_t st, const char* name) {
-    using C = SaCfg<K, N, WN, RT, X3>;
-    auto kern = k_ws_sa<K, N, WN, RT, X3>;
+    using C = SaCfg<K, N, WN, RT>;
+    auto kern = k_ws_sa<K, N, WN, RT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -483,9 +364,9 @@ int launch_ws_sa(int H, int Cout, const SaParams& p, hipStream_t st) {
         T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_sa: packed f16x3 weights must be 16-byte aligned");
         return launch_ws_sa2(H, Cout, p, st);
     } else {
-        if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2, 0>(p, st, "ws_edge_sa_k32_n64");
-        if (H == 128 && Cout == 128) return launch_sa_cfg<128, 128, 4, 1, 0>(p, st, "ws_edge_sa_k128_n128");
-        if (H == 256 && Cout == 256) return launch_sa_cfg<256, 256, 8, 1, 0>(p, st, "ws_edge_sa_k256_n256");
+        if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2>(p, st, "ws_edge_sa_k32_n64");
+        if (H == 128 && Cout == 128) return launch_sa_cfg<128, 128, 4, 1>(p, st, "ws_edge_sa_k128_n128");
+        if (H == 256 && Cout == 256) return launch_sa_cfg<256, 256, 8, 1>(p, st, "ws_edge_sa_k256_n256");
     }
     set_error("ws_sa: no instantiation for H=%d C=%d", H, Cout);
     return T2P_E_UNSUPPORTED;
