@@ -33,16 +33,18 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 // NW = waves per workgroup.  8: one workgroup per CU (two waves per SIMD that share every barrier).  4: TWO independent
 // workgroups per CU (one wave per SIMD each): the two waves of a SIMD then belong to different workgroups, drift apart
 // and cover each other's non-MFMA phases; needs <= 80 KB of LDS, which the single-buffered accumulator allows for K <= 128.
-template <int K, int N, int WN, int RT, int NW>
+// WGS = workgroups per CU (1 or 2; 2 needs <= 80 KB of LDS each, hence a single accumulator buffer).
+template <int K, int N, int WN, int RT, int NW, int WGS>
 struct Cfg2 {
     static constexpr int NT = 64 * NW;
-    static constexpr int ACC_BUFS = NW == 8 ? 2 : 1;
+    static constexpr int ACC_BUFS = WGS == 1 ? 2 : 1;
     static constexpr int WM = NW / WN;
     static constexpr int NTW = N / (32 * WN);
     static constexpr int TR = WM * RT * 32;
     static constexpr int F4_PER_ROW = K / 4;
     static constexpr int ITERS = TR * F4_PER_ROW / NT;
-    static_assert(ITERS == 4 && TR * F4_PER_ROW == ITERS * NT, "every thread stages 4 consecutive rows of one column quad");
+    static_assert((ITERS == 4 || ITERS == 2) && TR * F4_PER_ROW == ITERS * NT,
+                  "every thread stages 2 or 4 consecutive rows of one column quad");
     static constexpr int LDHH = K + 8;       // halves; 16-byte pad keeps ds_read_b128 conflict-free
     static constexpr int PLANE = TR * LDHH;  // halves per plane
     static constexpr int S16 = K / 16;
@@ -87,9 +89,10 @@ struct BatchIt {
         else issue(it_g, meta_g, k, dbuf);                                                     \
     }
 
-template <int K, int N, int WN, int RT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p) {
-    using C = Cfg2<K, N, WN, RT, NW>;
+template <int K, int N, int WN, int RT, int NW, int WGS>
+__global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
+    using C = Cfg2<K, N, WN, RT, NW, WGS>;
+    constexpr int IT = C::ITERS;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     _Float16* hidh = (_Float16*)lds;                            // [2][hi plane | lo plane]
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
     const int rgrp = (tid / C::F4_PER_ROW) * C::ITERS;  // first of this thread's 4 staged rows inside a batch
     const int c4 = tid % C::F4_PER_ROW;
     const uint32_t c4b = (uint32_t)c4 * 16u;
-    typedef uint16_t metav __attribute__((ext_vector_type(4)));
+    typedef uint16_t metav __attribute__((ext_vector_type(C::ITERS)));
 
     for (int ga = g_begin; ga < g_end; ga += kSub) {
         const int cnt = (g_end - ga) < kSub ? (g_end - ga) : kSub;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
         auto valid = [&](const BatchIt& it) { return it.gi < cnt; };
 
         metav meta_g, meta_m;
-        f32x4 sa[4], sb[4];
+        f32x4 sa[IT], sb[IT];
         f32x4 vv;            // staged values between the two halves of a staging step
         fp16x2 vh01, vh23;
 
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
         // end of the batch (touching the value earlier would put a vmcnt wait in front of the MFMAs)
         auto load_meta = [&](const BatchIt& it, metav& m) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) m[k] = 0xFFFF;
+            for (int k = 0; k < IT; k++) m[k] = 0xFFFF;
             if (valid(it) && it.r0 + rgrp < it.n) {
                 const uint32_t off = (uint32_t)(ga + it.gi) * (uint32_t)maxr + (uint32_t)(it.r0 + rgrp);
                 m = *(const metav*)(p.rows + off);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
         };
         auto fix_meta = [&](const BatchIt& it, metav& m) {
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < IT; k++)
                 if (it.r0 + rgrp + k >= it.n) m[k] = 0xFFFF;
         };
         // gathers of row k of a batch (A_j and B_i) + its destination byte.  Unconditional: padding rows (and batches
@@ -237,16 +240,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
         load_meta(it_c, meta_g);
         fix_meta(it_c, meta_g);
 #pragma unroll
-        for (int k = 0; k < 4; k++) issue(it_c, meta_g, k, 0);
+        for (int k = 0; k < IT; k++) issue(it_c, meta_g, k, 0);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < IT; k++) {
             stage_a(0, k);
             stage_b(0, k);
         }
         load_meta(it_s, meta_g);
         fix_meta(it_s, meta_g);
 #pragma unroll
-        for (int k = 0; k < 4; k++) issue(it_s, meta_g, k, 1);
+        for (int k = 0; k < IT; k++) issue(it_s, meta_g, k, 1);
         load_meta(it_g, meta_g);
         fix_meta(it_g, meta_g);
         for (int i = tid; i < C::TR; i += NT) dstl[3 * C::TR + i] = (uint16_t)(nc * N * 4);  // "batch -1": all padding
@@ -411,11 +414,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void k_ws_sa2(SaParams p)
     }
 }
 
-template <int K, int N, int WN, int RT, int NW>
+template <int K, int N, int WN, int RT, int NW, int WGS>
 int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
-    using C = Cfg2<K, N, WN, RT, NW>;
-    static_assert(NW == 8 || K <= 128, "the 4-wave form relies on the deferred atomics (K <= 128)");
-    auto kern = k_ws_sa2<K, N, WN, RT, NW>;
+    using C = Cfg2<K, N, WN, RT, NW, WGS>;
+    static_assert(WGS == 1 || K <= 128, "two workgroups per CU rely on the deferred atomics (K <= 128)");
+    static_assert(C::lds_bytes() * WGS <= 160 * 1024, "LDS budget");
+    auto kern = k_ws_sa2<K, N, WN, RT, NW, WGS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -430,7 +434,7 @@ int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
     T2P_CHECK_ARG(p.n_obj < (1 << 30) && p.n_obj * p.n_dense * (int64_t)K * 4 < 0xffffffffLL &&
                       p.n_obj * p.n_cent * (int64_t)K * 4 < 0xffffffffLL,
                   "ws_sa: chunk too large for 32-bit table offsets");
-    int n_wg = num_cus() * (NW == 8 ? 1 : 2);
+    int n_wg = num_cus() * WGS;
     if (n_wg > 1024) n_wg = 1024;
     if (n_wg > p.n_obj) n_wg = (int)p.n_obj;
     int rc = launch_sa_balance(p, C::TR, n_wg, st);
@@ -466,11 +470,13 @@ int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
 }  // namespace
 
 int launch_ws_sa2(int H, int Cout, const SaParams& p, hipStream_t st) {
-    // SA1: two 4-wave workgroups per CU measured 4 % faster than one 8-wave workgroup; SA2: no difference (kept 8-wave,
-    // whose double-buffered accumulator drains under the MFMAs); SA3 cannot (128 weight registers per 32 columns).
-    if (H == 32 && Cout == 64) return launch_cfg2<32, 64, 2, 2, 4>(p, st, "ws_edge_sa_k32_n64");
-    if (H == 128 && Cout == 128) return launch_cfg2<128, 128, 4, 1, 8>(p, st, "ws_edge_sa_k128_n128");
-    if (H == 256 && Cout == 256) return launch_cfg2<256, 256, 8, 1, 8>(p, st, "ws_edge_sa_k256_n256");
+    // SA2: two 4-wave workgroups per CU measured no faster than one 8-wave workgroup (kept: its double-buffered accumulator
+    // drains under the MFMAs); SA3 cannot split (128 weight registers per 32 columns).
+    // SA1: the weights take 16 registers, so 16 waves per CU fit (two 8-wave workgroups of <= 128 registers, 2 rows per
+    // thread): 4 waves per SIMD measured 10 % faster than 2 (two 4-wave workgroups) and 14 % faster than one 8-wave one
+    if (H == 32 && Cout == 64) return launch_cfg2<32, 64, 2, 1, 8, 2>(p, st, "ws_edge_sa_k32_n64");
+    if (H == 128 && Cout == 128) return launch_cfg2<128, 128, 4, 1, 8, 1>(p, st, "ws_edge_sa_k128_n128");
+    if (H == 256 && Cout == 256) return launch_cfg2<256, 256, 8, 1, 8, 1>(p, st, "ws_edge_sa_k256_n256");
     set_error("ws_sa2: no instantiation for H=%d C=%d", H, Cout);
     return T2P_E_UNSUPPORTED;
 }
