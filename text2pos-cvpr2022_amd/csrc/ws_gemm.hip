@@ -22,9 +22,6 @@
 //     the MFMA block of batch t; their VALU part and the LDS write follow it; one barrier per batch.
 //   * Column slices of one row stream (GA: N = 1024 in slices of 128) are mapped to the same XCD (block b runs on
 //     XCD b % 8), so they share the stream's A rows through that XCD's L2.
-#ifndef T2P_GA1_V1
-#define T2P_GA1_V1 0
-#endif
 #ifndef T2P_GA2_V1
 #define T2P_GA2_V1 0
 #endif
@@ -39,9 +36,9 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 constexpr int kMaxRows = 32 * 33;   // kNN group: 32 destination rows x up to 32 neighbours (+ slack)
 constexpr int kAccFloats = 8192;    // 32 x 256
 
-template <int K, int NW, int WN, int RT, int MODE, int X3>
+template <int K, int NW, int WN, int RT, int MODE, int X3, int W8 = 0>
 struct WsCfg {
-    static constexpr int NWAVES = WN > 4 ? WN : 4;  // WN = 8: eight waves (two per SIMD, <= 256 registers each)
+    static constexpr int NWAVES = (WN > 4 || W8) ? 8 : 4;  // eight waves = two per SIMD, <= 256 registers each
     static constexpr int NTH = 64 * NWAVES;
     static constexpr int WM = NWAVES / WN;
     static constexpr int NTW = NW / (32 * WN);
@@ -68,9 +65,9 @@ struct WsCfg {
     static_assert(NW % (32 * WN) == 0, "NW must split into 32-column tiles per wave");
 };
 
-template <int K, int NW, int WN, int RT, int MODE, int X3, int SPLIT_IO>
-__global__ __launch_bounds__(WN > 4 ? 512 : 256, WN > 4 ? 2 : 1) void k_ws(WsParams p, int n_slices) {
-    using C = WsCfg<K, NW, WN, RT, MODE, X3>;
+template <int K, int NW, int WN, int RT, int MODE, int X3, int SPLIT_IO, int W8 = 0>
+__global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1) void k_ws(WsParams p, int n_slices) {
+    using C = WsCfg<K, NW, WN, RT, MODE, X3, W8>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* hid = lds;                  // fp32: two buffers of TILE_FLOATS
     _Float16* hidh = (_Float16*)lds;   // f16x3: two buffers of [hi plane | lo plane]
@@ -438,10 +435,10 @@ __global__ __launch_bounds__(WN > 4 ? 512 : 256, WN > 4 ? 2 : 1) void k_ws(WsPar
     }
 }
 
-template <int K, int NW, int WN, int RT, int MODE, int X3, int SPLIT_IO>
+template <int K, int NW, int WN, int RT, int MODE, int X3, int SPLIT_IO, int W8 = 0>
 int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
-    using C = WsCfg<K, NW, WN, RT, MODE, X3>;
-    auto kern = k_ws<K, NW, WN, RT, MODE, X3, SPLIT_IO>;
+    using C = WsCfg<K, NW, WN, RT, MODE, X3, W8>;
+    auto kern = k_ws<K, NW, WN, RT, MODE, X3, SPLIT_IO, W8>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -491,18 +488,15 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
     if (mode == MODE_ && K == K_ && N == N_ && x3 == X3_ && split_io == SIO_)                  \
         return launch_cfg<K_, NW_, WN_, RT_, MODE_, X3_, SIO_>(p, N_ / NW_, st);
     // DynamicEdgeConv layer 2 (fp32)
-    WS_CASE(WS_EDGE_KNN, 256, 256, 256, 4, 1, 0, 0)
+    WS_CASE(WS_EDGE_KNN, 256, 256, 256, 8, 1, 0, 0)  // 8 waves, one 32-column block each (128 weight registers)
     // SA2 / SA3 layer-1 point tables ([feat | pos | zero pad] -> H) and GA layer 1
     WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 0, 0)
     WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 0, 0)
     WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 0, 0)
-    WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 1, 0)
-    WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 1, 0)
-#if T2P_GA1_V1
-    WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 1, 2)
-#else
+    if (mode == WS_DENSE_STORE && K == 96 && N == 128 && x3 == 1 && split_io == 0)  // 8 waves: 4 column blocks x 2 row tiles
+        return launch_cfg<96, 128, 4, 1, WS_DENSE_STORE, 1, 0, 1>(p, 1, st);
+    WS_CASE(WS_DENSE_STORE, 160, 256, 256, 8, 1, 1, 0)  // 8 waves (two per SIMD), one 32-column block per wave
     WS_CASE(WS_DENSE_STORE, 288, 512, 256, 8, 1, 1, 2)  // 8 waves: two per SIMD, two column slices instead of four
-#endif
     // GA layer 2 + max over the 32 points of an object
     WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 0, 0)
 #if !T2P_GA2_V1
