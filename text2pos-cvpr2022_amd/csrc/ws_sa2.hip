@@ -322,11 +322,14 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
                     n_hi = *(const half8*)(hrow + rt2 * 32 * C::LDHH + s2 * 8);
                     n_lo = *(const half8*)(hrow + C::PLANE + rt2 * 32 * C::LDHH + s2 * 8);
                 }
+                __builtin_amdgcn_s_setprio(1);  // a wave inside its MFMA pair wins issue arbitration over its SIMD neighbour's
+                                                // staging work (measured: -2 % at K = 256; on the third MFMA too: 0)
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++) {
                     acc[rt][nt] = MFMA16(a_hi, w_hi[nt][s], s == 0 ? biasv[nt] : acc[rt][nt]);
                     acc[rt][nt] = MFMA16(a_hi, w_lo[nt][s], acc[rt][nt]);
                 }
+                __builtin_amdgcn_s_setprio(0);
                 SB();
                 if (j == 0) load_meta(it_m, meta_m);  // M(t+3); issued behind the first MFMAs so nothing waits on it
                 CHUNKS();
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++)
                     acc[rt][nt] = MFMA16(a_lo, w_hi[nt][s], acc[rt][nt]);
+
                 a_hi = n_hi;
                 a_lo = n_lo;
                 if (j == C::NG / 2 - 1) {
