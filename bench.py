@@ -98,12 +98,21 @@ def cpu_baseline(S, seed, n_cells_sample, n_query_sample):
     OM.retrieve_topk_f64(c, q, TOPK)
     t_retr = time.perf_counter() - t0
     total = CELLS_PER_GPU * t_cell + QUERIES_PER_GPU * t_query + t_retr
+    # the same cell encoder on ONE thread (SURVEY 8(d) asks for both), on a 16-cell slice
+    torch.set_num_threads(1)
+    n1 = min(16, n_cells_sample)
+    t0 = time.perf_counter()
+    a, b = cell_ptr[0], cell_ptr[n1]
+    om.encode_objects_packed(xyz[a:b], rgb[a:b], center[a:b], mean_rgb[a:b], cell_ptr[: n1 + 1] - a)
+    t_cell_1 = (time.perf_counter() - t0) / n1
+    torch.set_num_threads(cores)
     return {
         "value": (CELLS_PER_GPU + QUERIES_PER_GPU) / total, "unit": "cells+queries/s", "cores": cores, "kind": "port",
         "sample": (f"{n_cells_sample} cells + {n_query_sample} queries encoded by the CPU oracle (torch "
                    f"{cores} threads, one PointNet++ forward per cell), full {QUERIES_PER_GPU}x{CELLS_PER_GPU} float64 "
                    "NumPy retrieval; extrapolated linearly to 12000 cells + 1000 queries"),
         "cells_per_s": 1.0 / t_cell, "queries_per_s": 1.0 / t_query, "retrieval_qps": QUERIES_PER_GPU / t_retr,
+        "cells_per_s_single_thread": 1.0 / t_cell_1,
     }
 
 
