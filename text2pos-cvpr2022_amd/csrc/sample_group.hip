@@ -70,7 +70,7 @@ __device__ __forceinline__ void wave_argmax(float& d, int& idx) {
 template <int PPL>  // points per lane: ceil(n_d / 64)
 __device__ void level(const float* px, const float* py, const float* pz, int n_d, int n_c, float r2,
                       uint8_t* sel, float* qx, float* qy, float* qz, uint8_t* nbr_lds, uint8_t* cnt_lds,
-                      uint16_t* rows_lds, int self_loops, int* n_rows_out) {
+                      uint16_t* __restrict__ rows_out, int self_loops, int* n_rows_out) {
     const int lane = threadIdx.x;
     // Lane l owns the CONTIGUOUS points [l*PPL, (l+1)*PPL): ascending index order is then lane-major, so "ties -> lowest
     // index" is "lowest lane, then lowest j" (one ballot + s_ff1 instead of a second wave reduction), and a hit's rank
@@ -125,14 +125,14 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
             if (hit[j] && pos < kMaxNbr) {
                 const int i = lane * PPL + j;
                 if (nbr_lds) nbr_lds[c * kMaxNbr + pos] = (uint8_t)i;
-                rows_lds[base + pos] = (uint16_t)((c << 8) | i);
+                if (rows_out) rows_out[base + pos] = (uint16_t)((c << 8) | i);
             }
             pos += hit[j] ? 1 : 0;
         }
         const int kept = count < kMaxNbr ? count : kMaxNbr;
         if (lane == 0) {
             if (nbr_lds) cnt_lds[c] = (uint8_t)kept;
-            if (self_loops) rows_lds[base + kept] = (uint16_t)(((c | 0x80) << 8) | c);
+            if (self_loops && rows_out) rows_out[base + kept] = (uint16_t)(((c | 0x80) << 8) | c);
         }
         base += kept + (self_loops ? 1 : 0);
         if (c + 1 < n_c) {  // uniform
@@ -142,14 +142,14 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
         }
     }
     // pad the list to a multiple of 4 rows with the "no row" marker, so that consumers may fetch 4 rows per load
-    if (lane < 4) rows_lds[base + lane] = 0xFFFF;
+    if (rows_out && lane < 4 && base + lane < n_c * (kMaxNbr + 1)) rows_out[base + lane] = 0xFFFF;
     *n_rows_out = base;
     __syncthreads();
 }
 
 // Centroid table of one level + the [xyz | 0 x 29] tail of the SA output rows (was k_pos_table): H/4 lanes per centroid row,
 // the lane's 4 output columns of W1p in registers, 16-byte stores.  Same arithmetic order as the stand-alone kernel.
-__device__ __forceinline__ void emit_centroid_table(const float* qx, const float* qy, const float* qz, int n_c,
+__device__ __attribute__((noinline)) void emit_centroid_table(const float* qx, const float* qy, const float* qz, int n_c,
                                                     const float* __restrict__ wp, int H, float* __restrict__ out,
                                                     float* __restrict__ tail, int ld_tail, int tail_col0) {
     const int lane = threadIdx.x;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void emit_centroid_table(const float* qx, const float
 }
 
 // SA1 layer-1 point table of one object (was k_sa1_point_table): A_1[j] = W1 [rgb_j | xyz_j] + b1
-__device__ __forceinline__ void emit_point_table(const float* px, const float* py, const float* pz,
+__device__ __attribute__((noinline)) void emit_point_table(const float* px, const float* py, const float* pz,
                                                  const float* __restrict__ rgb, int n_pts, const float* __restrict__ w,
                                                  const float* __restrict__ bias, int H, float* __restrict__ out) {
     const int lane = threadIdx.x;
@@ -192,19 +192,18 @@ __device__ __forceinline__ void emit_point_table(const float* px, const float* p
     }
 }
 
-__global__ __launch_bounds__(64, 3) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
+__global__ __launch_bounds__(64, 4) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
                                                      float r0, float r1, float r2, GroupTables gt) {
-    // dynamic LDS: coordinates of the 4 levels | FPS selection | compact rows | (only when the neighbour table is
-    // wanted: nbr + cnt) -- the production path leaves the table out, which lifts occupancy from 8 to 11 waves per CU
+    // dynamic LDS: coordinates of the 4 levels | FPS selection | (only when the neighbour table is wanted: nbr + cnt);
+    // 5.9 KB in the production path, so the register count (<= 128) sets the occupancy: 16 waves per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* p0 = (float*)smem;                     // [3][256]
     float* p1 = p0 + 3 * kMaxPts;                 // [3][128]
     float* p2 = p1 + 3 * (kMaxPts / 2);           // [3][64]
     float* p3 = p2 + 3 * (kMaxPts / 4);           // [3][32]
     uint8_t* sel_lds = (uint8_t*)(p3 + 3 * (kMaxPts / 8));                 // [128]
-    uint16_t* rows_lds = (uint16_t*)(sel_lds + kMaxPts / 2);                 // [128*33 + 4]
     const bool want_nbr = gt.nbr[0] != nullptr;
-    uint8_t* nbr_lds = want_nbr ? (uint8_t*)(rows_lds + (kMaxPts / 2) * (kMaxNbr + 1) + 4) : nullptr;  // [128*32]
+    uint8_t* nbr_lds = want_nbr ? sel_lds + kMaxPts / 2 : nullptr;  // [128*32]
     uint8_t* cnt_lds = want_nbr ? nbr_lds + (kMaxPts / 2) * kMaxNbr : nullptr;                       // [128]
     const int lane = threadIdx.x;
     for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
@@ -235,27 +234,19 @@ __global__ __launch_bounds__(64, 3) void k_sample_group(const float* __restrict_
             }
             __syncthreads();
             int n_rows = 0;
+            // the compact row list goes straight to HBM (2-byte stores from the hit lanes): staging it in LDS cost 8.4 KB per
+            // wave and capped the occupancy at 11 waves per CU, and this kernel is latency-bound (half the waves: +64 % time)
+            uint16_t* g_rows16 = gt.rows[l] ? gt.rows[l] + o * (int64_t)(n_c * (kMaxNbr + 1)) : nullptr;
             if (n_d > 128)
                 level<4>(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
-                         pin[l + 1][2], nbr_lds, cnt_lds, rows_lds, gt.self_loops, &n_rows);
+                         pin[l + 1][2], nbr_lds, cnt_lds, g_rows16, gt.self_loops, &n_rows);
             else if (n_d > 64)
                 level<2>(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
-                         pin[l + 1][2], nbr_lds, cnt_lds, rows_lds, gt.self_loops, &n_rows);
+                         pin[l + 1][2], nbr_lds, cnt_lds, g_rows16, gt.self_loops, &n_rows);
             else
                 level<1>(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
-                         pin[l + 1][2], nbr_lds, cnt_lds, rows_lds, gt.self_loops, &n_rows);
-            if (gt.rows[l] != nullptr) {
-                const int maxr = n_c * (kMaxNbr + 1);
-                uint16_t* g_rows16 = gt.rows[l] + o * (int64_t)maxr;
-                if ((maxr & 1) == 0) {  // every object's list starts 4-byte aligned: copy two rows per store
-                    uint32_t* g_rows = (uint32_t*)g_rows16;
-                    const int n_copy = n_rows + 4 < maxr ? n_rows + 4 : maxr;  // includes the 0xFFFF padding
-                    for (int i = lane; i < (n_copy + 1) / 2; i += 64) g_rows[i] = ((const uint32_t*)rows_lds)[i];
-                } else {
-                    for (int i = lane; i < n_rows; i += 64) g_rows16[i] = rows_lds[i];
-                }
-                if (lane == 0) gt.n_rows[l][o] = (uint16_t)n_rows;
-            }
+                         pin[l + 1][2], nbr_lds, cnt_lds, g_rows16, gt.self_loops, &n_rows);
+            if (g_rows16 != nullptr && lane == 0) gt.n_rows[l][o] = (uint16_t)n_rows;
             if (gt.B[l] != nullptr) {
                 const float* wpl = gt.wp[l];
                 asm volatile("" : "+s"(wpl));
@@ -295,8 +286,7 @@ int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float 
                       "sample_group: point table: H=%d", gt.H1);
     T2P_CHECK_ARG(!want_nbr || (gt.nbr[1] && gt.nbr[2] && gt.cnt[0] && gt.cnt[1] && gt.cnt[2]),
                   "sample_group: neighbour tables must be given for all levels or none");
-    size_t lds = sizeof(float) * 3 * (kMaxPts + kMaxPts / 2 + kMaxPts / 4 + kMaxPts / 8) + kMaxPts / 2 +
-                 sizeof(uint16_t) * ((kMaxPts / 2) * (kMaxNbr + 1) + 4);
+    size_t lds = sizeof(float) * 3 * (kMaxPts + kMaxPts / 2 + kMaxPts / 4 + kMaxPts / 8) + kMaxPts / 2;
     if (want_nbr) lds += (kMaxPts / 2) * kMaxNbr + kMaxPts / 2;
     hipLaunchKernelGGL(k_sample_group, dim3((unsigned)grid), dim3(64), lds, st, xyz, n_obj, n_pts, radius[0],
                        radius[1], radius[2], gt);
