@@ -192,10 +192,11 @@ __device__ __attribute__((noinline)) void emit_point_table(const float* px, cons
     }
 }
 
-__global__ __launch_bounds__(64, 4) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
+// 6 waves per SIMD (80 registers, some spills) measured fastest: 4 -> 3.26, 5 -> 3.08, 6 -> 2.85, 7 -> 3.5, 8 -> 3.16 ms / 3k cells
+__global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
                                                      float r0, float r1, float r2, GroupTables gt) {
     // dynamic LDS: coordinates of the 4 levels | FPS selection | (only when the neighbour table is wanted: nbr + cnt);
-    // 5.9 KB in the production path, so the register count (<= 128) sets the occupancy: 16 waves per CU
+    // 5.9 KB in the production path, so the register count sets the occupancy
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* p0 = (float*)smem;                     // [3][256]
     float* p1 = p0 + 3 * kMaxPts;                 // [3][128]
