@@ -91,6 +91,7 @@ class SuperGlueMatch(nn.Module):
                                     "sinkhorn_iterations": self.sinkhorn_iters, "match_threshold": MATCH_THRESHOLD})
         self._opack = None
         self._mpack = None
+        self._side = None
 
     # ---- cached weight images -------------------------------------------------------------------------------------
     def _object_pack(self):
@@ -143,13 +144,22 @@ class SuperGlueMatch(nn.Module):
                                    radius=self.object_encoder.pointnet.radii, precision=self.precision,
                                    class_idx=class_idx, color_idx=color_idx, objects_only=True)
         dev = self.device
+        # the hint sentences do not depend on the objects: their (latency-bound) biLSTM runs on a second HIP stream
+        # underneath the object encoder
+        main = torch.cuda.current_stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            if tokenised:
+                hint = self.language_encoder.encode_tokens(hints[0], hints[1], normalize=True).view(b, n_hints, d)
+            else:
+                flat = [s for h in hints for s in h]
+                hint = self.language_encoder(flat, normalize=True).view(b, n_hints, d)  # :94-97
         obj = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, torch.from_numpy(cp).to(dev), self._object_pack(), cfg)
         obj = ops.rownorm(obj).view(b, n_obj, d)                                    # F.normalize (:103)
-        if tokenised:
-            hint = self.language_encoder.encode_tokens(hints[0], hints[1], normalize=True).view(b, n_hints, d)
-        else:
-            flat = [s for h in hints for s in h]
-            hint = self.language_encoder(flat, normalize=True).view(b, n_hints, d)  # :94-97
+        main.wait_stream(self._side)
+        hint.record_stream(main)
         out = ops.match(obj.contiguous(), hint.contiguous(), self._match_pack(), self.sinkhorn_iters, MATCH_THRESHOLD)
         return MatchOutputs(P=out["P"], matches0=out["matches0"], matches1=out["matches1"], offsets=out["offsets"],
                             matching_scores0=out["matching_scores0"], matching_scores1=out["matching_scores1"],
