@@ -2,7 +2,8 @@
 
 CPU restatement of the Text2Pos coarse cell-retrieval forward path
 (/root/reference: models/cell_retrieval.py, models/object_encoder.py,
-models/pointcloud/pointnet2.py, models/modules.py, training/coarse.py:100-140).
+models/pointcloud/pointnet2.py, models/modules.py, training/coarse.py:100-140) and of the fine
+stage (models/superglue_matcher.py, models/superglue.py).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package -- as the checker, never as the thing measured or shipped.  The
@@ -22,6 +23,9 @@ PARITY STATUS
     (torch_geometric / torch_cluster, version un-pinned in requirements.txt:9-10);
     oracle/pyg_restated.py restates their published algorithms with the
     nondeterministic choices pinned (see oracle/primitives.c header).
+  * fine stage (oracle/fine.py: SuperGlue matcher, offsets, get_pos_in_cell): PINNED -- tests/golden/fine.npz holds
+    outputs of the reference's own models/superglue.py::SuperGlue (pure torch, executed unmodified) and of its
+    SuperGlueMatch.forward glue; the object encoder underneath shares the primitives' "unpinned" status above.
 """
 import ctypes
 import os
