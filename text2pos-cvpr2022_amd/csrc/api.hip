@@ -90,7 +90,7 @@ struct CellWs {
     GroupTables gt;
     float *A[3], *B[3], *F[3];
     float *gh, *f0, *f1, *f2, *cat, *emb, *embn, *P, *Q, *x1, *pool, *l1, *l2;
-    int32_t *knn, *seg_ptr, *first, *prefix, *bounds;
+    int32_t *knn, *seg_ptr, *first, *prefix[3], *bounds[3];
 };
 
 // Carve the per-chunk workspace (n objects, nb cells).  With base == nullptr this only measures.
@@ -123,8 +123,10 @@ size_t carve(Bump& b, int64_t n, int64_t nb, const t2p_cell_config& cfg, CellWs*
     w.x1 = b.take<float>(n * D);
     w.knn = b.take<int32_t>(n * (size_t)cfg.knn_k);
     w.first = b.take<int32_t>(n);
-    w.prefix = b.take<int32_t>(n + 1);
-    w.bounds = b.take<int32_t>(1024 + 1);
+    for (int l = 0; l < 3; l++) {
+        w.prefix[l] = b.take<int32_t>(n + 1);
+        w.bounds[l] = b.take<int32_t>(1024 + 1);
+    }
     w.seg_ptr = b.take<int32_t>(nb + 1);
     w.pool = b.take<float>(nb * D);
     w.l1 = b.take<float>(nb * D);
@@ -211,6 +213,16 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         gt.rgb = rgb;
         gt.H1 = Geo::H[0];
         T2P_TRY(launch_sample_group(xyz, n, cfg.n_pts, cfg.radius, gt, st));
+        // the per-centroid row counts of all three levels exist now: cut every level's balanced object ranges at once
+        SaParams bp[3] = {};
+        for (int l = 0; l < 3; l++) {
+            bp[l].n_rows = gt.n_rows[l];
+            bp[l].n_obj = n;
+            bp[l].prefix_ws = ws.prefix[l];
+            bp[l].bounds_ws = ws.bounds[l];
+            bp[l].W_x3 = cfg.precision == 1 ? W.sa_w2_x3[l] : nullptr;
+        }
+        T2P_TRY(launch_sa_balance_levels(bp, Geo::H, Geo::C, st));
     }
 
     // ---- three set-abstraction levels -----------------------------------------------------------------------
@@ -256,8 +268,9 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.n_dense = g.nd[l];
         p.n_cent = g.nc[l];
         p.n_obj = n;
-        p.prefix_ws = ws.prefix;
-        p.bounds_ws = ws.bounds;
+        p.prefix_ws = ws.prefix[l];
+        p.bounds_ws = ws.bounds[l];
+        p.balanced = 1;
         T2P_TRY(launch_ws_sa(H, C, p, st));
     }
     // ---- global abstraction: [x | pos] -> 512 -> 1024, max over the object's 32 points ------------------------

@@ -158,8 +158,12 @@ struct SaParams {
     int64_t n_obj;
     int32_t* prefix_ws;      // [n_obj+1] scratch (tile prefix sums)
     int32_t* bounds_ws;      // [n_workgroups+1] scratch (balanced contiguous object ranges)
+    int balanced;            // 1: bounds_ws was filled by launch_sa_balance_levels for this level's launch shape
 };
 int launch_ws_sa(int H, int C, const SaParams& p, hipStream_t st);
+// One launch that balances all three levels (their row counts are known once k_sample_group has run); fills
+// prefix_ws / bounds_ws of every p[l] for the launch shape launch_ws_sa(H[l], C[l], p[l]) will use.
+int launch_sa_balance_levels(const SaParams p[3], const int H[3], const int C[3], hipStream_t st);
 
 // ---- lstm.hip ---------------------------------------------------------------------------------------------
 int launch_bilstm_impl(const float* gate_table /*[2][V][4D]*/, const float* whh /*[2][D][4D] k-major*/,

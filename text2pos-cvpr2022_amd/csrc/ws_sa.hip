@@ -41,8 +41,8 @@ struct SaCfg {
 };
 
 // Tile-count prefix sums over the objects and balanced contiguous ranges for n_wg workgroups.  One block.
-__global__ __launch_bounds__(1024) void k_balance(const uint16_t* __restrict__ n_rows, int n, int tile_rows, int n_wg,
-                                                  int32_t* __restrict__ prefix, int32_t* __restrict__ bounds) {
+__device__ __forceinline__ void balance_body(const uint16_t* __restrict__ n_rows, int n, int tile_rows, int n_wg,
+                                             int32_t* __restrict__ prefix, int32_t* __restrict__ bounds) {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
     const int per = (n + 1023) / 1024;
@@ -75,6 +75,23 @@ __global__ __launch_bounds__(1024) void k_balance(const uint16_t* __restrict__ n
         }
         bounds[b] = b == n_wg ? n : l;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_balance(const uint16_t* __restrict__ n_rows, int n, int tile_rows, int n_wg,
+                                                  int32_t* __restrict__ prefix, int32_t* __restrict__ bounds) {
+    balance_body(n_rows, n, tile_rows, n_wg, prefix, bounds);
+}
+
+struct BalanceJobs {
+    const uint16_t* n_rows[3];
+    int32_t* prefix[3];
+    int32_t* bounds[3];
+    int tile_rows[3], n_wg[3];
+    int n;
+};
+__global__ __launch_bounds__(1024) void k_balance_levels(BalanceJobs j) {  // one block per level
+    const int l = blockIdx.x;
+    balance_body(j.n_rows[l], j.n, j.tile_rows[l], j.n_wg[l], j.prefix[l], j.bounds[l]);
 }
 
 struct BatchIt {  // position in the flattened batch stream of a sub-range
@@ -334,12 +351,12 @@ int launch_sa_cfg(const SaParams& p_in, hipStream_t st, const char* name) {
     int n_wg = num_cus();
     if (n_wg > p_in.n_obj) n_wg = (int)p_in.n_obj;
     const SaParams& p = p_in;
-    {
+    if (!p.balanced) {
         ProfScope ps_("sa_balance", st);
         hipLaunchKernelGGL(k_balance, dim3(1), dim3(1024), 0, st, p.n_rows, (int)p.n_obj, C::TR, n_wg, p.prefix_ws,
                            p.bounds_ws);
+        T2P_CHECK_LAUNCH("sa_balance");
     }
-    T2P_CHECK_LAUNCH("sa_balance");
     ProfScope ps_(name, st);
     hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NT), C::lds_bytes(), st, p);
     T2P_CHECK_LAUNCH("ws_sa");
@@ -354,6 +371,37 @@ int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st
     ProfScope ps_("sa_balance", st);
     hipLaunchKernelGGL(k_balance, dim3(1), dim3(1024), 0, st, p.n_rows, (int)p.n_obj, tile_rows, n_wg, p.prefix_ws,
                        p.bounds_ws);
+    T2P_CHECK_LAUNCH("sa_balance");
+    return 0;
+}
+
+int sa2_launch_shape(int H, int Cout, int64_t n_obj, int* tile_rows, int* n_wg);  // ws_sa2.hip
+
+// tile rows / workgroup count of the kernel launch_ws_sa will pick for (H, Cout)
+static int sa_launch_shape(int H, int Cout, bool x3, int64_t n_obj, int* tile_rows, int* n_wg) {
+    if (x3) return sa2_launch_shape(H, Cout, n_obj, tile_rows, n_wg);
+    int n = num_cus();
+    if (n > n_obj) n = (int)n_obj;
+    *n_wg = n;
+    if (H == 32 && Cout == 64) { *tile_rows = SaCfg<32, 64, 2, 2>::TR; return 0; }
+    if (H == 128 && Cout == 128) { *tile_rows = SaCfg<128, 128, 4, 1>::TR; return 0; }
+    if (H == 256 && Cout == 256) { *tile_rows = SaCfg<256, 256, 8, 1>::TR; return 0; }
+    set_error("ws_sa: no instantiation for H=%d C=%d", H, Cout);
+    return T2P_E_UNSUPPORTED;
+}
+
+int launch_sa_balance_levels(const SaParams p[3], const int H[3], const int C[3], hipStream_t st) {
+    if (p[0].n_obj <= 0) return 0;
+    BalanceJobs j;
+    j.n = (int)p[0].n_obj;
+    for (int l = 0; l < 3; l++) {
+        j.n_rows[l] = p[l].n_rows;
+        j.prefix[l] = p[l].prefix_ws;
+        j.bounds[l] = p[l].bounds_ws;
+        T2P_TRY(sa_launch_shape(H[l], C[l], p[l].W_x3 != nullptr, p[l].n_obj, &j.tile_rows[l], &j.n_wg[l]));
+    }
+    ProfScope ps_("sa_balance", st);
+    hipLaunchKernelGGL(k_balance_levels, dim3(3), dim3(1024), 0, st, j);
     T2P_CHECK_LAUNCH("sa_balance");
     return 0;
 }

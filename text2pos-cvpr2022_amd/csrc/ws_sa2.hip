@@ -441,8 +441,10 @@ int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
     int n_wg = num_cus() * WGS;
     if (n_wg > 1024) n_wg = 1024;
     if (n_wg > p.n_obj) n_wg = (int)p.n_obj;
-    int rc = launch_sa_balance(p, C::TR, n_wg, st);
-    if (rc != 0) return rc;
+    if (!p.balanced) {
+        int rc = launch_sa_balance(p, C::TR, n_wg, st);
+        if (rc != 0) return rc;
+    }
     ProfScope ps_(name, st);
     hipLaunchKernelGGL(kern, dim3(n_wg), dim3(C::NT), C::lds_bytes(), st, p);
     T2P_CHECK_LAUNCH("ws_sa2");
@@ -472,6 +474,24 @@ int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
 }
 
 }  // namespace
+
+// (tile rows, workgroups) of the configuration launch_ws_sa2 uses for (H, Cout): keep in step with the table below
+int sa2_launch_shape(int H, int Cout, int64_t n_obj, int* tile_rows, int* n_wg) {
+    int tr, wgs;
+    if (H == 32 && Cout == 64) { tr = Cfg2<32, 64, 2, 1, 8, 2>::TR; wgs = 2; }
+    else if (H == 128 && Cout == 128) { tr = Cfg2<128, 128, 4, 1, 8, 1>::TR; wgs = 1; }
+    else if (H == 256 && Cout == 256) { tr = Cfg2<256, 256, 8, 1, 8, 1>::TR; wgs = 1; }
+    else {
+        set_error("ws_sa2: no instantiation for H=%d C=%d", H, Cout);
+        return T2P_E_UNSUPPORTED;
+    }
+    int n = num_cus() * wgs;
+    if (n > 1024) n = 1024;
+    if (n > n_obj) n = (int)n_obj;
+    *tile_rows = tr;
+    *n_wg = n;
+    return 0;
+}
 
 int launch_ws_sa2(int H, int Cout, const SaParams& p, hipStream_t st) {
     // SA2: two 4-wave workgroups per CU measured no faster than one 8-wave workgroup (kept: its double-buffered accumulator
