@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 7
+#define T2P_ABI_VERSION 8
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -182,10 +182,14 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
  * raw_xyz, raw_rgb [n_points_total][3] fp32: the raw points of all objects back to back; obj_ptr [n_obj+1] int32 CSR;
  * sample_idx [n_obj][n_pts] int32: per-object LOCAL indices drawn with replacement by the host's seeded generator
  * (T.FixedPoints is random even at evaluation time, evaluation/pipeline.py:290-293 -- the draw stays on the host so that
- * runs are reproducible).  Outputs are exactly the inputs of t2p_encode_cells.
+ * runs are reproducible).  rot_cos_sin: NULL, or [n_obj][2] fp32 (cos, sin) of one angle per object = the training
+ * transform's T.RandomRotate(120, axis=2) between FixedPoints and NormalizeScale (training/coarse.py:192-198):
+ * pos <- pos @ [[c, s, 0], [-s, c, 0], [0, 0, 1]] (PyG 1.7 - 2.0 LinearTransformation; later releases multiply by the
+ * transpose, i.e. the opposite angle -- the same distribution for a symmetric range); the angle is drawn on the host.
+ * Outputs are exactly the inputs of t2p_encode_cells.
  * ---------------------------------------------------------------------------------------------------------- */
 int t2p_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
-                     int64_t n_obj, int32_t n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
+                     const float* rot_cos_sin, int64_t n_obj, int32_t n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
                      t2p_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

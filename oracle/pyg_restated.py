@@ -234,6 +234,19 @@ class NormalizeScale:
         return data
 
 
+class RotateZ:
+    """T.RandomRotate(degrees, axis=2) with the drawn angle made explicit (cos, sin given as fp32 like the matrix tensor
+    PyG builds): pos <- pos @ [[c, s, 0], [-s, c, 0], [0, 0, 1]] (LinearTransformation of PyG 1.7 - 2.0; unverifiable
+    here -- later releases use the transposed matrix, the same distribution for the symmetric range the reference uses)."""
+
+    def __init__(self, cos: float, sin: float):
+        self.matrix = torch.tensor([[cos, sin, 0.0], [-sin, cos, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float)
+
+    def __call__(self, data):
+        data.pos = torch.matmul(data.pos, self.matrix)
+        return data
+
+
 class Compose:
     def __init__(self, ts):
         self.ts = ts

@@ -281,6 +281,16 @@ def test_pack_objects_matches_host_transform_chain(hip_model, oracle_model):
         assert np.abs(got[0][i] - d.pos.numpy()).max() < 2e-6
         assert np.array_equal(got[1][i], d.x.numpy())
         assert np.abs(got[2][i] - o.get_center()).max() < 1e-6 and np.abs(got[3][i] - o.get_color_rgb()).max() < 1e-6
+    # training transform: FixedPoints -> RandomRotate(120, axis=2) -> NormalizeScale (training/coarse.py:192-198)
+    rot = D.draw_rotations(len(flat), 120.0, np.random.default_rng(11))
+    assert rot.shape == (len(flat), 2) and (rot[:, 0] >= np.cos(np.pi * 120 / 180) - 1e-6).all()
+    got_r = [t.cpu().numpy() for t in ops.pack_objects(*_to_dev(raw_xyz, raw_rgb, obj_ptr, sample_idx, rot))]
+    for i, o in enumerate(flat):
+        d = P.Data(x=None, pos=torch.tensor(o.xyz, dtype=torch.float)[sample_idx[i].astype(np.int64)])
+        d = P.Compose([P.RotateZ(float(rot[i, 0]), float(rot[i, 1])), P.NormalizeScale()])(d)
+        assert np.abs(got_r[0][i] - d.pos.numpy()).max() < 2e-6     # fp32 rotation + centring + scaling
+    for k in (1, 2, 3):
+        assert np.array_equal(got_r[k], got[k])                      # colours and the raw-object means do not rotate
     with torch.no_grad():
         a = hip_model.encode_raw_objects(objects, np.random.default_rng(9)).cpu()
         b = hip_model.encode_objects_packed(*_to_dev(*got), cell_ptr).cpu()

@@ -411,3 +411,20 @@ class Net(nn.Module):
         got = IO.load_reference_checkpoint(str(tmp_path / f))
         assert list(got.keys()) == list(want.keys())
         assert all(torch.equal(got[k], want[k]) for k in want)
+
+
+def test_draw_rotations_and_oracle_rotate_z():
+    """Host draw of T.RandomRotate(120, axis=2) + its CPU restatement: unit (cos, sin) rows inside the range, z and the
+    xy norms untouched, and the matrix convention pos @ [[c, s, 0], [-s, c, 0], [0, 0, 1]]."""
+    from oracle import pyg_restated as P
+    from text2pos_amd import data as D
+    rot = D.draw_rotations(500, 120.0, np.random.default_rng(3))
+    assert rot.dtype == np.float32 and rot.shape == (500, 2)
+    assert np.abs((rot ** 2).sum(1) - 1).max() < 1e-6 and rot[:, 0].min() >= -0.5 - 1e-6
+    assert (rot[:, 1] > 0).any() and (rot[:, 1] < 0).any()
+    pos = torch.randn(64, 3)
+    out = P.RotateZ(float(rot[0, 0]), float(rot[0, 1]))(P.Data(pos=pos.clone())).pos
+    assert torch.equal(out[:, 2], pos[:, 2])
+    assert (out[:, :2].norm(dim=1) - pos[:, :2].norm(dim=1)).abs().max() < 1e-5
+    q = P.RotateZ(0.0, 1.0)(P.Data(pos=torch.tensor([[1.0, 0.0, 0.0]]))).pos   # +90 degrees: x axis -> (0, 1, 0)
+    assert torch.allclose(q, torch.tensor([[0.0, 1.0, 0.0]]))

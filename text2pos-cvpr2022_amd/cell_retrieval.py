@@ -114,17 +114,19 @@ class CellRetrievalNetwork(nn.Module):
         return self.encode_objects_packed(to(xyz), to(rgb), to(center), to(mean_rgb), cell_ptr, class_idx=class_idx,
                                           color_idx=color_idx)
 
-    def encode_raw_objects(self, objects, generator: np.random.Generator):
+    def encode_raw_objects(self, objects, generator: np.random.Generator, rotate_degrees: float = None):
         """objects: List[List[Object3d]] with RAW point sets.  The dataloader's per-object transform chain
-        (T.FixedPoints(256) -> T.NormalizeScale, dataloading/kitti360pose/utils.py:99-109) and the per-object means run on
-        the GPU (csrc/small_kernels.hip::k_pack_objects); only the random draw of T.FixedPoints stays on the host."""
-        from .data import flatten_raw_objects
+        (T.FixedPoints(256) [-> T.RandomRotate(rotate_degrees, axis=2), the training transform] -> T.NormalizeScale,
+        dataloading/kitti360pose/utils.py:99-109, training/coarse.py:192-199) and the per-object means run on the GPU
+        (csrc/small_kernels.hip::k_pack_objects); only the random draws stay on the host."""
+        from .data import draw_rotations, flatten_raw_objects
         self._check_forward_only()
         n_pts = int(getattr(self.args, "pointnet_numpoints", 256))
         raw_xyz, raw_rgb, obj_ptr, sample_idx, cell_ptr = flatten_raw_objects(objects, n_pts, generator)
         dev = self.device
         to = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
-        xyz, rgb, center, mean_rgb = ops.pack_objects(to(raw_xyz), to(raw_rgb), to(obj_ptr), to(sample_idx))
+        rot = None if rotate_degrees is None else to(draw_rotations(len(obj_ptr) - 1, rotate_degrees, generator))
+        xyz, rgb, center, mean_rgb = ops.pack_objects(to(raw_xyz), to(raw_rgb), to(obj_ptr), to(sample_idx), rot)
         if "color" not in self.args.use_features:
             rgb.zero_()
         return self.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)

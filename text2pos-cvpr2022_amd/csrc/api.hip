@@ -594,11 +594,11 @@ int t2p_sample_group(const float* xyz, int64_t n_obj, int32_t n_pts, const float
 }
 
 int t2p_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
-                     int64_t n_obj, int32_t n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
+                     const float* rot_cos_sin, int64_t n_obj, int32_t n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
                      t2p_stream_t stream) {
     T2P_CHECK_ARG(raw_xyz && raw_rgb && obj_ptr && sample_idx && xyz && rgb && center && mean_rgb, "pack_objects: NULL argument");
     T2P_CHECK_ARG(n_obj >= 0 && n_pts >= 1, "pack_objects: bad sizes");
-    return launch_pack_objects(raw_xyz, raw_rgb, obj_ptr, sample_idx, n_obj, n_pts, xyz, rgb, center, mean_rgb,
+    return launch_pack_objects(raw_xyz, raw_rgb, obj_ptr, sample_idx, rot_cos_sin, n_obj, n_pts, xyz, rgb, center, mean_rgb,
                                (hipStream_t)stream);
 }
 

@@ -177,9 +177,13 @@ __global__ __launch_bounds__(256) void k_mlp3_norm(const float* __restrict__ in3
 // (T.FixedPoints: the indices come from the host's seeded generator), apply T.NormalizeScale (subtract the mean of the
 // SAMPLED points, scale by 0.999999 / max|.|) and emit Object3d.get_center() / get_color_rgb() (means over ALL raw
 // points, accumulated in float64 like NumPy).  One wavefront per object.
+// rot (optional, [n_obj][2] = cos, sin of the object's angle): T.RandomRotate(deg, axis=2) of the training transform
+// (training/coarse.py:192-198), applied between the resampling and NormalizeScale: pos <- pos @ [[c, s, 0], [-s, c, 0],
+// [0, 0, 1]].  The angle is drawn on the host like the FixedPoints indices.
 __global__ __launch_bounds__(256) void k_pack_objects(const float* __restrict__ raw_xyz, const float* __restrict__ raw_rgb,
                                                       const int32_t* __restrict__ obj_ptr,
-                                                      const int32_t* __restrict__ sample_idx, int64_t n_obj, int n_pts,
+                                                      const int32_t* __restrict__ sample_idx,
+                                                      const float* __restrict__ rot, int64_t n_obj, int n_pts,
                                                       float* __restrict__ xyz, float* __restrict__ rgb,
                                                       float* __restrict__ center, float* __restrict__ mean_rgb) {
     const int lane = threadIdx.x & 63;
@@ -201,13 +205,27 @@ __global__ __launch_bounds__(256) void k_pack_objects(const float* __restrict__ 
     }
     if (lane < 3) center[o * 3 + lane] = (float)(acc[lane] / (double)m);
     else if (lane < 6) mean_rgb[o * 3 + lane - 3] = (float)(acc[lane] / (double)m);
-    // resample + NormalizeScale
+    // resample (+ rotate) + NormalizeScale
+    const bool rotate = rot != nullptr;
+    const float rc = rotate ? rot[o * 2] : 1.f, rs = rotate ? rot[o * 2 + 1] : 0.f;
+    auto point = [&](int i, float& x, float& y, float& z) {
+        const int j = lo + sample_idx[o * n_pts + i];
+        x = raw_xyz[(int64_t)j * 3];
+        y = raw_xyz[(int64_t)j * 3 + 1];
+        z = raw_xyz[(int64_t)j * 3 + 2];
+        if (rotate) {  // row vector times the matrix, terms added in column order like the fp32 matmul
+            const float xr = x * rc + y * -rs, yr = x * rs + y * rc;
+            x = xr;
+            y = yr;
+        }
+    };
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int i = lane; i < n_pts; i += 64) {
-        const int j = lo + sample_idx[o * n_pts + i];
-        sx += raw_xyz[(int64_t)j * 3 + 0];
-        sy += raw_xyz[(int64_t)j * 3 + 1];
-        sz += raw_xyz[(int64_t)j * 3 + 2];
+        float x, y, z;
+        point(i, x, y, z);
+        sx += x;
+        sy += y;
+        sz += z;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -218,9 +236,9 @@ __global__ __launch_bounds__(256) void k_pack_objects(const float* __restrict__ 
     const float mx = sx / (float)n_pts, my = sy / (float)n_pts, mz = sz / (float)n_pts;
     float amax = 0.f;
     for (int i = lane; i < n_pts; i += 64) {
-        const int j = lo + sample_idx[o * n_pts + i];
-        amax = fmaxf(amax, fmaxf(fabsf(raw_xyz[(int64_t)j * 3] - mx),
-                                 fmaxf(fabsf(raw_xyz[(int64_t)j * 3 + 1] - my), fabsf(raw_xyz[(int64_t)j * 3 + 2] - mz))));
+        float x, y, z;
+        point(i, x, y, z);
+        amax = fmaxf(amax, fmaxf(fabsf(x - mx), fmaxf(fabsf(y - my), fabsf(z - mz))));
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
@@ -229,9 +247,11 @@ __global__ __launch_bounds__(256) void k_pack_objects(const float* __restrict__ 
         const int j = lo + sample_idx[o * n_pts + i];
         float* q = xyz + (o * n_pts + i) * 3;
         float* c = rgb + (o * n_pts + i) * 3;
-        q[0] = (raw_xyz[(int64_t)j * 3] - mx) * scale;
-        q[1] = (raw_xyz[(int64_t)j * 3 + 1] - my) * scale;
-        q[2] = (raw_xyz[(int64_t)j * 3 + 2] - mz) * scale;
+        float x, y, z;
+        point(i, x, y, z);
+        q[0] = (x - mx) * scale;
+        q[1] = (y - my) * scale;
+        q[2] = (z - mz) * scale;
         c[0] = raw_rgb[(int64_t)j * 3];
         c[1] = raw_rgb[(int64_t)j * 3 + 1];
         c[2] = raw_rgb[(int64_t)j * 3 + 2];
@@ -293,12 +313,12 @@ int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const fl
 }
 
 int launch_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
-                        int64_t n_obj, int n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
+                        const float* rot, int64_t n_obj, int n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
                         hipStream_t st) {
     if (n_obj == 0) return 0;
     ProfScope ps_("pack_objects", st);
     hipLaunchKernelGGL(k_pack_objects, dim3((unsigned)((n_obj + 3) / 4)), dim3(256), 0, st, raw_xyz, raw_rgb, obj_ptr,
-                       sample_idx, n_obj, n_pts, xyz, rgb, center, mean_rgb);
+                       sample_idx, rot, n_obj, n_pts, xyz, rgb, center, mean_rgb);
     T2P_CHECK_LAUNCH("pack_objects");
     return 0;
 }

@@ -17,6 +17,10 @@
 #ifndef T2P_TRACE
 #define T2P_TRACE 0
 #endif
+// T2P_ABL (development only, results are wrong): 1 = no A_j gathers, 2 = no B_i gathers, 4 = no atomics, 8 = no third MFMA
+#ifndef T2P_ABL
+#define T2P_ABL 0
+#endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #include "t2p_common.h"
 
@@ -74,6 +78,10 @@ __device__ __forceinline__ float sub_half(float v, fp16x2 h) {
     else
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
     return r;
+}
+
+__device__ __forceinline__ void abl_keep(const f32x16& v, uint32_t a, const void* q) {  // T2P_ABL: keeps the operands live
+    asm volatile("" ::"v"(v), "v"(a), "v"(q));
 }
 
 struct BatchIt {
@@ -193,8 +201,16 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             const uint32_t srow = (d & 0x80) ? (sb0 + src) : (g * (uint32_t)p.n_dense + src);
             {
                 // 32-bit BYTE offsets from the uniform table bases (checked by the launcher): SGPR base + VGPR offset loads
-                sa[k] = *(const f32x4*)((const char*)p.A + (srow * (uint32_t)(K * 4) + c4b));
-                sb[k] = *(const f32x4*)((const char*)p.Bc + ((g * (uint32_t)nc + dl) * (uint32_t)(K * 4) + c4b));
+                if constexpr (T2P_ABL & 1) {
+                    const float f = __uint_as_float((srow * (uint32_t)(K * 4) + c4b) | 0x3f000000u);
+                    sa[k] = f32x4{f, f, f, f};
+                } else
+                    sa[k] = *(const f32x4*)((const char*)p.A + (srow * (uint32_t)(K * 4) + c4b));
+                if constexpr (T2P_ABL & 2) {
+                    const float f = __uint_as_float(((g * (uint32_t)nc + dl) * (uint32_t)(K * 4) + c4b) | 0x3e000000u);
+                    sb[k] = f32x4{f, f, f, f};
+                } else
+                    sb[k] = *(const f32x4*)((const char*)p.Bc + ((g * (uint32_t)nc + dl) * (uint32_t)(K * 4) + c4b));
             }
             if (c4 == 0) dstl[dbuf * C::TR + rgrp + k] = (uint16_t)((pad ? (uint32_t)nc : dl) * (uint32_t)(N * 4));
         };
@@ -276,6 +292,10 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         auto atomics = [&](const f32x16 (&v)[DEFER ? RT : 1][DEFER ? C::NTW : 1], const uint2 (&four)[RT][4], int abuf,
                            int e0, int e1) {
             int* accb = acc_lds + abuf * C::ACC_INTS;
+            if constexpr (T2P_ABL & 4) {
+                if (e0 == 0) abl_keep(v[0][0], four[0][0].x, accb);
+                return;
+            }
 #pragma unroll
             for (int idx = e0; idx < e1; idx++) {
                 const int rt = idx / (C::NTW * 16), nt = (idx / 16) % C::NTW, e = idx % 16;
@@ -340,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
                 SB();
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++)
-                    acc[rt][nt] = MFMA16(a_lo, w_hi[nt][s], acc[rt][nt]);
+                    if constexpr (!(T2P_ABL & 8)) acc[rt][nt] = MFMA16(a_lo, w_hi[nt][s], acc[rt][nt]);
 
                 a_hi = n_hi;
                 a_lo = n_lo;
@@ -376,10 +396,14 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
 #pragma unroll
                     for (int nt = 0; nt < C::NTW; nt++) {
                         char* col = (char*)(accb + wn * C::NTW * 32 + nt * 32 + l31);
+                        if constexpr (T2P_ABL & 4) {
+                            abl_keep(acc[rt][nt], four[rt][0].x, col);
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 16; e++) {
-                            const uint32_t pair = (e & 2) ? four[rt][e >> 2].y : four[rt][e >> 2].x;
-                            atomicMax((int*)(col + ((e & 1) ? (pair >> 16) : (pair & 0xFFFFu))), __float_as_int(acc[rt][nt][e]));
+                            for (int e = 0; e < 16; e++) {
+                                const uint32_t pair = (e & 2) ? four[rt][e >> 2].y : four[rt][e >> 2].x;
+                                atomicMax((int*)(col + ((e & 1) ? (pair >> 16) : (pair & 0xFFFFu))), __float_as_int(acc[rt][nt][e]));
+                            }
                         }
                     }
                 }

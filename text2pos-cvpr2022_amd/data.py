@@ -199,3 +199,10 @@ def flatten_raw_objects(objects: List[List[Object3d]], n_pts: int, generator: np
     cell_ptr = np.zeros(len(objects) + 1, dtype=np.int32)
     cell_ptr[1:] = np.cumsum([len(o) for o in objects])
     return raw_xyz, raw_rgb, obj_ptr, sample_idx, cell_ptr
+
+
+def draw_rotations(n_obj: int, degrees: float, generator: np.random.Generator) -> np.ndarray:
+    """Host draw of T.RandomRotate(degrees, axis=2) (training/coarse.py:196): one angle ~ U(-degrees, degrees) per
+    object, returned as [n_obj, 2] fp32 (cos, sin) -- the values PyG puts into its fp32 rotation matrix."""
+    ang = np.pi * generator.uniform(-abs(degrees), abs(degrees), n_obj) / 180.0
+    return np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)

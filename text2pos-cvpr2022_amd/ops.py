@@ -269,9 +269,10 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
     return (out, trace) if want_trace else out
 
 
-def pack_objects(raw_xyz, raw_rgb, obj_ptr, sample_idx):
-    """Device-side FixedPoints gather + NormalizeScale + per-object means.  raw_xyz/raw_rgb [Np,3] fp32, obj_ptr [Nobj+1]
-    int32, sample_idx [Nobj,P] int32 (local indices).  Returns (xyz [Nobj,P,3], rgb [Nobj,P,3], center, mean_rgb)."""
+def pack_objects(raw_xyz, raw_rgb, obj_ptr, sample_idx, rot=None):
+    """Device-side FixedPoints gather (+ RandomRotate about z) + NormalizeScale + per-object means.  raw_xyz/raw_rgb
+    [Np,3] fp32, obj_ptr [Nobj+1] int32, sample_idx [Nobj,P] int32 (local indices), rot None or [Nobj,2] fp32 (cos, sin
+    of each object's angle, data.draw_rotations).  Returns (xyz [Nobj,P,3], rgb [Nobj,P,3], center, mean_rgb)."""
     _need(raw_xyz, "raw_xyz", torch.float32, 2)
     dev = raw_xyz.device
     _need(raw_rgb, "raw_rgb", torch.float32, 2, dev)
@@ -280,11 +281,16 @@ def pack_objects(raw_xyz, raw_rgb, obj_ptr, sample_idx):
     n_obj, n_pts = sample_idx.shape
     if obj_ptr.numel() != n_obj + 1 or tuple(raw_rgb.shape) != tuple(raw_xyz.shape) or raw_xyz.shape[1] != 3:
         raise RuntimeError("pack_objects: inconsistent shapes")
+    if rot is not None:
+        _need(rot, "rot", torch.float32, 2, dev)
+        if tuple(rot.shape) != (n_obj, 2):
+            raise RuntimeError("pack_objects: rot must be [n_obj, 2]")
     xyz = torch.empty((n_obj, n_pts, 3), dtype=torch.float32, device=dev)
     rgb = torch.empty((n_obj, n_pts, 3), dtype=torch.float32, device=dev)
     center = torch.empty((n_obj, 3), dtype=torch.float32, device=dev)
     mean_rgb = torch.empty((n_obj, 3), dtype=torch.float32, device=dev)
-    L.check(L.lib().t2p_pack_objects(_ptr(raw_xyz), _ptr(raw_rgb), _ptr(obj_ptr), _ptr(sample_idx), n_obj, n_pts,
+    L.check(L.lib().t2p_pack_objects(_ptr(raw_xyz), _ptr(raw_rgb), _ptr(obj_ptr), _ptr(sample_idx),
+                                     _ptr(rot) if rot is not None else None, n_obj, n_pts,
                                      _ptr(xyz), _ptr(rgb), _ptr(center), _ptr(mean_rgb), _stream(dev)), "t2p_pack_objects")
     return xyz, rgb, center, mean_rgb
 
