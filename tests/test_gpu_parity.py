@@ -343,6 +343,27 @@ def test_encode_cells_chunking_is_invisible(hip_model):
     assert torch.equal(one, many)
 
 
+def test_encode_cells_ragged_extremes_vs_oracle(hip_model, oracle_model):
+    """Cell sizes the synthetic benchmark never draws: single-object cells (kNN k = min(8, n) = 1, the self loop is the
+    only graph edge), a cell of 90 objects (more than one 64-row tile of the kNN / cell-graph kernels) between them, and
+    an empty batch.  The reference has no upper bound on a cell's object count (dataloading/kitti360pose/cells.py)."""
+    from text2pos_amd import synthetic as S
+    sizes = [1, 90, 1, 2, 37]
+    xyz, rgb, center, mean_rgb = S.make_objects(77, 0, sum(sizes))
+    cell_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    with torch.no_grad():
+        got = hip_model.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr).cpu()
+        chunked = hip_model.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr, chunk_objects=8).cpu()
+    want = oracle_model.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)
+    assert got.shape == (len(sizes), 256)
+    assert (got - want).abs().max().item() < TOL
+    assert torch.equal(got, chunked)            # a cell larger than the chunk budget still travels whole
+    with torch.no_grad():
+        none = hip_model.encode_objects_packed(*_to_dev(xyz[:0], rgb[:0], center[:0], mean_rgb[:0]),
+                                               np.zeros(1, dtype=np.int32))
+    assert tuple(none.shape) == (0, 256)
+
+
 def test_encode_cells_full_size_properties(hip_model):
     """Size-independent properties at a BASELINE-sized slice (3,000 cells = 48 k objects, several internal chunks and
     every workgroup of the persistent kernels busy): unit norms, bit-determinism, chunking invisible, cells independent

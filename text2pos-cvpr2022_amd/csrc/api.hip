@@ -481,6 +481,8 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
     hipStream_t st = (hipStream_t)stream;
     T2P_TRY(check_cfg(cfg));
     T2P_CHECK_ARG(w != nullptr && cell_ptr_host != nullptr && cell_ptr != nullptr, "encode_cells: NULL argument");
+    T2P_CHECK_ARG(n_cells >= 0 && n_obj >= 0, "encode_cells: negative size");
+    if (n_cells == 0) return 0;  // an empty batch has no output rows (and its buffers may be NULL)
     if (cfg->objects_only)
         T2P_CHECK_ARG(trace != nullptr && trace->obj_emb != nullptr, "encode_cells: objects_only needs trace->obj_emb");
     else
@@ -493,8 +495,6 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
                           w->sa_w1_x3[1] && w->sa_w1_x3[2] &&
                           w->ga_w1_x3 && w->ga_w2_x3,
                       "encode_cells: precision = f16x3 needs the packed *_x3 weight images");
-    T2P_CHECK_ARG(n_cells >= 0 && n_obj >= 0, "encode_cells: negative size");
-    if (n_cells == 0) return 0;
     T2P_CHECK_ARG(cell_ptr_host[0] == 0 && cell_ptr_host[n_cells] == n_obj,
                   "encode_cells: cell_ptr must start at 0 and end at n_obj=%lld (got %d..%d)", (long long)n_obj,
                   cell_ptr_host[0], cell_ptr_host[n_cells]);
