@@ -75,18 +75,19 @@ __global__ __launch_bounds__(NT, 2) void k_ga2(WsParams p, int n_slices) {
     // traffic beside the operand reads; the __syncthreads() that ends the tile drains it (vmcnt(0)).  Measured against
     // register staging (8 global_load_dwordx4 + 8 ds_write_b128 per thread, written in the second half of the k loop):
     // 15.3 vs 15.8 ms per 12k cells (written in the first half: 16.1).
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gl_void;
+    auto dma_piece = [&](int64_t g, int buf, int it) {
+        const int q = it * (NT / 64) + wave;  // 64 plane rows over 8 waves
+        const int pl = q >> 5, row = q & 31;
+        const _Float16* base = (const _Float16*)(pl ? p.A_lo : p.A_hi);
+        const _Float16* src = base + (g * 32 + row) * (int64_t)p.lda + lane * 8;
+        _Float16* dst = tile + buf * TILE_HALVES + pl * PLANE + row * LDHH;  // wave-uniform; the lane's 16 bytes follow
+        __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst, 16, 0, 0);
+    };
     auto dma_tile = [&](int64_t g, int buf) {
-        typedef __attribute__((address_space(3))) void lds_void;
-        typedef const __attribute__((address_space(1))) void gl_void;
 #pragma unroll
-        for (int it = 0; it < CHUNKS; it++) {
-            const int q = it * (NT / 64) + wave;  // 64 plane rows over 8 waves
-            const int pl = q >> 5, row = q & 31;
-            const _Float16* base = (const _Float16*)(pl ? p.A_lo : p.A_hi);
-            const _Float16* src = base + (g * 32 + row) * (int64_t)p.lda + lane * 8;
-            _Float16* dst = tile + buf * TILE_HALVES + pl * PLANE + row * LDHH;  // wave-uniform; the lane's 16 bytes follow
-            __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst, 16, 0, 0);
-        }
+        for (int it = 0; it < CHUNKS; it++) dma_piece(g, buf, it);
     };
     int64_t g = stream;
     if (g < p.n_groups) dma_tile(g, 0);
@@ -94,7 +95,6 @@ __global__ __launch_bounds__(NT, 2) void k_ga2(WsParams p, int n_slices) {
     for (int i = 0; g < p.n_groups; g += n_streams, i++) {
         const int64_t gn = g + n_streams;
         const bool more = gn < p.n_groups;
-        if (more) dma_tile(gn, (i + 1) & 1);
 
         f32x16 acc, accx;
 #pragma unroll
@@ -113,6 +113,12 @@ __global__ __launch_bounds__(NT, 2) void k_ga2(WsParams p, int n_slices) {
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, w_hi[s], acc, 0, 0, 0);
             accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, w_lo[s], accx, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // one LDS-DMA piece of the next tile per k-step of the first half: issuing one costs the wave 60-180 cycles
+            // (all 8 at the top of the tile stall both waves of a SIMD at once: 15.4 ms instead of 14.9; spread over all
+            // 16 steps the last pieces land too late for the barrier: 15.9).  Without any tile loads: 12.1 ms; the MFMA
+            // loop and its barrier alone: 11.1 ms (9.5 ms of MFMA time at the sustained clock).
+            if (more && s < CHUNKS) dma_piece(gn, (i + 1) & 1, s);
             __builtin_amdgcn_sched_barrier(0);
             accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, w_hi[s], accx, 0, 0, 0);
             a_hi = n_hi;
