@@ -147,6 +147,88 @@ __device__ void level(const float* px, const float* py, const float* pz, int n_d
     __syncthreads();
 }
 
+// The production shape of level(): every lane owns PPL valid points (n_d == 64 * PPL), the row list is wanted, the
+// neighbour table is not.  Same arithmetic and tie-breaking, ~1/3 fewer instructions per FPS step (the kernel is bound by
+// instruction issue: ~230 instructions per step of the 256-point level in the generic form):
+//   * no validity masks, no NULL checks of the optional outputs;
+//   * the 32-neighbour cap is tested once per centroid (uniform) instead of once per point;
+//   * the lane's farthest point is found with max() and located only afterwards (lowest j that equals the wave maximum:
+//     the first point a strict '>' scan would have kept).
+template <int PPL>
+__device__ void level_fast(const float* px, const float* py, const float* pz, int n_c, float r2, uint8_t* sel, float* qx,
+                           float* qy, float* qz, uint16_t* __restrict__ rows_out, int self_loops, int* n_rows_out) {
+    const int lane = threadIdx.x;
+    const int i0 = lane * PPL;
+    float x[PPL], y[PPL], z[PPL], mind[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+        x[j] = px[i0 + j];
+        y[j] = py[i0 + j];
+        z[j] = pz[i0 + j];
+        mind[j] = INFINITY;
+    }
+    int cur = 0;
+    int base = 0;
+    for (int c = 0; c < n_c; c++) {
+        const float cx = px[cur], cy = py[cur], cz = pz[cur];
+        if (lane == 0) {
+            sel[c] = (uint8_t)cur;
+            qx[c] = cx;
+            qy[c] = cy;
+            qz[c] = cz;
+        }
+        float d[PPL];
+        unsigned long long m[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            d[j] = dist2(x[j], y[j], z[j], cx, cy, cz);
+            mind[j] = d[j] < mind[j] ? d[j] : mind[j];
+            m[j] = __ballot(d[j] < r2);
+        }
+        int lower = 0, count = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            lower = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[j], lower));
+            count += __popcll(m[j]);
+        }
+        const uint32_t tag = (uint32_t)c << 8;
+        if (count <= kMaxNbr) {  // (uniform) nothing to cut off
+            int pos = base + lower;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const bool hit = d[j] < r2;
+                if (hit) rows_out[pos] = (uint16_t)(tag | (uint32_t)(i0 + j));
+                pos += hit ? 1 : 0;
+            }
+        } else {
+            int pos = lower;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const bool hit = d[j] < r2;
+                if (hit && pos < kMaxNbr) rows_out[base + pos] = (uint16_t)(tag | (uint32_t)(i0 + j));
+                pos += hit ? 1 : 0;
+            }
+        }
+        const int kept = count < kMaxNbr ? count : kMaxNbr;
+        if (self_loops && lane == 0) rows_out[base + kept] = (uint16_t)(((c | 0x80) << 8) | c);
+        base += kept + (self_loops ? 1 : 0);
+        if (c + 1 < n_c) {  // uniform
+            float bd = mind[0];
+#pragma unroll
+            for (int j = 1; j < PPL; j++) bd = fmaxf(bd, mind[j]);
+            const float mx = wave_max_f(bd);
+            const unsigned long long tie = __ballot(bd == mx);
+            int jb = PPL - 1;
+#pragma unroll
+            for (int j = PPL - 2; j >= 0; j--) jb = mind[j] == mx ? j : jb;
+            cur = __builtin_amdgcn_readlane(i0 + jb, (int)__builtin_ctzll(tie));
+        }
+    }
+    if (lane < 4 && base + lane < n_c * (kMaxNbr + 1)) rows_out[base + lane] = 0xFFFF;
+    *n_rows_out = base;
+    __syncthreads();
+}
+
 // Centroid table of one level + the [xyz | 0 x 29] tail of the SA output rows (was k_pos_table): H/4 lanes per centroid row,
 // the lane's 4 output columns of W1p in registers, 16-byte stores.  Same arithmetic order as the stand-alone kernel.
 __device__ __attribute__((noinline)) void emit_centroid_table(const float* qx, const float* qy, const float* qz, int n_c,
@@ -193,6 +275,9 @@ __device__ __attribute__((noinline)) void emit_point_table(const float* px, cons
 }
 
 // 6 waves per SIMD (80 registers, some spills) measured fastest: 4 -> 3.26, 5 -> 3.08, 6 -> 2.85, 7 -> 3.5, 8 -> 3.16 ms / 3k cells
+// (FAST form, 12k cells: 5 -> 10.0, 6 -> 9.8, 7 -> 10.2, 8 -> 10.7 ms)
+// FAST: n_pts == 256 (every level fills its lanes), row lists of all levels wanted, no neighbour tables: level_fast
+template <bool FAST>
 __global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
                                                      float r0, float r1, float r2, GroupTables gt) {
     // dynamic LDS: coordinates of the 4 levels | FPS selection | (only when the neighbour table is wanted: nbr + cnt);
@@ -203,7 +288,7 @@ __global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict_
     float* p2 = p1 + 3 * (kMaxPts / 2);           // [3][64]
     float* p3 = p2 + 3 * (kMaxPts / 4);           // [3][32]
     uint8_t* sel_lds = (uint8_t*)(p3 + 3 * (kMaxPts / 8));                 // [128]
-    const bool want_nbr = gt.nbr[0] != nullptr;
+    const bool want_nbr = !FAST && gt.nbr[0] != nullptr;
     uint8_t* nbr_lds = want_nbr ? sel_lds + kMaxPts / 2 : nullptr;  // [128*32]
     uint8_t* cnt_lds = want_nbr ? nbr_lds + (kMaxPts / 2) * kMaxNbr : nullptr;                       // [128]
     const int lane = threadIdx.x;
@@ -238,7 +323,17 @@ __global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict_
             // the compact row list goes straight to HBM (2-byte stores from the hit lanes): staging it in LDS cost 8.4 KB per
             // wave and capped the occupancy at 11 waves per CU, and this kernel is latency-bound (half the waves: +64 % time)
             uint16_t* g_rows16 = gt.rows[l] ? gt.rows[l] + o * (int64_t)(n_c * (kMaxNbr + 1)) : nullptr;
-            if (n_d > 128)
+            if constexpr (FAST) {
+                if (l == 0)
+                    level_fast<4>(pin[l][0], pin[l][1], pin[l][2], n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
+                                  pin[l + 1][2], g_rows16, gt.self_loops, &n_rows);
+                else if (l == 1)
+                    level_fast<2>(pin[l][0], pin[l][1], pin[l][2], n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
+                                  pin[l + 1][2], g_rows16, gt.self_loops, &n_rows);
+                else
+                    level_fast<1>(pin[l][0], pin[l][1], pin[l][2], n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
+                                  pin[l + 1][2], g_rows16, gt.self_loops, &n_rows);
+            } else if (n_d > 128)
                 level<4>(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
                          pin[l + 1][2], nbr_lds, cnt_lds, g_rows16, gt.self_loops, &n_rows);
             else if (n_d > 64)
@@ -289,8 +384,14 @@ int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float 
                   "sample_group: neighbour tables must be given for all levels or none");
     size_t lds = sizeof(float) * 3 * (kMaxPts + kMaxPts / 2 + kMaxPts / 4 + kMaxPts / 8) + kMaxPts / 2;
     if (want_nbr) lds += (kMaxPts / 2) * kMaxNbr + kMaxPts / 2;
-    hipLaunchKernelGGL(k_sample_group, dim3((unsigned)grid), dim3(64), lds, st, xyz, n_obj, n_pts, radius[0],
-                       radius[1], radius[2], gt);
+    const bool fast = n_pts == kMaxPts && !want_nbr && gt.rows[0] && gt.rows[1] && gt.rows[2] &&
+                      gt.n_dense[0] == kMaxPts && gt.n_dense[1] == kMaxPts / 2 && gt.n_dense[2] == kMaxPts / 4;
+    if (fast)
+        hipLaunchKernelGGL(k_sample_group<true>, dim3((unsigned)grid), dim3(64), lds, st, xyz, n_obj, n_pts, radius[0],
+                           radius[1], radius[2], gt);
+    else
+        hipLaunchKernelGGL(k_sample_group<false>, dim3((unsigned)grid), dim3(64), lds, st, xyz, n_obj, n_pts, radius[0],
+                           radius[1], radius[2], gt);
     T2P_CHECK_LAUNCH("sample_group");
     return 0;
 }
