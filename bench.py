@@ -252,9 +252,8 @@ def main():
         "retrieval": {"bound": "mfma (fp64)", "achieved_tflops": sim_flops / t_topk / 1e12, "peak_tflops": 78.6,
                       "frac": sim_flops / t_topk / 1e12 / 78.6}}
     if rank == 0:  # PCIe-inclusive cell rate: pinned host arrays -> HBM -> embeddings (never `value`)
-        def with_h2d():
-            d = [t.to(dev, non_blocking=True) for t in h_pinned]
-            return model.encode_objects_packed(*d, cell_ptr, d_ptr, chunk_objects=args.chunk_objects)
+        def with_h2d():  # copies of block b+1 under the kernels of block b (CellRetrievalNetwork.encode_objects_packed_host)
+            return model.encode_objects_packed_host(*h_pinned, cell_ptr)
         with torch.no_grad():
             t_h2d, _ = timed(with_h2d, 1)
         phase_rates["cells_per_s_incl_h2d"] = (c_hi - c_lo) / t_h2d

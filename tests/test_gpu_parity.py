@@ -364,6 +364,20 @@ def test_encode_cells_ragged_extremes_vs_oracle(hip_model, oracle_model):
     assert tuple(none.shape) == (0, 256)
 
 
+def test_encode_cells_from_host_overlapped_copies(hip_model):
+    """encode_objects_packed_host (blocks of cells copied on a second stream under the previous block's kernels) returns
+    exactly what the device-resident call returns, for pinned and for pageable host tensors."""
+    from text2pos_amd import synthetic as S
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(52, 23)
+    with torch.no_grad():
+        want = hip_model.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr).cpu()
+        host = [torch.from_numpy(a) for a in (xyz, rgb, center, mean_rgb)]
+        got_pageable = hip_model.encode_objects_packed_host(*host, cell_ptr, cells_per_chunk=5).cpu()
+        got_pinned = hip_model.encode_objects_packed_host(*[t.pin_memory() for t in host], cell_ptr, cells_per_chunk=7).cpu()
+        one_block = hip_model.encode_objects_packed_host(*host, cell_ptr).cpu()
+    assert torch.equal(got_pageable, want) and torch.equal(got_pinned, want) and torch.equal(one_block, want)
+
+
 def test_encode_cells_full_size_properties(hip_model):
     """Size-independent properties at a BASELINE-sized slice (3,000 cells = 48 k objects, several internal chunks and
     every workgroup of the persistent kernels busy): unit norms, bit-determinism, chunking invisible, cells independent

@@ -94,6 +94,45 @@ class CellRetrievalNetwork(nn.Module):
         cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx)
         return ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
 
+    def encode_objects_packed_host(self, xyz, rgb, center, mean_rgb, cell_ptr, cells_per_chunk=2048):
+        """The same for HOST tensors (pinned for real overlap): the cells travel in blocks of `cells_per_chunk`; the
+        host-to-device copies of block b+1 run on a second HIP stream under the kernels of block b, so the PCIe time
+        (6 KB per object) hides behind the encoder instead of preceding it.  Cells are independent, so the result is
+        the one of encode_objects_packed on the whole batch."""
+        self._check_forward_only()
+        dev = self.device
+        cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int32)
+        n_cells = cp.shape[0] - 1
+        if n_cells <= 0:
+            return torch.empty((0, self.embed_dim), dtype=torch.float32, device=dev)
+        bounds = list(range(0, n_cells, int(cells_per_chunk))) + [n_cells]
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        copy = self._copy_stream
+        copy.wait_stream(main)
+
+        def stage(b):
+            lo, hi = int(cp[bounds[b]]), int(cp[bounds[b + 1]])
+            with torch.cuda.stream(copy):
+                d = [t[lo:hi].to(dev, non_blocking=True) for t in (xyz, rgb, center, mean_rgb)]
+                d.append(torch.from_numpy(cp[bounds[b]: bounds[b + 1] + 1] - lo).to(dev, non_blocking=True))
+                ev = torch.cuda.Event()
+                ev.record(copy)
+            return d, ev, cp[bounds[b]: bounds[b + 1] + 1] - lo
+
+        outs = []
+        nxt = stage(0)
+        for b in range(len(bounds) - 1):
+            d, ev, cpb = nxt
+            if b + 2 < len(bounds):
+                nxt = stage(b + 1)
+            main.wait_event(ev)
+            for t in d:
+                t.record_stream(main)
+            outs.append(self.encode_objects_packed(d[0], d[1], d[2], d[3], cpb, d[4]))
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
+
     def encode_objects(self, objects, object_points):
         """objects: List[List[Object3d]], object_points: List[Batch] (one PyG-style batch per cell)
         -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:77-107)."""
