@@ -413,16 +413,61 @@ def test_encode_cells_full_size_properties(hip_model):
 
 
 def test_train_mode_and_grad_fail_loudly(hip_model):
+    """The cell branch is forward-only (batch-statistics BatchNorm / autograd: SURVEY 8(f) #4 is not finished): it must
+    refuse training mode and enabled gradients instead of silently computing eval-mode results."""
+    from text2pos_amd import synthetic as S
+    args = _to_dev(*S.make_objects(5, 0, 6))
+    cell_ptr = np.array([0, 6], dtype=np.int32)
     hip_model.train()
     try:
         with pytest.raises(NotImplementedError):
-            hip_model.encode_text(["north"])
+            hip_model.encode_objects_packed(*args, cell_ptr)
     finally:
         hip_model.eval()
     with pytest.raises(NotImplementedError):
-        hip_model.encode_text(["north"])      # grad enabled, parameters require grad
+        hip_model.encode_objects_packed(*args, cell_ptr)      # grad enabled, parameters require grad
     with pytest.raises(Exception):
         hip_model.forward()
+
+
+def test_encode_text_training_step_matches_autograd(hip_model, oracle_model):
+    """Text branch with gradients (training/coarse.py:44-58: anchor = model.encode_text(texts); loss.backward()): output
+    and the gradients of every LanguageEncoder parameter against torch.autograd through the oracle's nn.Embedding +
+    packed nn.LSTM (models/modules.py:77-90), incl. unknown words (padding row: no gradient) and unequal lengths.
+    Tolerance 1e-4 absolute on the unit-norm output, 1e-4 relative to each gradient's largest entry."""
+    from text2pos_amd import synthetic as S
+    texts = S.make_texts(9, 0, 12, n_hints=3) + ["The pose is north of a zzzz wall.", "east"]
+    coef = torch.randn(len(texts), 256, generator=torch.Generator().manual_seed(3))
+    # oracle: plain autograd
+    ref_params = list(oracle_model.language_encoder.parameters())
+    was = [p.requires_grad for p in ref_params]
+    for p in ref_params:
+        p.requires_grad_(True)
+    oracle_model.zero_grad(set_to_none=True)
+    want = torch.nn.functional.normalize(oracle_model.language_encoder(texts))   # (OracleCellRetrieval.encode_text is no_grad)
+    (want * coef).sum().backward()
+    # HIP: step-wise recurrence + its backward kernels
+    hip_model.zero_grad(set_to_none=True)
+    got = hip_model.encode_text(texts)
+    assert got.requires_grad and got.grad_fn is not None
+    (got * coef.to(got.device)).sum().backward()
+    assert (got.detach().cpu() - want.detach()).abs().max().item() < TOL
+    with torch.no_grad():
+        eval_path = hip_model.encode_text(texts)
+    assert (eval_path - got.detach()).abs().max().item() < 1e-5       # same numbers as the persistent inference kernel
+    ho, oo = hip_model.language_encoder, oracle_model.language_encoder
+    names = ["word_embedding.weight"] + [f"lstm.{n}" for n, _ in oo.lstm.named_parameters()]
+    for name in names:
+        g_hip = dict(ho.named_parameters())[name].grad
+        g_ref = dict(oo.named_parameters())[name].grad
+        assert g_hip is not None, name
+        err = (g_hip.cpu() - g_ref).abs().max().item()
+        assert err < 1e-4 * max(1.0, g_ref.abs().max().item()), (name, err, g_ref.abs().max().item())
+    assert float(ho.word_embedding.weight.grad[0].abs().max()) == 0.0   # padding_idx row
+    hip_model.zero_grad(set_to_none=True)
+    oracle_model.zero_grad(set_to_none=True)
+    for p, r in zip(ref_params, was):
+        p.requires_grad_(r)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -185,7 +185,10 @@ def test_forward_raises_like_the_reference_and_train_mode_is_refused():
     with pytest.raises(Exception, match="Not implemented"):
         m.forward()
     m.train()
-    with pytest.raises(NotImplementedError):
+    objs, pts, _ = _cell(2)
+    with pytest.raises(NotImplementedError):     # cell branch: batch-statistics BatchNorm is not built
+        m.encode_objects([objs], [pts])
+    with pytest.raises(RuntimeError, match="no CPU path"):   # text branch trains on the GPU only
         m.encode_text(["north"])
 
 

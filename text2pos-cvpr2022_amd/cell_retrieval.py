@@ -51,8 +51,9 @@ class CellRetrievalNetwork(nn.Module):
 
     # ---- text branch -----------------------------------------------------------------------------------------
     def encode_text(self, descriptions):
-        """List[str] -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:69-75)."""
-        self._check_forward_only()
+        """List[str] -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:69-75).  With gradients enabled the text
+        branch runs its training-mode recurrence and the result carries a grad_fn (training/coarse.py:44); the cell branch
+        is forward-only."""
         return self.language_encoder(descriptions, normalize=True)
 
     # ---- cell branch -----------------------------------------------------------------------------------------

@@ -563,6 +563,25 @@ int t2p_encode_text(const int32_t* tokens, const int32_t* lengths, int64_t batch
     return 0;
 }
 
+int t2p_lstm_cell_forward(const float* pre, const float* gate_table, const int32_t* tokens, const int32_t* lengths,
+                          int64_t batch, int32_t max_len, int32_t embed_dim, int32_t step, int32_t reverse, const float* c_prev,
+                          const float* h_prev, float* gates, float* c, float* h, t2p_stream_t stream) {
+    T2P_CHECK_ARG(pre && gate_table && tokens && lengths && c_prev && h_prev && gates && c && h, "lstm_cell_forward: NULL argument");
+    T2P_CHECK_ARG(batch >= 0 && max_len >= 1 && embed_dim >= 1 && step >= 0 && step < max_len, "lstm_cell_forward: bad sizes");
+    return launch_lstm_cell_fwd(pre, gate_table, tokens, lengths, batch, max_len, embed_dim, step, reverse, c_prev, h_prev, gates,
+                                c, h, (hipStream_t)stream);
+}
+
+int t2p_lstm_cell_backward(const float* dh_gemm, const float* dh_carry_in, const float* dc_in, const float* gates,
+                           const float* c_prev, const float* c, const int32_t* lengths, int64_t batch, int32_t embed_dim,
+                           int32_t step, float* d_pre, float* dc_out, float* dh_carry_out, t2p_stream_t stream) {
+    T2P_CHECK_ARG(dh_carry_in && dc_in && gates && c_prev && c && lengths && d_pre && dc_out && dh_carry_out,
+                  "lstm_cell_backward: NULL argument");
+    T2P_CHECK_ARG(batch >= 0 && embed_dim >= 1 && step >= 0, "lstm_cell_backward: bad sizes");
+    return launch_lstm_cell_bwd(dh_gemm, dh_carry_in, dc_in, gates, c_prev, c, lengths, batch, embed_dim, step, d_pre, dc_out,
+                                dh_carry_out, (hipStream_t)stream);
+}
+
 size_t t2p_sim_topk_workspace_bytes(int64_t nq, int64_t nc, int32_t k) { return sim_topk_workspace_bytes(nq, nc, k); }
 
 int t2p_sim_topk(const float* queries, const float* cells, int64_t nq, int64_t nc, int32_t dim, int32_t k,

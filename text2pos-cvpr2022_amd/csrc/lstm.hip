@@ -168,4 +168,97 @@ int launch_bilstm_impl(const float* gate_table, const float* whh, const int32_t*
     return 0;
 }
 
+// ---- training-mode recurrence, step by step (text branch) ---------------------------------------------
+// The persistent kernel above keeps no activations.  For training (training/coarse.py:44: anchor = model.encode_text(...),
+// loss.backward()) the recurrence runs one step per launch - pre-activations of the recurrent term from the tiled GEMM, this
+// cell kernel - and stores what the backward pass needs: the gate activations, the cell and the hidden state of every step.
+// Same semantics as above: a sequence is updated while step < len; the reverse direction reads token len-1-step.
+namespace {
+
+// one thread = one hidden unit of one sequence
+__global__ void k_lstm_cell_fwd(const float* __restrict__ pre /*[B][4D] h_{s-1} W_hh*/, const float* __restrict__ table /*[V][4D]*/,
+                                const int32_t* __restrict__ tokens, const int32_t* __restrict__ lengths, int64_t B, int T,
+                                int D, int step, int reverse, const float* __restrict__ c_prev,
+                                const float* __restrict__ h_prev, float* __restrict__ gates /*[B][4D] i f g o*/,
+                                float* __restrict__ c, float* __restrict__ h) {
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    const int64_t b = idx / D;
+    const int u = (int)(idx % D);
+    const int len = lengths[b];
+    float* g = gates + b * 4 * D;
+    if (step >= len) {  // past the end of this sequence: the state is carried, the step contributes no gradient
+        c[idx] = c_prev[idx];
+        h[idx] = h_prev[idx];
+        g[u] = g[D + u] = g[2 * D + u] = g[3 * D + u] = 0.f;
+        return;
+    }
+    const int tok = tokens[b * T + (reverse ? len - 1 - step : step)];
+    const float* tr = table + (int64_t)tok * 4 * D;
+    const float* pr = pre + b * 4 * D;
+    const float gi = sigmoidf_(pr[u] + tr[u]), gf = sigmoidf_(pr[D + u] + tr[D + u]);
+    const float gg = tanhf(pr[2 * D + u] + tr[2 * D + u]), go = sigmoidf_(pr[3 * D + u] + tr[3 * D + u]);
+    const float cn = gf * c_prev[idx] + gi * gg;
+    c[idx] = cn;
+    h[idx] = go * tanhf(cn);
+    g[u] = gi;
+    g[D + u] = gf;
+    g[2 * D + u] = gg;
+    g[3 * D + u] = go;
+}
+
+// dh = dh_gemm (= d_pre of the later step x W_hh^T; NULL at the last step) + dh_carry_in; writes the gradient of this step's
+// gate pre-activations, the cell gradient of the previous step and the part of dh that bypasses the step (finished sequences)
+__global__ void k_lstm_cell_bwd(const float* __restrict__ dh_gemm, const float* __restrict__ dh_carry_in,
+                                const float* __restrict__ dc_in, const float* __restrict__ gates,
+                                const float* __restrict__ c_prev, const float* __restrict__ c,
+                                const int32_t* __restrict__ lengths, int64_t B, int D, int step, float* __restrict__ d_pre,
+                                float* __restrict__ dc_out, float* __restrict__ dh_carry_out) {
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    const int64_t b = idx / D;
+    const int u = (int)(idx % D);
+    const float dh = (dh_gemm ? dh_gemm[idx] : 0.f) + dh_carry_in[idx];
+    const float dc = dc_in[idx];
+    float* dp = d_pre + b * 4 * D;
+    if (step >= lengths[b]) {
+        dp[u] = dp[D + u] = dp[2 * D + u] = dp[3 * D + u] = 0.f;
+        dc_out[idx] = dc;
+        dh_carry_out[idx] = dh;
+        return;
+    }
+    const float* g = gates + b * 4 * D;
+    const float gi = g[u], gf = g[D + u], gg = g[2 * D + u], go = g[3 * D + u];
+    const float tc = tanhf(c[idx]);
+    const float dct = dc + dh * go * (1.f - tc * tc);
+    dp[u] = dct * gg * gi * (1.f - gi);
+    dp[D + u] = dct * c_prev[idx] * gf * (1.f - gf);
+    dp[2 * D + u] = dct * gi * (1.f - gg * gg);
+    dp[3 * D + u] = dh * tc * go * (1.f - go);
+    dc_out[idx] = dct * gf;
+    dh_carry_out[idx] = 0.f;
+}
+
+}  // namespace
+
+int launch_lstm_cell_fwd(const float* pre, const float* table, const int32_t* tokens, const int32_t* lengths, int64_t B, int T,
+                         int D, int step, int reverse, const float* c_prev, const float* h_prev, float* gates, float* c,
+                         float* h, hipStream_t st) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_lstm_cell_fwd, dim3((unsigned)((B * D + 255) / 256)), dim3(256), 0, st, pre, table, tokens, lengths, B,
+                       T, D, step, reverse, c_prev, h_prev, gates, c, h);
+    T2P_CHECK_LAUNCH("lstm_cell_fwd");
+    return 0;
+}
+
+int launch_lstm_cell_bwd(const float* dh_gemm, const float* dh_carry_in, const float* dc_in, const float* gates,
+                         const float* c_prev, const float* c, const int32_t* lengths, int64_t B, int D, int step, float* d_pre,
+                         float* dc_out, float* dh_carry_out, hipStream_t st) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_lstm_cell_bwd, dim3((unsigned)((B * D + 255) / 256)), dim3(256), 0, st, dh_gemm, dh_carry_in, dc_in,
+                       gates, c_prev, c, lengths, B, D, step, d_pre, dc_out, dh_carry_out);
+    T2P_CHECK_LAUNCH("lstm_cell_bwd");
+    return 0;
+}
+
 }  // namespace t2p

@@ -171,6 +171,13 @@ int launch_bilstm_impl(const float* gate_table /*[2][V][4D]*/, const float* whh 
                        float* hdir_ws /*[2][B][D]*/, float* out /*[B, D] mean of the two final hidden states*/,
                        hipStream_t st);
 
+int launch_lstm_cell_fwd(const float* pre, const float* table, const int32_t* tokens, const int32_t* lengths, int64_t B, int T,
+                         int D, int step, int reverse, const float* c_prev, const float* h_prev, float* gates, float* c,
+                         float* h, hipStream_t st);
+int launch_lstm_cell_bwd(const float* dh_gemm, const float* dh_carry_in, const float* dc_in, const float* gates,
+                         const float* c_prev, const float* c, const int32_t* lengths, int64_t B, int D, int step, float* d_pre,
+                         float* dc_out, float* dh_carry_out, hipStream_t st);
+
 // ---- sim_topk.hip -----------------------------------------------------------------------------------------
 size_t sim_topk_workspace_bytes(int64_t nq, int64_t nc, int k);
 int launch_sim_topk(const float* Q, const float* C, int64_t nq, int64_t nc, int dim, int k, int64_t c_index_offset,

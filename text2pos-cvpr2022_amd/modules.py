@@ -39,6 +39,73 @@ def tokenize(descriptions: List[str], known_words: dict):
     return padded, lengths
 
 
+class _LstmTrainFn(torch.autograd.Function):
+    """Training-mode text branch (first part): Embedding -> packed biLSTM -> mean of the two final
+    hidden states (models/modules.py:77-90) with a backward pass, for `anchor = model.encode_text(...); loss.backward()`
+    (training/coarse.py:44-58).  The recurrence runs step by step on the HIP kernels t2p_lstm_cell_forward / _backward and
+    t2p_gemm (the persistent inference kernel keeps no activations); the weight-gradient reductions at the end are plain
+    library GEMMs over the stored activations.  Parameters come in nn.LSTM's own layout (weight_* [4D, D], gates i f g o)."""
+
+    @staticmethod
+    def forward(ctx, tokens, lengths, emb, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        b, t = tokens.shape
+        d = emb.shape[1]
+        dev = emb.device
+        emb_c = emb.detach().contiguous()
+        wih_k = [w_ih.detach().t().contiguous(), w_ih_r.detach().t().contiguous()]      # k-major [D, 4D]
+        whh_k = [w_hh.detach().t().contiguous(), w_hh_r.detach().t().contiguous()]
+        bias = [(b_ih + b_hh).detach().contiguous(), (b_ih_r + b_hh_r).detach().contiguous()]
+        gates = torch.empty((2, t, b, 4 * d), dtype=torch.float32, device=dev)
+        cs = torch.zeros((2, t + 1, b, d), dtype=torch.float32, device=dev)
+        hs = torch.zeros((2, t + 1, b, d), dtype=torch.float32, device=dev)
+        for dr in (0, 1):
+            table = ops.gemm(emb_c, wih_k[dr], bias[dr])                                 # [V, 4D] = E W_ih^T + b_ih + b_hh
+            for s in range(t):
+                pre = ops.gemm(hs[dr, s], whh_k[dr])
+                ops.lstm_cell_forward(pre, table, tokens, lengths, s, dr == 1, cs[dr, s], hs[dr, s], gates[dr, s],
+                                      cs[dr, s + 1], hs[dr, s + 1])
+        ctx.save_for_backward(tokens, lengths, emb_c, wih_k[0], wih_k[1], whh_k[0], whh_k[1], gates, cs, hs)
+        return 0.5 * (hs[0, t] + hs[1, t])
+
+    @staticmethod
+    def backward(ctx, dout):
+        tokens, lengths, emb_c, wih0, wih1, whh0, whh1, gates, cs, hs = ctx.saved_tensors
+        b, t = tokens.shape
+        d, v = emb_c.shape[1], emb_c.shape[0]
+        dev = emb_c.device
+        steps = torch.arange(t, device=dev, dtype=torch.int64)[:, None]                   # [T, 1]
+        ln = lengths.to(torch.int64)[None, :]                                             # [1, B]
+        active = steps < ln                                                               # [T, B]
+        d_emb = torch.zeros_like(emb_c)
+        grads = []
+        for dr, (wih_k, whh_k) in enumerate(((wih0, whh0), (wih1, whh1))):
+            whh_t = whh_k.t().contiguous()                                                # [4D, D]: d_pre -> dh_{s-1}
+            d_pre = torch.empty((t, b, 4 * d), dtype=torch.float32, device=dev)
+            dh_carry = (0.5 * dout).contiguous()
+            dc = torch.zeros((b, d), dtype=torch.float32, device=dev)
+            dh_gemm = None
+            for s in range(t - 1, -1, -1):
+                dc_new, carry_new = torch.empty_like(dc), torch.empty_like(dc)
+                ops.lstm_cell_backward(dh_gemm, dh_carry, dc, gates[dr, s], cs[dr, s], cs[dr, s + 1], lengths, s, d_pre[s],
+                                       dc_new, carry_new)
+                dh_gemm = ops.gemm(d_pre[s], whh_t) if s > 0 else None
+                dc, dh_carry = dc_new, carry_new
+            flat = d_pre.reshape(t * b, 4 * d)
+            d_whh_k = hs[dr, :t].reshape(t * b, d).t() @ flat                             # [D, 4D]
+            # gate-table gradient: rows of d_pre summed per token (one-hot product: deterministic, V is ~40)
+            pos = steps if dr == 0 else (ln - 1 - steps).clamp(min=0)                     # token position of (step, sequence)
+            tok = torch.gather(tokens.to(torch.int64).t(), 0, pos.expand(t, b))           # [T, B]
+            onehot = torch.zeros((v, t * b), dtype=torch.float32, device=dev)
+            onehot.scatter_(0, tok.reshape(1, t * b), active.reshape(1, t * b).to(torch.float32))
+            d_table = onehot @ flat                                                       # [V, 4D]
+            d_bias = d_table.sum(0)
+            d_wih_k = emb_c.t() @ d_table                                                 # [D, 4D]
+            d_emb += d_table @ wih_k.t()
+            grads += [d_wih_k.t().contiguous(), d_whh_k.t().contiguous(), d_bias, d_bias.clone()]
+        d_emb[0].zero_()                                                                  # nn.Embedding(padding_idx=0)
+        return (None, None, d_emb) + tuple(grads)
+
+
 class LanguageEncoder(nn.Module):
     def __init__(self, known_words, embedding_dim, bi_dir, num_layers=1):
         super().__init__()
@@ -61,14 +128,21 @@ class LanguageEncoder(nn.Module):
             self._pack = (ver, t, ops.make_text_weights(t["embedding"], t["w_ih"], t["w_hh"], t["bias"]))
         return self._pack[2]
 
+    def _wants_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def encode_tokens(self, tokens: torch.Tensor, lengths: torch.Tensor, normalize: bool):
         d = self.word_embedding.embedding_dim
+        if self._wants_grad():  # training step: the step-wise recurrence that keeps its activations
+            m = self.lstm
+            raw = _LstmTrainFn.apply(tokens, lengths, self.word_embedding.weight, m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0,
+                                     m.bias_hh_l0, m.weight_ih_l0_reverse, m.weight_hh_l0_reverse, m.bias_ih_l0_reverse,
+                                     m.bias_hh_l0_reverse)
+            return nn.functional.normalize(raw, dim=-1) if normalize else raw
         out, raw = ops.encode_text(tokens, lengths, self._weights(), self.word_embedding.num_embeddings, d, want_raw=True)
         return out if normalize else raw
 
     def forward(self, descriptions, normalize: bool = False):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the HIP text path is forward-only; call it under torch.no_grad()")
         padded, lengths = tokenize(descriptions, self.known_words)
         dev = self.device
         tok = torch.from_numpy(padded).to(dev, non_blocking=True)

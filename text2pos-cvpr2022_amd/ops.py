@@ -365,6 +365,41 @@ def encode_text(tokens: torch.Tensor, lengths: torch.Tensor, weights: L.TextWeig
     return (out, raw) if want_raw else out
 
 
+def lstm_cell_forward(pre, table, tokens, lengths, step: int, reverse: bool, c_prev, h_prev, gates, c, h):
+    """One training-mode LSTM step (t2p_lstm_cell_forward): pre [B,4D] = h_prev @ W_hh^T, table [V,4D]; writes gates
+    [B,4D] (i, f, g, o), c, h [B,D] in place."""
+    dev = pre.device
+    for name, t in (("pre", pre), ("table", table), ("gates", gates)):
+        _need(t, name, torch.float32, 2, dev)
+    for name, t in (("c_prev", c_prev), ("h_prev", h_prev), ("c", c), ("h", h)):
+        _need(t, name, torch.float32, 2, dev)
+    _need(tokens, "tokens", torch.int32, 2, dev)
+    _need(lengths, "lengths", torch.int32, 1, dev)
+    b, d = c.shape
+    if tuple(pre.shape) != (b, 4 * d) or tuple(gates.shape) != (b, 4 * d) or table.shape[1] != 4 * d or tokens.shape[0] != b:
+        raise RuntimeError("lstm_cell_forward: inconsistent shapes")
+    L.check(L.lib().t2p_lstm_cell_forward(_ptr(pre), _ptr(table), _ptr(tokens), _ptr(lengths), b, tokens.shape[1], d,
+                                          int(step), int(bool(reverse)), _ptr(c_prev), _ptr(h_prev), _ptr(gates), _ptr(c),
+                                          _ptr(h), _stream(dev)), "t2p_lstm_cell_forward")
+
+
+def lstm_cell_backward(dh_gemm, dh_carry_in, dc_in, gates, c_prev, c, lengths, step: int, d_pre, dc_out, dh_carry_out):
+    """Backward of one training-mode LSTM step (t2p_lstm_cell_backward); dh_gemm may be None (last step)."""
+    dev = gates.device
+    for name, t in (("dh_carry_in", dh_carry_in), ("dc_in", dc_in), ("gates", gates), ("c_prev", c_prev), ("c", c),
+                    ("d_pre", d_pre), ("dc_out", dc_out), ("dh_carry_out", dh_carry_out)):
+        _need(t, name, torch.float32, 2, dev)
+    if dh_gemm is not None:
+        _need(dh_gemm, "dh_gemm", torch.float32, 2, dev)
+    _need(lengths, "lengths", torch.int32, 1, dev)
+    b, d = c.shape
+    if tuple(gates.shape) != (b, 4 * d) or tuple(d_pre.shape) != (b, 4 * d):
+        raise RuntimeError("lstm_cell_backward: inconsistent shapes")
+    L.check(L.lib().t2p_lstm_cell_backward(_ptr(dh_gemm) if dh_gemm is not None else None, _ptr(dh_carry_in), _ptr(dc_in),
+                                           _ptr(gates), _ptr(c_prev), _ptr(c), _ptr(lengths), b, d, int(step), _ptr(d_pre),
+                                           _ptr(dc_out), _ptr(dh_carry_out), _stream(dev)), "t2p_lstm_cell_backward")
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def profile_enable(on: bool):
     """Bracket every kernel launch with hipEvents on its launch stream (bench.py's live per-kernel timing)."""
