@@ -280,6 +280,12 @@ int t2p_lstm_cell_backward(const float* dh_gemm, const float* dh_carry_in, const
                            const float* c_prev, const float* c, const int32_t* lengths, int64_t batch, int32_t embed_dim,
                            int32_t step, float* d_pre, float* dc_out, float* dh_carry_out, t2p_stream_t stream);
 
+/* PairwiseRankingLoss (training/losses.py:126-164, margin training/args.py:46) on the score matrix of the L2-normalised
+ * anchor / positive embeddings, scores [B][B] = im_n s_n^T:  row_loss [B] (loss = sum(row_loss) / B),
+ * d_scores [B][B] = dLoss / dScores, row_count [B] scratch.  Deterministic (fixed-order reductions). */
+int t2p_pairwise_ranking(const float* scores, int32_t batch, float margin, float* row_loss, float* d_scores, float* row_count,
+                         t2p_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Stage-level exports (used by the stage-wise parity tests).
  * ---------------------------------------------------------------------------------------------------------- */

@@ -470,6 +470,63 @@ def test_encode_text_training_step_matches_autograd(hip_model, oracle_model):
         p.requires_grad_(r)
 
 
+@pytest.mark.parametrize("b", [1, 7, 64, 300])
+def test_pairwise_ranking_loss_matches_reference_formula(b):
+    """PairwiseRankingLoss forward value and both input gradients against the reference's statements
+    (training/losses.py:138-164, restated here with autograd; margin 0.35 = training/args.py:46)."""
+    import text2pos_amd as t2p
+    g = torch.Generator().manual_seed(b)
+    im = torch.randn(b, 256, generator=g)
+    s = (0.7 * im + 0.6 * torch.randn(b, 256, generator=g))          # positives correlate with their anchors
+    margin = 0.35
+
+    def reference(im, s):
+        im = im / torch.norm(im, dim=1, keepdim=True)
+        s = s / torch.norm(s, dim=1, keepdim=True)
+        scores = torch.mm(im, s.transpose(1, 0))
+        diagonal = scores.diag()
+        cost_s = torch.clamp((margin - diagonal).expand_as(scores) + scores, min=0)
+        cost_im = torch.clamp((margin - diagonal).expand_as(scores).transpose(1, 0) + scores, min=0)
+        eye = torch.eye(len(im), dtype=torch.bool)
+        return (cost_s.masked_fill(eye, 0).sum() + cost_im.masked_fill(eye, 0).sum()) / len(im)
+
+    a, c = im.double().requires_grad_(True), s.double().requires_grad_(True)
+    want = reference(a, c)
+    want.backward()
+    x, y = im.to(_dev()).requires_grad_(True), s.to(_dev()).requires_grad_(True)
+    got = t2p.PairwiseRankingLoss(margin)(x, y)
+    got.backward()
+    assert abs(got.item() - want.item()) < 1e-5 * max(1.0, abs(want.item()))
+    scale = max(1e-6, a.grad.abs().max().item())
+    assert (x.grad.cpu().double() - a.grad).abs().max().item() < 1e-4 * scale
+    assert (y.grad.cpu().double() - c.grad).abs().max().item() < 1e-4 * scale
+    again = t2p.PairwiseRankingLoss(margin)(x.detach(), y.detach())
+    assert again.item() == got.item()                                   # fixed-order reductions
+
+
+def test_text_branch_learns_against_fixed_cell_embeddings(hip_model, vocab):
+    """A few Adam steps of the text branch alone on the HIP path (encode_text with gradients + PairwiseRankingLoss)
+    against frozen cell embeddings lower the loss: the pieces of training/coarse.py:31-62 that exist so far work together."""
+    import text2pos_amd as t2p
+    from text2pos_amd import synthetic as S
+    model = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
+    model.load_state_dict(hip_model.state_dict(), strict=True)
+    model = model.to(_dev()).eval()
+    texts = S.make_texts(21, 0, 32, n_hints=2)
+    with torch.no_grad():
+        target = torch.nn.functional.normalize(torch.randn(32, 256, generator=torch.Generator().manual_seed(1)), dim=1).to(_dev())
+    opt = torch.optim.Adam(model.language_encoder.parameters(), lr=1e-3)
+    crit = t2p.PairwiseRankingLoss(0.35)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = crit(model.encode_text(texts), target)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.8 * losses[0], losses
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # retrieval
 # ---------------------------------------------------------------------------------------------------------------

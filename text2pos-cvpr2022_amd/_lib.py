@@ -74,6 +74,7 @@ SYMBOLS = {
                                         c_void, c_void, c_void, c_void, c_void, c_void]),
     "t2p_lstm_cell_backward": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int32,
                                          C.c_int32, c_void, c_void, c_void, c_void]),
+    "t2p_pairwise_ranking": (C.c_int, [c_void, C.c_int32, C.c_float, c_void, c_void, c_void, c_void]),
     "t2p_pack_objects": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, c_void, c_void, c_void, c_void,
                                    c_void]),
     "t2p_match_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

@@ -582,6 +582,13 @@ int t2p_lstm_cell_backward(const float* dh_gemm, const float* dh_carry_in, const
                                 dh_carry_out, (hipStream_t)stream);
 }
 
+int t2p_pairwise_ranking(const float* scores, int32_t batch, float margin, float* row_loss, float* d_scores, float* row_count,
+                         t2p_stream_t stream) {
+    T2P_CHECK_ARG(scores && row_loss && d_scores && row_count, "pairwise_ranking: NULL argument");
+    T2P_CHECK_ARG(batch >= 0 && batch <= 32768, "pairwise_ranking: batch=%d outside [0, 32768]", batch);
+    return launch_pairwise_ranking(scores, batch, margin, row_loss, d_scores, row_count, (hipStream_t)stream);
+}
+
 size_t t2p_sim_topk_workspace_bytes(int64_t nq, int64_t nc, int32_t k) { return sim_topk_workspace_bytes(nq, nc, k); }
 
 int t2p_sim_topk(const float* queries, const float* cells, int64_t nq, int64_t nc, int32_t dim, int32_t k,

@@ -258,6 +258,59 @@ __global__ __launch_bounds__(256) void k_pack_objects(const float* __restrict__ 
     }
 }
 
+// PairwiseRankingLoss (training/losses.py:126-164) on the score matrix S = im_n s_n^T [B][B]:
+//   cost_s[i][j] = max(0, margin - S[j][j] + S[i][j]),  cost_im[i][j] = max(0, margin - S[i][i] + S[i][j]),  diagonals 0,
+//   loss = (sum cost_s + sum cost_im) / B.
+// One block per row: the row's loss, dLoss/dS off the diagonal, and the row's count of active cost_im terms (which
+// the diagonal entry of the gradient needs); fixed-order reductions, so the result is run-to-run identical.
+__global__ __launch_bounds__(256) void k_rank_rows(const float* __restrict__ S, int B, float margin,
+                                                   float* __restrict__ row_loss, float* __restrict__ dS,
+                                                   float* __restrict__ row_cnt) {
+    __shared__ float red[2][256];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const float di = S[(int64_t)i * B + i], inv = 1.f / (float)B;
+    float loss = 0.f, cnt = 0.f;
+    for (int j = tid; j < B; j += 256) {
+        if (j == i) continue;
+        const float sij = S[(int64_t)i * B + j];
+        const float cs = margin - S[(int64_t)j * B + j] + sij, ci = margin - di + sij;
+        loss += fmaxf(cs, 0.f) + fmaxf(ci, 0.f);
+        cnt += ci > 0.f ? 1.f : 0.f;
+        dS[(int64_t)i * B + j] = ((cs > 0.f ? 1.f : 0.f) + (ci > 0.f ? 1.f : 0.f)) * inv;
+    }
+    red[0][tid] = loss;
+    red[1][tid] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] += red[0][tid + s];
+            red[1][tid] += red[1][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        row_loss[i] = red[0][0];
+        row_cnt[i] = red[1][0];
+    }
+}
+// diagonal of the gradient: -(active cost_s terms of column j + active cost_im terms of row j) / B
+__global__ __launch_bounds__(256) void k_rank_diag(const float* __restrict__ S, int B, float margin,
+                                                   const float* __restrict__ row_cnt, float* __restrict__ dS) {
+    __shared__ float red[256];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const float dj = S[(int64_t)j * B + j];
+    float cnt = 0.f;
+    for (int i = tid; i < B; i += 256)
+        if (i != j) cnt += (margin - dj + S[(int64_t)i * B + j]) > 0.f ? 1.f : 0.f;
+    red[tid] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) dS[(int64_t)j * B + j] = -(red[0] + row_cnt[j]) / (float)B;
+}
+
 __global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, int32_t o_lo,
                              int32_t* __restrict__ seg_ptr_local, int32_t* __restrict__ first) {
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= n_cells; c += gridDim.x * blockDim.x) {
@@ -320,6 +373,16 @@ int launch_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_
     hipLaunchKernelGGL(k_pack_objects, dim3((unsigned)((n_obj + 3) / 4)), dim3(256), 0, st, raw_xyz, raw_rgb, obj_ptr,
                        sample_idx, rot, n_obj, n_pts, xyz, rgb, center, mean_rgb);
     T2P_CHECK_LAUNCH("pack_objects");
+    return 0;
+}
+
+int launch_pairwise_ranking(const float* scores, int batch, float margin, float* row_loss, float* d_scores, float* row_cnt,
+                            hipStream_t st) {
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(k_rank_rows, dim3((unsigned)batch), dim3(256), 0, st, scores, batch, margin, row_loss, d_scores, row_cnt);
+    T2P_CHECK_LAUNCH("rank_rows");
+    hipLaunchKernelGGL(k_rank_diag, dim3((unsigned)batch), dim3(256), 0, st, scores, batch, margin, row_cnt, d_scores);
+    T2P_CHECK_LAUNCH("rank_diag");
     return 0;
 }
 

@@ -98,6 +98,8 @@ int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const fl
 int launch_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
                         const float* rot, int64_t n_obj, int n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
                         hipStream_t st);
+int launch_pairwise_ranking(const float* scores, int batch, float margin, float* row_loss, float* d_scores, float* row_cnt,
+                            hipStream_t st);
 int launch_cell_index(const int32_t* cell_ptr, int n_cells, int32_t o_lo, int32_t* seg_ptr_local, int32_t* first,
                       hipStream_t st);
 

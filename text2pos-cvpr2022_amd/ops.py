@@ -365,6 +365,21 @@ def encode_text(tokens: torch.Tensor, lengths: torch.Tensor, weights: L.TextWeig
     return (out, raw) if want_raw else out
 
 
+def pairwise_ranking(scores: torch.Tensor, margin: float):
+    """scores [B, B] fp32 -> (row_loss [B], d_scores [B, B]) of PairwiseRankingLoss (t2p_pairwise_ranking)."""
+    _need(scores, "scores", torch.float32, 2)
+    b = scores.shape[0]
+    if scores.shape[1] != b:
+        raise RuntimeError("pairwise_ranking: scores must be square")
+    dev = scores.device
+    row_loss = torch.empty((b,), dtype=torch.float32, device=dev)
+    row_cnt = torch.empty((b,), dtype=torch.float32, device=dev)
+    d_scores = torch.empty_like(scores)
+    L.check(L.lib().t2p_pairwise_ranking(_ptr(scores), b, float(margin), _ptr(row_loss), _ptr(d_scores), _ptr(row_cnt),
+                                         _stream(dev)), "t2p_pairwise_ranking")
+    return row_loss, d_scores
+
+
 def lstm_cell_forward(pre, table, tokens, lengths, step: int, reverse: bool, c_prev, h_prev, gates, c, h):
     """One training-mode LSTM step (t2p_lstm_cell_forward): pre [B,4D] = h_prev @ W_hh^T, table [V,4D]; writes gates
     [B,4D] (i, f, g, o), c, h [B,D] in place."""
