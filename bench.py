@@ -275,6 +275,13 @@ def main():
         achieved = (flops_per_step * args.steps) / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
         peak = F16_MFMA_PEAK_TFLOPS if args.precision == "f16x3" else FP32_MFMA_PEAK_TFLOPS
         phases = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        # FPS / ball query are scan-type (latency / issue bound); their compulsory read is the object's xyz + rgb
+        # (6,168 B): report the HBM rate that corresponds to, as overhead against the encoder's MFMA bound
+        sg_launches, sg_ms = prof.get("sample_group", (0, 0.0))
+        if sg_ms > 0:
+            gbps = 6168.0 * n_obj * args.steps / (sg_ms * 1e-3) / 1e9
+            phase_rates["roofline"]["sample_group"] = {"bound": "latency / issue (scan)", "achieved_gbps": gbps, "peak_gbps": 8000.0,
+                                                       "frac": gbps / 8000.0, "ms_per_step": sg_ms / args.steps}
         # HBM traffic of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this command;
         # bench.py cannot host rocprofv3 itself): newest profiles/*_pmc_traffic.json, kernel k_ws_sa<256, 256, ...>
         traffic = None
