@@ -26,6 +26,9 @@ PARITY STATUS
   * fine stage (oracle/fine.py: SuperGlue matcher, offsets, get_pos_in_cell): PINNED -- tests/golden/fine.npz holds
     outputs of the reference's own models/superglue.py::SuperGlue (pure torch, executed unmodified) and of its
     SuperGlueMatch.forward glue; the object encoder underneath shares the primitives' "unpinned" status above.
+  * training-mode text branch / PairwiseRankingLoss: PINNED by direct execution -- the gradient tests differentiate
+    OracleLanguageEncoder (torch's own nn.Embedding + packed nn.LSTM, what the reference calls) with torch.autograd,
+    and the loss test restates training/losses.py:138-164 in fp64 with autograd.
 """
 import ctypes
 import os
