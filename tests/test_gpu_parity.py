@@ -527,6 +527,79 @@ def test_text_branch_learns_against_fixed_cell_embeddings(hip_model, vocab):
     assert losses[-1] < 0.8 * losses[0], losses
 
 
+def _segments(sizes):
+    return torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
+
+
+@pytest.mark.parametrize("sizes,c,relu", [([50], 64, True), ([7, 2, 300, 33], 96, True), ([2, 2, 5], 32, False),
+                                          ([1000, 3], 256, True)])
+def test_bn_relu_train_matches_torch_per_segment(sizes, c, relu):
+    """Batch-statistics BatchNorm1d (+ReLU) per row segment == calling torch's BatchNorm1d in train() once per segment,
+    in order (models/modules.py:21-29 under model.train(); per-cell statistics, models/object_encoder.py:92-95): output,
+    input / weight / bias gradients and the running estimates; 1e-4 bar."""
+    from text2pos_amd import train_ops as TO
+    g = torch.Generator().manual_seed(len(sizes) * 100 + c)
+    m = int(sum(sizes))
+    x = torch.randn(m, c, generator=g) * 2.0 + 0.5
+    coef = torch.randn(m, c, generator=g)
+    ref = torch.nn.BatchNorm1d(c)
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(c, generator=g))          # negative scales included
+        ref.bias.copy_(torch.randn(c, generator=g))
+        ref.running_mean.copy_(torch.randn(c, generator=g))
+        ref.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    import copy
+    mine = copy.deepcopy(ref).to(_dev())
+    ref.train()
+    mine.train()
+    xr = x.clone().requires_grad_(True)
+    outs, lo = [], 0
+    for n in sizes:
+        if n == 1:      # torch refuses a single row in training mode; so does the reference's pipeline (cells have >= 6 objects)
+            pytest.skip("single-row segments are not reachable in torch")
+        y = ref(xr[lo: lo + n])
+        outs.append(torch.relu(y) if relu else y)
+        lo += n
+    want = torch.cat(outs)
+    (want * coef).sum().backward()
+    xm = x.to(_dev()).requires_grad_(True)
+    got = TO.bn_relu_train(xm, _segments(sizes).to(_dev()), mine, relu)
+    (got * coef.to(_dev())).sum().backward()
+    assert (got.detach().cpu() - want.detach()).abs().max().item() < TOL
+    assert (xm.grad.cpu() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+    for a, b in ((mine.weight.grad, ref.weight.grad), (mine.bias.grad, ref.bias.grad)):
+        assert (a.cpu() - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
+    assert (mine.running_mean.cpu() - ref.running_mean).abs().max().item() < 1e-5
+    assert (mine.running_var.cpu() - ref.running_var).abs().max().item() < 1e-4
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == len(sizes)
+
+
+def test_segment_max_and_linear_match_torch():
+    """Segment max (PointConv / global_max_pool / DynamicEdgeConv aggregation over rows sorted by destination) and Linear on
+    the tiled GEMM, forward and backward, against torch; K = 67 exercises the zero-padded operand."""
+    from text2pos_amd import train_ops as TO
+    g = torch.Generator().manual_seed(4)
+    sizes = [5, 1, 33, 8, 17]
+    m = sum(sizes)
+    x = torch.randn(m, 67, generator=g)
+    lin = torch.nn.Linear(67, 128)
+    coef = torch.randn(len(sizes), 128, generator=g)
+    xr = x.clone().requires_grad_(True)
+    h = torch.relu(lin(xr))
+    want = torch.stack([h[lo: lo + n].max(0).values for lo, n in zip(np.concatenate([[0], np.cumsum(sizes)[:-1]]), sizes)])
+    (want * coef).sum().backward()
+    import copy
+    lin_d = copy.deepcopy(lin).to(_dev())
+    lin_d.zero_grad()
+    xm = x.to(_dev()).requires_grad_(True)
+    got = TO.segment_max(torch.relu(TO.linear(xm, lin_d)), _segments(sizes).to(_dev()))
+    (got * coef.to(_dev())).sum().backward()
+    assert (got.detach().cpu() - want.detach()).abs().max().item() < 1e-5
+    assert (xm.grad.cpu() - xr.grad).abs().max().item() < 1e-5
+    assert (lin_d.weight.grad.cpu() - lin.weight.grad).abs().max().item() < 1e-4
+    assert (lin_d.bias.grad.cpu() - lin.bias.grad).abs().max().item() < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # retrieval
 # ---------------------------------------------------------------------------------------------------------------

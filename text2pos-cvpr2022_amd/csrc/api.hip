@@ -589,6 +589,39 @@ int t2p_pairwise_ranking(const float* scores, int32_t batch, float margin, float
     return launch_pairwise_ranking(scores, batch, margin, row_loss, d_scores, row_count, (hipStream_t)stream);
 }
 
+int t2p_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, const float* gamma,
+                              const float* beta, float eps, int32_t relu, float* y, float* mean, float* invstd,
+                              float* var_unbiased, t2p_stream_t stream) {
+    T2P_CHECK_ARG(x && seg_ptr && gamma && beta && y && mean && invstd && var_unbiased, "bn_relu_train_forward: NULL argument");
+    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1, "bn_relu_train_forward: bad sizes");
+    return launch_bn_relu_train_forward(x, seg_ptr, n_seg, channels, gamma, beta, eps, relu, y, mean, invstd, var_unbiased,
+                                        (hipStream_t)stream);
+}
+
+int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int32_t n_seg,
+                               int32_t channels, const float* mean, const float* invstd, const float* gamma, int32_t relu,
+                               float* dx, float* dgamma_seg, float* dbeta_seg, t2p_stream_t stream) {
+    T2P_CHECK_ARG(dy && x && y && seg_ptr && mean && invstd && gamma && dx && dgamma_seg && dbeta_seg,
+                  "bn_relu_train_backward: NULL argument");
+    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1, "bn_relu_train_backward: bad sizes");
+    return launch_bn_relu_train_backward(dy, x, y, seg_ptr, n_seg, channels, mean, invstd, gamma, relu, dx, dgamma_seg,
+                                         dbeta_seg, (hipStream_t)stream);
+}
+
+int t2p_segment_max_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, float* out, int32_t* arg,
+                            t2p_stream_t stream) {
+    T2P_CHECK_ARG(x && seg_ptr && out && arg, "segment_max_forward: NULL argument");
+    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1, "segment_max_forward: bad sizes");
+    return launch_segment_max(x, seg_ptr, n_seg, channels, out, arg, (hipStream_t)stream);
+}
+
+int t2p_segment_max_backward(const float* dout, const int32_t* arg, const int32_t* seg_ptr, int32_t n_seg, int32_t channels,
+                             float* dx, t2p_stream_t stream) {
+    T2P_CHECK_ARG(dout && arg && seg_ptr && dx, "segment_max_backward: NULL argument");
+    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1, "segment_max_backward: bad sizes");
+    return launch_segment_max_backward(dout, arg, seg_ptr, n_seg, channels, dx, (hipStream_t)stream);
+}
+
 size_t t2p_sim_topk_workspace_bytes(int64_t nq, int64_t nc, int32_t k) { return sim_topk_workspace_bytes(nq, nc, k); }
 
 int t2p_sim_topk(const float* queries, const float* cells, int64_t nq, int64_t nc, int32_t dim, int32_t k,

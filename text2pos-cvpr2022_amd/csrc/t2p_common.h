@@ -180,6 +180,17 @@ int launch_lstm_cell_bwd(const float* dh_gemm, const float* dh_carry_in, const f
                          const float* c_prev, const float* c, const int32_t* lengths, int64_t B, int D, int step, float* d_pre,
                          float* dc_out, float* dh_carry_out, hipStream_t st);
 
+// ---- train_ops.hip --------------------------------------------------------------------------------------------
+int launch_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int n_seg, int C, const float* gamma,
+                                 const float* beta, float eps, int relu, float* y, float* mean, float* invstd,
+                                 float* var_unbiased, hipStream_t st);
+int launch_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int n_seg, int C,
+                                  const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
+                                  float* dgamma_seg, float* dbeta_seg, hipStream_t st);
+int launch_segment_max(const float* x, const int32_t* seg_ptr, int n_seg, int C, float* out, int32_t* arg, hipStream_t st);
+int launch_segment_max_backward(const float* dout, const int32_t* arg, const int32_t* seg_ptr, int n_seg, int C, float* dx,
+                                hipStream_t st);
+
 // ---- sim_topk.hip -----------------------------------------------------------------------------------------
 size_t sim_topk_workspace_bytes(int64_t nq, int64_t nc, int k);
 int launch_sim_topk(const float* Q, const float* C, int64_t nq, int64_t nc, int dim, int k, int64_t c_index_offset,

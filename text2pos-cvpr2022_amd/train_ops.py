@@ -1,0 +1,121 @@
+"""Autograd building blocks of the training-mode cell branch (second part), backed by
+csrc/train_ops.hip through the C ABI: batch-statistics BatchNorm1d (+ReLU) over row segments, segment max with the winning
+row remembered, and Linear on the tiled GEMM.  The reference layers they stand for: `get_mlp` blocks in `model.train()`
+(models/modules.py:21-29; PointNet++ layers take their statistics per cell because the reference runs it once per cell,
+models/object_encoder.py:92-95), `PointConv(aggr="max")`, `gnn.global_max_pool`, `DynamicEdgeConv(aggr="max")`
+(models/pointcloud/pointnet2.py:31-49, models/cell_retrieval.py:46-49, :96-99)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import _need, _ptr, _stream
+
+
+class _BnReluTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg_ptr, gamma, beta, eps, relu):
+        _need(x, "x", torch.float32, 2)
+        dev = x.device
+        _need(seg_ptr, "seg_ptr", torch.int32, 1, dev)
+        _need(gamma, "gamma", torch.float32, 1, dev)
+        _need(beta, "beta", torch.float32, 1, dev)
+        m, c = x.shape
+        n_seg = seg_ptr.numel() - 1
+        y = torch.empty_like(x)
+        mean, invstd, var_u = (torch.empty((n_seg, c), dtype=torch.float32, device=dev) for _ in range(3))
+        L.check(L.lib().t2p_bn_relu_train_forward(_ptr(x), _ptr(seg_ptr), n_seg, c, _ptr(gamma.detach()), _ptr(beta.detach()),
+                                                  float(eps), int(bool(relu)), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(var_u),
+                                                  _stream(dev)), "t2p_bn_relu_train_forward")
+        ctx.save_for_backward(x, y, seg_ptr, mean, invstd, gamma.detach())
+        ctx.relu = bool(relu)
+        ctx.mark_non_differentiable(mean, var_u)
+        return y, mean, var_u
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        x, y, seg_ptr, mean, invstd, gamma = ctx.saved_tensors
+        dev = x.device
+        n_seg, c = mean.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg, db = (torch.empty((n_seg, c), dtype=torch.float32, device=dev) for _ in range(2))
+        L.check(L.lib().t2p_bn_relu_train_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(seg_ptr), n_seg, c, _ptr(mean), _ptr(invstd),
+                                                   _ptr(gamma), int(ctx.relu), _ptr(dx), _ptr(dg), _ptr(db), _stream(dev)),
+                "t2p_bn_relu_train_backward")
+        return dx, None, dg.sum(0), db.sum(0), None, None
+
+
+def bn_relu_train(x, seg_ptr, bn: torch.nn.BatchNorm1d, relu: bool = True):
+    """BatchNorm1d in training mode (+ ReLU) over the row segments seg_ptr [S+1] int32 (device), statistics per segment.
+    Updates bn.running_mean / running_var / num_batches_tracked once per segment, in order, exactly as S consecutive
+    calls of the module would (momentum bn.momentum, unbiased variance)."""
+    y, mean, var_u = _BnReluTrainFn.apply(x.contiguous(), seg_ptr, bn.weight, bn.bias, bn.eps, relu)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            s = mean.shape[0]
+            # r <- (1 - m) r + m stat, S times: closed form with weights m (1 - m)^(S-1-k)
+            w = mom * (1.0 - mom) ** torch.arange(s - 1, -1, -1, device=mean.device, dtype=torch.float32)
+            keep = (1.0 - mom) ** s
+            bn.running_mean.mul_(keep).add_((w[:, None] * mean).sum(0))
+            bn.running_var.mul_(keep).add_((w[:, None] * var_u).sum(0))
+            bn.num_batches_tracked += s
+    return y
+
+
+class _SegmentMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg_ptr):
+        _need(x, "x", torch.float32, 2)
+        dev = x.device
+        _need(seg_ptr, "seg_ptr", torch.int32, 1, dev)
+        n_seg, c = seg_ptr.numel() - 1, x.shape[1]
+        out = torch.empty((n_seg, c), dtype=torch.float32, device=dev)
+        arg = torch.empty((n_seg, c), dtype=torch.int32, device=dev)
+        L.check(L.lib().t2p_segment_max_forward(_ptr(x), _ptr(seg_ptr), n_seg, c, _ptr(out), _ptr(arg), _stream(dev)),
+                "t2p_segment_max_forward")
+        ctx.save_for_backward(arg, seg_ptr)
+        ctx.rows = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        arg, seg_ptr = ctx.saved_tensors
+        n_seg, c = arg.shape
+        dx = torch.zeros((ctx.rows, c), dtype=torch.float32, device=dout.device)
+        L.check(L.lib().t2p_segment_max_backward(_ptr(dout.contiguous()), _ptr(arg), _ptr(seg_ptr), n_seg, c, _ptr(dx),
+                                                 _stream(dout.device)), "t2p_segment_max_backward")
+        return dx, None
+
+
+def segment_max(x, seg_ptr):
+    """Row-segment maximum [S, C] of x [M, C] (rows sorted by destination); gradient flows to the winning rows."""
+    return _SegmentMaxFn.apply(x.contiguous(), seg_ptr)
+
+
+class _LinearFn(torch.autograd.Function):
+    """x [M, K] @ weight[N, K]^T + bias on the tiled fp32-MFMA GEMM (t2p_gemm); dX on the same GEMM (weight is its k-major
+    operand), dW / db are reductions over the rows (library GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        k = x.shape[1]
+        pad = (-k) % 8                                     # the GEMM wants K % 4 == 0 and N % 8 == 0: zero columns
+        xp = torch.nn.functional.pad(x.detach(), (0, pad)).contiguous() if pad else x.detach().contiguous()
+        wp = torch.nn.functional.pad(weight.detach(), (0, pad)).contiguous() if pad else weight.detach().contiguous()
+        ctx.save_for_backward(xp, wp)
+        ctx.k = k
+        return ops.gemm(xp, wp.t().contiguous(), bias.detach().contiguous() if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wp = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.gemm(dy, wp)                              # [M, N] x [N, K]: the weight is its own k-major operand
+        return dx[:, : ctx.k], (dy.t() @ xp)[:, : ctx.k], dy.sum(0)
+
+
+def linear(x, lin: torch.nn.Linear):
+    return _LinearFn.apply(x, lin.weight, lin.bias)
