@@ -188,7 +188,11 @@ class OracleCellRetrieval(nn.Module):
 
     @torch.no_grad()
     def encode_objects_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, trace=None, class_idx=None, color_idx=None):
-        """xyz/rgb [Nobj,P,3] fp32 (already FixedPoints+NormalizeScale'd), center/mean_rgb [Nobj,3], cell_ptr [B+1]."""
+        return self.encode_objects_packed_grad(xyz, rgb, center, mean_rgb, cell_ptr, trace, class_idx, color_idx)
+
+    def encode_objects_packed_grad(self, xyz, rgb, center, mean_rgb, cell_ptr, trace=None, class_idx=None, color_idx=None):
+        """xyz/rgb [Nobj,P,3] fp32 (already FixedPoints+NormalizeScale'd), center/mean_rgb [Nobj,3], cell_ptr [B+1].
+        (No no_grad: the training-mode tests differentiate this with torch.autograd, in train() mode.)"""
         xyz, rgb = torch.as_tensor(xyz).float(), torch.as_tensor(rgb).float()
         cell_ptr = [int(v) for v in cell_ptr]
         p = xyz.shape[1]

@@ -113,9 +113,9 @@ def _scatter(msg, index, n_out, aggr):
     c = msg.shape[1]
     if aggr == "max":
         out = torch.full((n_out, c), float("-inf"), dtype=msg.dtype)
-        out.scatter_reduce_(0, index[:, None].expand(-1, c), msg, reduce="amax", include_self=True)
-        out[out == float("-inf")] = 0.0  # PyG fills empty segments with 0
-        return out
+        out = out.scatter_reduce(0, index[:, None].expand(-1, c), msg, reduce="amax", include_self=True)
+        # PyG fills empty segments with 0 (out of place: the training-mode tests differentiate through this)
+        return torch.where(out == float("-inf"), torch.zeros_like(out), out)
     if aggr == "mean":
         out = torch.zeros((n_out, c), dtype=msg.dtype)
         out.index_add_(0, index, msg)

@@ -185,11 +185,11 @@ def test_forward_raises_like_the_reference_and_train_mode_is_refused():
     with pytest.raises(Exception, match="Not implemented"):
         m.forward()
     m.train()
-    objs, pts, _ = _cell(2)
-    with pytest.raises(NotImplementedError):     # cell branch: batch-statistics BatchNorm is not built
-        m.encode_objects([objs], [pts])
-    with pytest.raises(RuntimeError, match="no CPU path"):   # text branch trains on the GPU only
+    with pytest.raises(RuntimeError, match="no CPU path"):   # both branches train on the GPU only
         m.encode_text(["north"])
+    objs, pts, _ = _cell(2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.encode_objects([objs], [pts])
 
 
 # ---- input packing -------------------------------------------------------------------------------------------------

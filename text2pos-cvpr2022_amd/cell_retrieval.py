@@ -80,14 +80,21 @@ class CellRetrievalNetwork(nn.Module):
 
     def _check_forward_only(self):
         if self.training:
-            raise NotImplementedError("training-mode forward (batch-statistics BatchNorm) is not built; call .eval()")
+            raise NotImplementedError("training-mode forward (batch-statistics BatchNorm) is not built for this entry "
+                                      "point; call .eval()")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the HIP path is forward-only; call it under torch.no_grad()")
+            raise NotImplementedError("the inference kernels are forward-only (BatchNorm folded): call them under "
+                                      "torch.no_grad(), or put the model in train() for the training-mode path")
 
     def encode_objects_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, cell_ptr_dev=None, want_trace=False,
                               chunk_objects=0, class_idx=None, color_idx=None):
         """Device-resident packed inputs: xyz/rgb [Nobj, P, 3], center/mean_rgb [Nobj, 3] (fp32, on self.device),
-        cell_ptr int32 [B+1] on the host.  Returns [B, D] L2-normalised."""
+        cell_ptr int32 [B+1] on the host.  Returns [B, D] L2-normalised.  In train() mode (training/coarse.py:32) the
+        batch-statistics path of train_cell.py runs instead of the folded inference kernels and the result carries a
+        grad_fn."""
+        if self.training and not want_trace and class_idx is None and color_idx is None:
+            from .train_cell import encode_objects_train
+            return encode_objects_train(self, xyz, rgb, center, mean_rgb, cell_ptr)
         self._check_forward_only()
         cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int32)
         if cell_ptr_dev is None:
@@ -136,8 +143,7 @@ class CellRetrievalNetwork(nn.Module):
 
     def encode_objects(self, objects, object_points):
         """objects: List[List[Object3d]], object_points: List[Batch] (one PyG-style batch per cell)
-        -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:77-107)."""
-        self._check_forward_only()
+        -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:77-107).  train() mode: see encode_objects_packed."""
         n_pts = int(getattr(self.args, "pointnet_numpoints", 256))
         zero_color = "color" not in self.args.use_features  # models/object_encoder.py:86-90
         xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, n_pts, zero_color)
@@ -160,7 +166,6 @@ class CellRetrievalNetwork(nn.Module):
         dataloading/kitti360pose/utils.py:99-109, training/coarse.py:192-199) and the per-object means run on the GPU
         (csrc/small_kernels.hip::k_pack_objects); only the random draws stay on the host."""
         from .data import draw_rotations, flatten_raw_objects
-        self._check_forward_only()
         n_pts = int(getattr(self.args, "pointnet_numpoints", 256))
         raw_xyz, raw_rgb, obj_ptr, sample_idx, cell_ptr = flatten_raw_objects(objects, n_pts, generator)
         dev = self.device

@@ -1,0 +1,123 @@
+"""Training-mode forward of the cell branch with a backward pass (second part): what
+`positive = model.encode_objects(...)` computes under `model.train()` in training/coarse.py:32-58.
+
+Same graph as the inference kernels, but every BatchNorm1d normalises with the statistics of the current rows
+(models/modules.py:21-29 in train mode) - per CELL inside the PointNet++, which the reference runs once per cell
+(models/object_encoder.py:92-95), over the whole batch elsewhere - so nothing is folded.  A first correct path:
+  * index-producing stages (FPS, ball query, kNN) are the inference kernels (t2p_sample_group, t2p_knn): no gradient
+    flows through them in the reference either;
+  * the arithmetic runs on the HIP building blocks of train_ops.py (Linear on the tiled GEMM, batch-statistics
+    BatchNorm + ReLU per segment, segment max with arg-max routing);
+  * edge lists, gathers, concatenations, ReLU of the two plain Linear heads and F.normalize are torch tensor ops (with
+    their autograd): data movement around the kernels.
+The PointConv self-loop rewrite of torch_geometric (remove edges whose two CELL-local indices agree, append (i, i) for
+every centroid row i of the cell: dense row i of the cell feeds centroid row i) is reproduced on the edge lists exactly as
+the inference path encodes it in its row tables."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from . import train_ops as TO
+
+
+def _i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+def _ptr_from_counts(counts):
+    """[n] counts -> int32 [n + 1] row pointer (device)."""
+    return _i32(torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]))
+
+
+def _mlp_train(x, mlp, seg_ptr):
+    """get_mlp block list (Linear, BatchNorm1d, ReLU) in training mode; statistics per row segment."""
+    for blk in mlp:
+        x = TO.bn_relu_train(TO.linear(x, blk[0]), seg_ptr, blk[1], relu=True)
+    return x
+
+
+def _sa_edges(nbr, cnt, first_obj, nd, nc, self_loops):
+    """Edge list (source dense row, target centroid row) of one set-abstraction level over all objects, sorted by target.
+    nbr [n_obj, nc, 32] / cnt [n_obj, nc]: ball-query hits as indices local to the object's dense set; first_obj [n_obj]:
+    first object of the object's cell."""
+    n_obj = cnt.shape[0]
+    dev = cnt.device
+    hit = torch.arange(32, device=dev)[None, None, :] < cnt.long()[:, :, None]
+    o, c, k = hit.nonzero(as_tuple=True)                       # lexicographic: already sorted by (object, centroid)
+    src = o * nd + nbr[o, c, k].long()
+    dst = o * nc + c
+    if self_loops:
+        f = first_obj[o]
+        keep = (src - f * nd) != (dst - f * nc)                # remove_self_loops on the cell-local indices
+        src, dst = src[keep], dst[keep]
+        rows = torch.arange(n_obj * nc, device=dev)            # every centroid row r: dense row with the same cell-local index
+        fr = first_obj[rows // nc]
+        src = torch.cat([src, fr * nd + (rows - fr * nc)])
+        dst = torch.cat([dst, rows])
+        order = torch.sort(dst, stable=True).indices
+        src, dst = src[order], dst[order]
+    return src, dst
+
+
+def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr):
+    """model: CellRetrievalNetwork in train(); packed device inputs as encode_objects_packed.  Returns [B, D] unit rows with
+    a grad_fn; BatchNorm running estimates are updated as the reference's per-cell / per-batch module calls would."""
+    a = model.args
+    if getattr(a, "class_embed", False) or getattr(a, "color_embed", False):
+        raise NotImplementedError("training with --class_embed / --color_embed is not built")
+    if model.variation != 0:
+        raise NotImplementedError("training with variation=1 (mean aggregation) is not built")
+    dev = xyz.device
+    oe, pn = model.object_encoder, model.object_encoder.pointnet
+    n_obj, n_pts = xyz.shape[0], xyz.shape[1]
+    cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int64)
+    n_cells = cp.shape[0] - 1
+    sizes = torch.from_numpy(cp[1:] - cp[:-1]).to(dev)
+    first_obj = torch.repeat_interleave(torch.from_numpy(cp[:-1]).to(dev), sizes)       # [n_obj]
+    cell_of_obj = torch.repeat_interleave(torch.arange(n_cells, device=dev), sizes)
+    cell_ptr_dev = _i32(torch.from_numpy(cp).to(dev))
+    one = lambda n: torch.tensor([0, n], dtype=torch.int32, device=dev)
+
+    parts = []
+    if "class" in a.use_features:
+        gt = ops.sample_group(xyz.contiguous(), pn.radii)
+        pos = xyz.reshape(n_obj * n_pts, 3)
+        x = rgb.reshape(n_obj * n_pts, 3)
+        if "color" not in a.use_features:                       # models/object_encoder.py:87-90
+            x = torch.zeros_like(x)
+        nd = n_pts
+        for lvl, sa in enumerate((pn.sa1, pn.sa2, pn.sa3)):
+            nc = (nd + 1) // 2
+            fps = gt["fps_idx"][lvl].long()
+            pos_c = pos.view(n_obj, nd, 3).gather(1, fps[:, :, None].expand(-1, -1, 3)).reshape(n_obj * nc, 3)
+            src, dst = _sa_edges(gt["nbr"][lvl], gt["cnt"][lvl], first_obj, nd, nc, model.add_self_loops)
+            cent_ptr = _ptr_from_counts(torch.bincount(dst, minlength=n_obj * nc))
+            cell_edge_ptr = _ptr_from_counts(torch.bincount(cell_of_obj[dst // nc], minlength=n_cells))
+            msg = torch.cat([x[src], pos[src] - pos_c[dst]], dim=1)
+            h = _mlp_train(msg, sa.point_conv.local_nn, cell_edge_ptr)
+            x, pos, nd = TO.segment_max(h, cent_ptr), pos_c, nc
+        h = _mlp_train(torch.cat([x, pos], dim=1), pn.ga.mlp, _i32(cell_ptr_dev.long() * nd))
+        f0 = TO.segment_max(h, _i32(torch.arange(n_obj + 1, device=dev) * nd))
+        f1 = torch.relu(TO.linear(f0, pn.lin1))
+        f2 = torch.relu(TO.linear(f1, pn.lin2))
+        feats = (f0, f1, f2)[a.pointnet_features]
+        parts.append(F.normalize(_mlp_train(feats, oe.mlp_pointnet, one(n_obj)), dim=-1))
+    if "color" in a.use_features:
+        parts.append(F.normalize(_mlp_train(mean_rgb.float(), oe.color_encoder, one(n_obj)), dim=-1))
+    if "position" in a.use_features:
+        parts.append(F.normalize(_mlp_train(center.float(), oe.pos_encoder, one(n_obj)), dim=-1))
+    emb = _mlp_train(torch.cat(parts, dim=-1), oe.mlp_merge, one(n_obj)) if len(parts) > 1 else parts[0]
+    emb = F.normalize(emb, dim=-1)
+
+    # DynamicEdgeConv(k = 8, max) inside each cell (models/cell_retrieval.py:46-48, :97), pool, lin, normalize (:98-106)
+    k = model.graph1.k
+    knn = ops.knn(emb.detach().contiguous(), cell_ptr_dev, k, max_seg_rows=int((cp[1:] - cp[:-1]).max()))
+    valid = knn >= 0
+    tgt = torch.arange(n_obj, device=dev)[:, None].expand(-1, k)[valid]
+    srcn = knn[valid].long()
+    msg = torch.cat([emb[tgt], emb[srcn] - emb[tgt]], dim=-1)
+    h = _mlp_train(msg, model.graph1.nn, one(msg.shape[0]))
+    xg = TO.segment_max(h, _ptr_from_counts(valid.sum(1)))
+    xc = TO.segment_max(xg, cell_ptr_dev)
+    return F.normalize(_mlp_train(xc, model.lin, one(n_cells)), dim=-1)
