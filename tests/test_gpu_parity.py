@@ -656,6 +656,38 @@ def test_cell_branch_training_step_matches_autograd(vocab):
             assert int(b) == int(rb[name]), name
 
 
+def test_coarse_training_loop_lowers_the_loss(vocab):
+    """training/coarse.py:31-62 (train_epoch) on the HIP path: model.train(); anchor = encode_text(texts); positive =
+    encode_objects(...); loss = PairwiseRankingLoss(0.35)(anchor, positive); backward; Adam step - a handful of steps on
+    one batch of 8 (cell, description) pairs must lower the loss, and eval-mode inference afterwards runs on the folded
+    kernels with the updated weights and running estimates."""
+    import weights as W
+    import text2pos_amd as t2p
+    from text2pos_amd import synthetic as S
+    model = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
+    W.fill_state_dict(model, 29)
+    model = model.to(_dev())
+    cells = _to_dev(*S.make_cells(41, 8)[:4])
+    cell_ptr = S.make_cells(41, 8)[4]
+    texts = S.make_texts(41, 0, 8, n_hints=2)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = t2p.PairwiseRankingLoss(0.35)
+    model.train()
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = crit(model.encode_text(texts), model.encode_objects_packed(*cells, cell_ptr))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
+    model.eval()
+    with torch.no_grad():
+        out = model.encode_objects_packed(*cells, cell_ptr)
+    assert out.shape == (8, 256) and bool(torch.isfinite(out).all())
+    assert (out.norm(dim=1) - 1).abs().max().item() < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # retrieval
 # ---------------------------------------------------------------------------------------------------------------
