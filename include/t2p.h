@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 10
+#define T2P_ABI_VERSION 11
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -284,17 +284,21 @@ int t2p_lstm_cell_backward(const float* dh_gemm, const float* dh_carry_in, const
  * BatchNorm1d in training mode + optional ReLU over row SEGMENTS (models/modules.py:21-29 in model.train(); the reference
  * runs its PointNet++ once per cell, models/object_encoder.py:92-95, so those layers take their statistics per cell):
  * x, y [M][C] fp32; seg_ptr [n_seg+1] int32 (device) tiles the rows; mean / invstd / var_unbiased [n_seg][C] (biased
- * variance normalises, the unbiased one feeds the running estimate; float64 accumulation, fixed order).
+ * variance normalises, the unbiased one feeds the running estimate; float64 accumulation in a fixed order: row chunks of a
+ * segment are reduced by separate workgroups into `workspace` - t2p_bn_train_workspace_bytes - and combined in order).
  * backward: dx [M][C]; dgamma_seg / dbeta_seg [n_seg][C] per segment (the caller sums them over the segments).
  * Segment max (PointConv aggr="max", gnn.global_max_pool, DynamicEdgeConv aggr="max" over rows sorted by destination):
  * out [n_seg][C], arg [n_seg][C] = winning row (first one on ties, -1 and out = 0 for an empty segment); the backward
  * routes dout to the winning rows. */
-int t2p_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, const float* gamma,
-                              const float* beta, float eps, int32_t relu, float* y, float* mean, float* invstd,
-                              float* var_unbiased, t2p_stream_t stream);
+size_t t2p_bn_train_workspace_bytes(int64_t rows, int32_t n_seg, int32_t channels);
+int t2p_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int64_t rows, int32_t channels,
+                              const float* gamma, const float* beta, float eps, int32_t relu, float* y, float* mean,
+                              float* invstd, float* var_unbiased, void* workspace, size_t workspace_bytes,
+                              t2p_stream_t stream);
 int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int32_t n_seg,
-                               int32_t channels, const float* mean, const float* invstd, const float* gamma, int32_t relu,
-                               float* dx, float* dgamma_seg, float* dbeta_seg, t2p_stream_t stream);
+                               int64_t rows, int32_t channels, const float* mean, const float* invstd, const float* gamma,
+                               int32_t relu, float* dx, float* dgamma_seg, float* dbeta_seg, void* workspace,
+                               size_t workspace_bytes, t2p_stream_t stream);
 int t2p_segment_max_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, float* out, int32_t* arg,
                             t2p_stream_t stream);
 int t2p_segment_max_backward(const float* dout, const int32_t* arg, const int32_t* seg_ptr, int32_t n_seg, int32_t channels,

@@ -589,23 +589,39 @@ int t2p_pairwise_ranking(const float* scores, int32_t batch, float margin, float
     return launch_pairwise_ranking(scores, batch, margin, row_loss, d_scores, row_count, (hipStream_t)stream);
 }
 
-int t2p_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, const float* gamma,
-                              const float* beta, float eps, int32_t relu, float* y, float* mean, float* invstd,
-                              float* var_unbiased, t2p_stream_t stream) {
+size_t t2p_bn_train_workspace_bytes(int64_t rows, int32_t n_seg, int32_t channels) {
+    return bn_train_workspace_bytes(rows, n_seg, channels);
+}
+
+int t2p_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int64_t rows, int32_t channels,
+                              const float* gamma, const float* beta, float eps, int32_t relu, float* y, float* mean,
+                              float* invstd, float* var_unbiased, void* workspace, size_t workspace_bytes,
+                              t2p_stream_t stream) {
     T2P_CHECK_ARG(x && seg_ptr && gamma && beta && y && mean && invstd && var_unbiased, "bn_relu_train_forward: NULL argument");
-    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1, "bn_relu_train_forward: bad sizes");
-    return launch_bn_relu_train_forward(x, seg_ptr, n_seg, channels, gamma, beta, eps, relu, y, mean, invstd, var_unbiased,
-                                        (hipStream_t)stream);
+    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1 && rows >= 0, "bn_relu_train_forward: bad sizes");
+    if (n_seg > 0 && (workspace == nullptr || workspace_bytes < bn_train_workspace_bytes(rows, n_seg, channels))) {
+        set_error("bn_relu_train_forward: workspace %zu B < required %zu B", workspace_bytes,
+                  bn_train_workspace_bytes(rows, n_seg, channels));
+        return T2P_E_WORKSPACE;
+    }
+    return launch_bn_relu_train_forward(x, seg_ptr, n_seg, rows, channels, gamma, beta, eps, relu, y, mean, invstd,
+                                        var_unbiased, (double*)workspace, (hipStream_t)stream);
 }
 
 int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int32_t n_seg,
-                               int32_t channels, const float* mean, const float* invstd, const float* gamma, int32_t relu,
-                               float* dx, float* dgamma_seg, float* dbeta_seg, t2p_stream_t stream) {
+                               int64_t rows, int32_t channels, const float* mean, const float* invstd, const float* gamma,
+                               int32_t relu, float* dx, float* dgamma_seg, float* dbeta_seg, void* workspace,
+                               size_t workspace_bytes, t2p_stream_t stream) {
     T2P_CHECK_ARG(dy && x && y && seg_ptr && mean && invstd && gamma && dx && dgamma_seg && dbeta_seg,
                   "bn_relu_train_backward: NULL argument");
-    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1, "bn_relu_train_backward: bad sizes");
-    return launch_bn_relu_train_backward(dy, x, y, seg_ptr, n_seg, channels, mean, invstd, gamma, relu, dx, dgamma_seg,
-                                         dbeta_seg, (hipStream_t)stream);
+    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1 && rows >= 0, "bn_relu_train_backward: bad sizes");
+    if (n_seg > 0 && (workspace == nullptr || workspace_bytes < bn_train_workspace_bytes(rows, n_seg, channels))) {
+        set_error("bn_relu_train_backward: workspace %zu B < required %zu B", workspace_bytes,
+                  bn_train_workspace_bytes(rows, n_seg, channels));
+        return T2P_E_WORKSPACE;
+    }
+    return launch_bn_relu_train_backward(dy, x, y, seg_ptr, n_seg, rows, channels, mean, invstd, gamma, relu, dx, dgamma_seg,
+                                         dbeta_seg, (double*)workspace, (hipStream_t)stream);
 }
 
 int t2p_segment_max_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, float* out, int32_t* arg,

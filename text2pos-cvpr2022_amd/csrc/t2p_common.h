@@ -181,12 +181,13 @@ int launch_lstm_cell_bwd(const float* dh_gemm, const float* dh_carry_in, const f
                          float* dc_out, float* dh_carry_out, hipStream_t st);
 
 // ---- train_ops.hip --------------------------------------------------------------------------------------------
-int launch_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int n_seg, int C, const float* gamma,
+size_t bn_train_workspace_bytes(int64_t rows, int n_seg, int C);
+int launch_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int n_seg, int64_t rows, int C, const float* gamma,
                                  const float* beta, float eps, int relu, float* y, float* mean, float* invstd,
-                                 float* var_unbiased, hipStream_t st);
-int launch_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int n_seg, int C,
-                                  const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
-                                  float* dgamma_seg, float* dbeta_seg, hipStream_t st);
+                                 float* var_unbiased, double* part, hipStream_t st);
+int launch_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int n_seg,
+                                  int64_t rows, int C, const float* mean, const float* invstd, const float* gamma, int relu,
+                                  float* dx, float* dgamma_seg, float* dbeta_seg, double* part, hipStream_t st);
 int launch_segment_max(const float* x, const int32_t* seg_ptr, int n_seg, int C, float* out, int32_t* arg, hipStream_t st);
 int launch_segment_max_backward(const float* dout, const int32_t* arg, const int32_t* seg_ptr, int n_seg, int C, float* dx,
                                 hipStream_t st);

@@ -24,33 +24,63 @@ __device__ __forceinline__ double combine4(double (*red)[kCols], int rl, int cl,
     return r;
 }
 
-// mean / 1/sqrt(var + eps) (biased variance, as BatchNorm1d normalises) of every column over the rows of a segment
-__global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, const int32_t* __restrict__ seg_ptr, int C,
-                                                  float eps, float* __restrict__ mean, float* __restrict__ invstd,
-                                                  float* __restrict__ var_unbiased) {
+// Row chunk z of gridDim.z of segment s: [lo, hi)
+__device__ __forceinline__ void chunk_rows(const int32_t* seg_ptr, int s, int& lo, int& hi, int& n) {
+    const int r0 = seg_ptr[s], r1 = seg_ptr[s + 1];
+    n = r1 - r0;
+    const int per = (n + (int)gridDim.z - 1) / (int)gridDim.z;
+    lo = r0 + (int)blockIdx.z * per;
+    hi = lo + per < r1 ? lo + per : r1;
+}
+
+// stage 1 of the statistics: per (segment, row chunk) partial sums of x and x^2 in float64; part [n_seg][R][2][C]
+__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x, const int32_t* __restrict__ seg_ptr, int C,
+                                                    double* __restrict__ part) {
     __shared__ double red[kRowsPar][kCols];
     const int s = blockIdx.x, cl = threadIdx.x % kCols, rl = threadIdx.x / kCols;
     const int c = blockIdx.y * kCols + cl;
-    const int r0 = seg_ptr[s], r1 = seg_ptr[s + 1], n = r1 - r0;
+    int lo, hi, n;
+    chunk_rows(seg_ptr, s, lo, hi, n);
     const bool ok = c < C;
-    double acc = 0.0;
-    for (int r = r0 + rl; r < r1; r += kRowsPar) acc += ok ? (double)x[(int64_t)r * C + c] : 0.0;
-    const double m = n > 0 ? combine4(red, rl, cl, acc) / (double)n : 0.0;
-    acc = 0.0;
-    for (int r = r0 + rl; r < r1; r += kRowsPar) {
-        const double d = ok ? (double)x[(int64_t)r * C + c] - m : 0.0;
-        acc += d * d;
+    double a0 = 0.0, a1 = 0.0;
+    for (int r = lo + rl; r < hi; r += kRowsPar) {
+        const double v = ok ? (double)x[(int64_t)r * C + c] : 0.0;
+        a0 += v;
+        a1 += v * v;
     }
-    const double ss = combine4(red, rl, cl, acc);
+    const double s0 = combine4(red, rl, cl, a0);
+    const double s1 = combine4(red, rl, cl, a1);
     if (ok && rl == 0) {
-        const double var = n > 0 ? ss / (double)n : 0.0;
-        mean[(int64_t)s * C + c] = (float)m;
-        invstd[(int64_t)s * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-        var_unbiased[(int64_t)s * C + c] = (float)(n > 1 ? ss / (double)(n - 1) : var);
+        double* p = part + (((int64_t)s * gridDim.z + blockIdx.z) * 2) * C;
+        p[c] = s0;
+        p[C + c] = s1;
     }
 }
+// stage 2: chunks combined in a fixed order -> mean, 1/sqrt(var + eps) (biased variance, as BatchNorm1d normalises), and
+// the unbiased variance for the running estimate
+__global__ void k_bn_finish(const double* __restrict__ part, const int32_t* __restrict__ seg_ptr, int n_seg, int C, int R,
+                            float eps, float* __restrict__ mean, float* __restrict__ invstd,
+                            float* __restrict__ var_unbiased) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_seg * C) return;
+    const int s = (int)(i / C), c = (int)(i % C);
+    const int n = seg_ptr[s + 1] - seg_ptr[s];
+    double s0 = 0.0, s1 = 0.0;
+    for (int z = 0; z < R; z++) {
+        const double* p = part + (((int64_t)s * R + z) * 2) * C;
+        s0 += p[c];
+        s1 += p[C + c];
+    }
+    const double m = n > 0 ? s0 / n : 0.0;
+    double ss = s1 - s0 * m;  // sum (x - m)^2
+    if (ss < 0.0) ss = 0.0;
+    const double var = n > 0 ? ss / n : 0.0;
+    mean[i] = (float)m;
+    invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    var_unbiased[i] = (float)(n > 1 ? ss / (n - 1) : var);
+}
 
-// y = act(gamma (x - mean) invstd + beta) for the rows of segment blockIdx.x
+// y = act(gamma (x - mean) invstd + beta) for the rows of chunk blockIdx.z of segment blockIdx.x
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const int32_t* __restrict__ seg_ptr, int C,
                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
@@ -58,47 +88,78 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
     const int s = blockIdx.x, cl = threadIdx.x % kCols, rl = threadIdx.x / kCols;
     const int c = blockIdx.y * kCols + cl;
     if (c >= C) return;
+    int lo, hi, n;
+    chunk_rows(seg_ptr, s, lo, hi, n);
     const float m = mean[(int64_t)s * C + c], is = invstd[(int64_t)s * C + c], g = gamma[c], b = beta[c];
-    for (int r = seg_ptr[s] + rl; r < seg_ptr[s + 1]; r += kRowsPar) {
+    for (int r = lo + rl; r < hi; r += kRowsPar) {
         const float v = (x[(int64_t)r * C + c] - m) * is * g + b;
         y[(int64_t)r * C + c] = relu ? fmaxf(v, 0.f) : v;
     }
 }
 
-// backward of the block above: dz = dy (y > 0);  dx = gamma invstd / n (n dz - sum dz - xhat sum(dz xhat));
-// per-segment dgamma = sum dz xhat, dbeta = sum dz (summed over the segments by the caller)
-__global__ __launch_bounds__(256) void k_bn_backward(const float* __restrict__ dy, const float* __restrict__ x,
-                                                     const float* __restrict__ y, const int32_t* __restrict__ seg_ptr, int C,
-                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                     const float* __restrict__ gamma, int relu, float* __restrict__ dx,
-                                                     float* __restrict__ dgamma_seg, float* __restrict__ dbeta_seg) {
+// backward, stage 1: per chunk partial sums of dz = dy (y > 0) and dz xhat; part [n_seg][R][2][C]
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ y, const int32_t* __restrict__ seg_ptr,
+                                                        int C, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, int relu,
+                                                        double* __restrict__ part) {
     __shared__ double red[kRowsPar][kCols];
     const int s = blockIdx.x, cl = threadIdx.x % kCols, rl = threadIdx.x / kCols;
     const int c = blockIdx.y * kCols + cl;
-    const int r0 = seg_ptr[s], r1 = seg_ptr[s + 1], n = r1 - r0;
+    int lo, hi, n;
+    chunk_rows(seg_ptr, s, lo, hi, n);
     const bool ok = c < C;
     const float m = ok ? mean[(int64_t)s * C + c] : 0.f, is = ok ? invstd[(int64_t)s * C + c] : 0.f;
     double a0 = 0.0, a1 = 0.0;
-    for (int r = r0 + rl; r < r1; r += kRowsPar) {
-        if (!ok) break;
+    if (ok)
+        for (int r = lo + rl; r < hi; r += kRowsPar) {
+            const int64_t i = (int64_t)r * C + c;
+            const float dz = (!relu || y[i] > 0.f) ? dy[i] : 0.f;
+            a0 += (double)dz;
+            a1 += (double)dz * (double)((x[i] - m) * is);
+        }
+    const double s0 = combine4(red, rl, cl, a0);
+    const double s1 = combine4(red, rl, cl, a1);
+    if (ok && rl == 0) {
+        double* p = part + (((int64_t)s * gridDim.z + blockIdx.z) * 2) * C;
+        p[c] = s0;
+        p[C + c] = s1;
+    }
+}
+// stage 2: per-segment dbeta = sum dz, dgamma = sum dz xhat (chunks in a fixed order)
+__global__ void k_bn_bwd_finish(const double* __restrict__ part, int n_seg, int C, int R, float* __restrict__ dgamma_seg,
+                                float* __restrict__ dbeta_seg) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_seg * C) return;
+    const int s = (int)(i / C), c = (int)(i % C);
+    double s0 = 0.0, s1 = 0.0;
+    for (int z = 0; z < R; z++) {
+        const double* p = part + (((int64_t)s * R + z) * 2) * C;
+        s0 += p[c];
+        s1 += p[C + c];
+    }
+    dbeta_seg[i] = (float)s0;
+    dgamma_seg[i] = (float)s1;
+}
+// stage 3: dx = gamma invstd (dz - sum dz / n - xhat sum(dz xhat) / n)
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ y, const int32_t* __restrict__ seg_ptr, int C,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, int relu,
+                                                      const float* __restrict__ dgamma_seg,
+                                                      const float* __restrict__ dbeta_seg, float* __restrict__ dx) {
+    const int s = blockIdx.x, cl = threadIdx.x % kCols, rl = threadIdx.x / kCols;
+    const int c = blockIdx.y * kCols + cl;
+    if (c >= C) return;
+    int lo, hi, n;
+    chunk_rows(seg_ptr, s, lo, hi, n);
+    const float m = mean[(int64_t)s * C + c], is = invstd[(int64_t)s * C + c], g = gamma[c];
+    const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
+    const float sdz = dbeta_seg[(int64_t)s * C + c] * inv_n, sdx = dgamma_seg[(int64_t)s * C + c] * inv_n;
+    for (int r = lo + rl; r < hi; r += kRowsPar) {
         const int64_t i = (int64_t)r * C + c;
         const float dz = (!relu || y[i] > 0.f) ? dy[i] : 0.f;
-        a0 += (double)dz;
-        a1 += (double)dz * (double)((x[i] - m) * is);
-    }
-    const double sdz = combine4(red, rl, cl, a0);
-    const double sdx = combine4(red, rl, cl, a1);
-    if (!ok) return;
-    if (rl == 0) {
-        dgamma_seg[(int64_t)s * C + c] = (float)sdx;
-        dbeta_seg[(int64_t)s * C + c] = (float)sdz;
-    }
-    const float g = gamma[c], inv_n = n > 0 ? 1.f / (float)n : 0.f;
-    for (int r = r0 + rl; r < r1; r += kRowsPar) {
-        const int64_t i = (int64_t)r * C + c;
-        const float dz = (!relu || y[i] > 0.f) ? dy[i] : 0.f;
-        const float xh = (x[i] - m) * is;
-        dx[i] = g * is * (dz - (float)sdz * inv_n - xh * (float)sdx * inv_n);
+        dx[i] = g * is * (dz - sdz - (x[i] - m) * is * sdx);
     }
 }
 
@@ -144,27 +205,49 @@ __global__ __launch_bounds__(256) void k_segment_max_backward(const float* __res
 
 }  // namespace
 
-int launch_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int n_seg, int C, const float* gamma,
+// row chunks per segment: ~4 k rows per block for balanced segments, so that one big segment still fills the chip
+static int bn_chunks(int64_t rows, int n_seg) {
+    int64_t r = (rows / (n_seg > 0 ? n_seg : 1) + 4095) / 4096;
+    return (int)(r < 1 ? 1 : (r > 256 ? 256 : r));
+}
+
+int launch_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int n_seg, int64_t rows, int C, const float* gamma,
                                  const float* beta, float eps, int relu, float* y, float* mean, float* invstd,
-                                 float* var_unbiased, hipStream_t st) {
+                                 float* var_unbiased, double* part, hipStream_t st) {
     if (n_seg == 0) return 0;
-    const dim3 grid((unsigned)n_seg, (unsigned)((C + kCols - 1) / kCols));
-    hipLaunchKernelGGL(k_bn_stats, grid, dim3(256), 0, st, x, seg_ptr, C, eps, mean, invstd, var_unbiased);
-    T2P_CHECK_LAUNCH("bn_stats");
+    const int R = bn_chunks(rows, n_seg);
+    const dim3 grid((unsigned)n_seg, (unsigned)((C + kCols - 1) / kCols), (unsigned)R);
+    hipLaunchKernelGGL(k_bn_partial, grid, dim3(256), 0, st, x, seg_ptr, C, part);
+    T2P_CHECK_LAUNCH("bn_partial");
+    const int64_t sc = (int64_t)n_seg * C;
+    hipLaunchKernelGGL(k_bn_finish, dim3((unsigned)((sc + 255) / 256)), dim3(256), 0, st, part, seg_ptr, n_seg, C, R, eps, mean,
+                       invstd, var_unbiased);
+    T2P_CHECK_LAUNCH("bn_finish");
     hipLaunchKernelGGL(k_bn_apply, grid, dim3(256), 0, st, x, seg_ptr, C, mean, invstd, gamma, beta, relu, y);
     T2P_CHECK_LAUNCH("bn_apply");
     return 0;
 }
 
-int launch_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int n_seg, int C,
-                                  const float* mean, const float* invstd, const float* gamma, int relu, float* dx,
-                                  float* dgamma_seg, float* dbeta_seg, hipStream_t st) {
+int launch_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int n_seg,
+                                  int64_t rows, int C, const float* mean, const float* invstd, const float* gamma, int relu,
+                                  float* dx, float* dgamma_seg, float* dbeta_seg, double* part, hipStream_t st) {
     if (n_seg == 0) return 0;
-    const dim3 grid((unsigned)n_seg, (unsigned)((C + kCols - 1) / kCols));
-    hipLaunchKernelGGL(k_bn_backward, grid, dim3(256), 0, st, dy, x, y, seg_ptr, C, mean, invstd, gamma, relu, dx, dgamma_seg,
+    const int R = bn_chunks(rows, n_seg);
+    const dim3 grid((unsigned)n_seg, (unsigned)((C + kCols - 1) / kCols), (unsigned)R);
+    hipLaunchKernelGGL(k_bn_bwd_partial, grid, dim3(256), 0, st, dy, x, y, seg_ptr, C, mean, invstd, relu, part);
+    T2P_CHECK_LAUNCH("bn_bwd_partial");
+    const int64_t sc = (int64_t)n_seg * C;
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3((unsigned)((sc + 255) / 256)), dim3(256), 0, st, part, n_seg, C, R, dgamma_seg,
                        dbeta_seg);
-    T2P_CHECK_LAUNCH("bn_backward");
+    T2P_CHECK_LAUNCH("bn_bwd_finish");
+    hipLaunchKernelGGL(k_bn_bwd_apply, grid, dim3(256), 0, st, dy, x, y, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg,
+                       dbeta_seg, dx);
+    T2P_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
+}
+
+size_t bn_train_workspace_bytes(int64_t rows, int n_seg, int C) {
+    return (size_t)n_seg * bn_chunks(rows, n_seg) * 2 * C * sizeof(double);
 }
 
 int launch_segment_max(const float* x, const int32_t* seg_ptr, int n_seg, int C, float* out, int32_t* arg, hipStream_t st) {

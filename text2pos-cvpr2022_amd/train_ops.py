@@ -25,9 +25,11 @@ class _BnReluTrainFn(torch.autograd.Function):
         n_seg = seg_ptr.numel() - 1
         y = torch.empty_like(x)
         mean, invstd, var_u = (torch.empty((n_seg, c), dtype=torch.float32, device=dev) for _ in range(3))
-        L.check(L.lib().t2p_bn_relu_train_forward(_ptr(x), _ptr(seg_ptr), n_seg, c, _ptr(gamma.detach()), _ptr(beta.detach()),
-                                                  float(eps), int(bool(relu)), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(var_u),
-                                                  _stream(dev)), "t2p_bn_relu_train_forward")
+        ws = torch.empty((max(1, L.lib().t2p_bn_train_workspace_bytes(m, n_seg, c)),), dtype=torch.uint8, device=dev)
+        L.check(L.lib().t2p_bn_relu_train_forward(_ptr(x), _ptr(seg_ptr), n_seg, m, c, _ptr(gamma.detach()),
+                                                  _ptr(beta.detach()), float(eps), int(bool(relu)), _ptr(y), _ptr(mean),
+                                                  _ptr(invstd), _ptr(var_u), _ptr(ws), ws.numel(), _stream(dev)),
+                "t2p_bn_relu_train_forward")
         ctx.save_for_backward(x, y, seg_ptr, mean, invstd, gamma.detach())
         ctx.relu = bool(relu)
         ctx.mark_non_differentiable(mean, var_u)
@@ -41,9 +43,11 @@ class _BnReluTrainFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dg, db = (torch.empty((n_seg, c), dtype=torch.float32, device=dev) for _ in range(2))
-        L.check(L.lib().t2p_bn_relu_train_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(seg_ptr), n_seg, c, _ptr(mean), _ptr(invstd),
-                                                   _ptr(gamma), int(ctx.relu), _ptr(dx), _ptr(dg), _ptr(db), _stream(dev)),
-                "t2p_bn_relu_train_backward")
+        m = x.shape[0]
+        ws = torch.empty((max(1, L.lib().t2p_bn_train_workspace_bytes(m, n_seg, c)),), dtype=torch.uint8, device=dev)
+        L.check(L.lib().t2p_bn_relu_train_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(seg_ptr), n_seg, m, c, _ptr(mean),
+                                                   _ptr(invstd), _ptr(gamma), int(ctx.relu), _ptr(dx), _ptr(dg), _ptr(db),
+                                                   _ptr(ws), ws.numel(), _stream(dev)), "t2p_bn_relu_train_backward")
         return dx, None, dg.sum(0), db.sum(0), None, None
 
 
