@@ -600,20 +600,27 @@ def test_segment_max_and_linear_match_torch():
     assert (lin_d.bias.grad.cpu() - lin.bias.grad).abs().max().item() < 1e-4
 
 
-def test_cell_branch_training_step_matches_autograd(vocab):
+@pytest.mark.parametrize("use_features,pointnet_features,self_loops,grad_bar",
+                         [(["class", "color", "position"], 2, True, 5e-3), (["class", "position"], 1, False, 0.2)])
+def test_cell_branch_training_step_matches_autograd(vocab, use_features, pointnet_features, self_loops, grad_bar):
     """model.train(); positive = model.encode_objects(...); loss.backward() (training/coarse.py:32-58) on the HIP
     training-mode path against torch.autograd through the oracle in train() mode: batch-statistics BatchNorm per cell inside
     the PointNet++ and per batch elsewhere, gradients of every parameter that takes part, BatchNorm running estimates.
     Bars: 1e-4 on the unit-norm output; each gradient within 5e-3 of its largest entry (measured over three seeds: <= 3e-3
     in the SA3 layers, <= 1e-3 elsewhere; fp32 through ~20 batch-normalised layers, and the winners of near-tied maxima may
-    differ between the two implementations)."""
+    differ between the two implementations).  The second configuration (no colour feature, features1, plain ball-query
+    neighbourhoods) only guards against gross errors (bar 0.2): with the synthetic weights some objects get near-zero
+    feature rows in front of an F.normalize, which makes the gradients of this 3-cell batch ill-conditioned - the fp32
+    oracle itself deviates from its own float64 evaluation by up to 0.25 there (profiles/oracle_grad_conditioning.py) - while the
+    forward output still has to meet 1e-4."""
     import weights as W
     import text2pos_amd as t2p
     from oracle import model as OM
     from text2pos_amd import synthetic as S
-    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args())
+    kw = dict(use_features=use_features, pointnet_features=pointnet_features)
+    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(**kw), self_loops)
     W.fill_state_dict(om, 23)
-    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
+    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(**kw), self_loops)
     hm.load_state_dict(om.state_dict(), strict=True)
     hm = hm.to(_dev())
     om.train()
@@ -645,9 +652,9 @@ def test_cell_branch_training_step_matches_autograd(vocab):
         err = (p.grad.cpu() - g_ref).abs().max().item()
         # relative to the parameter's own largest gradient entry, with a floor of 1 % of the step's gradient scale
         # (parameters whose gradient nearly cancels - e.g. shifts a following BatchNorm removes - hold rounding noise)
-        assert err < 5e-3 * max(1e-2 * g_all, g_ref.abs().max().item()), (name, err, g_ref.abs().max().item(), g_all)
+        assert err < grad_bar * max(1e-2 * g_all, g_ref.abs().max().item()), (name, err, g_ref.abs().max().item(), g_all)
         checked += 1
-    assert checked >= 45
+    assert checked >= 35
     rb, hb = dict(om.named_buffers()), dict(hm.named_buffers())
     for name, b in hb.items():
         if name.endswith("running_mean") or name.endswith("running_var"):
