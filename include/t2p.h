@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 11
+#define T2P_ABI_VERSION 12
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -303,6 +303,21 @@ int t2p_segment_max_forward(const float* x, const int32_t* seg_ptr, int32_t n_se
                             t2p_stream_t stream);
 int t2p_segment_max_backward(const float* dout, const int32_t* arg, const int32_t* seg_ptr, int32_t n_seg, int32_t channels,
                              float* dx, t2p_stream_t stream);
+
+/* Message inputs of the two graph operators and F.normalize, with their backward (training mode):
+ *   edge features  out [E][C+3] = [x[src] | pos[src] - pos_c[dst]]   (PointConv, models/pointcloud/pointnet2.py:31-35);
+ *                  backward: dx [rows of x][C] += d_out[:, :C] at src (dx zeroed by the caller; float atomics)
+ *   pair features  out [E][2D] = [x[tgt] | x[src] - x[tgt]]          (DynamicEdgeConv, models/cell_retrieval.py:46-48)
+ *   rownorm backward: gradient of t2p_rownorm (F.normalize, eps 1e-12) */
+int t2p_edge_features_forward(const float* x, const float* pos, const float* pos_c, const int32_t* src, const int32_t* dst,
+                              int64_t n_edges, int32_t channels, float* out, t2p_stream_t stream);
+int t2p_edge_features_backward(const float* d_out, const int32_t* src, int64_t n_edges, int32_t channels, float* dx,
+                               t2p_stream_t stream);
+int t2p_pair_features_forward(const float* x, const int32_t* tgt, const int32_t* src, int64_t n_edges, int32_t dim, float* out,
+                              t2p_stream_t stream);
+int t2p_pair_features_backward(const float* d_out, const int32_t* tgt, const int32_t* src, int64_t n_edges, int32_t dim,
+                               float* dx, t2p_stream_t stream);
+int t2p_rownorm_backward(const float* x, const float* dy, int64_t n_rows, int32_t dim, float* dx, t2p_stream_t stream);
 
 /* PairwiseRankingLoss (training/losses.py:126-164, margin training/args.py:46) on the score matrix of the L2-normalised
  * anchor / positive embeddings, scores [B][B] = im_n s_n^T:  row_loss [B] (loss = sum(row_loss) / B),

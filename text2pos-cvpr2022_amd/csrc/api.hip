@@ -624,6 +624,36 @@ int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* y, 
                                          dbeta_seg, (double*)workspace, (hipStream_t)stream);
 }
 
+int t2p_edge_features_forward(const float* x, const float* pos, const float* pos_c, const int32_t* src, const int32_t* dst,
+                              int64_t n_edges, int32_t channels, float* out, t2p_stream_t stream) {
+    T2P_CHECK_ARG(pos && pos_c && src && dst && out && (x || channels == 0), "edge_features_forward: NULL argument");
+    T2P_CHECK_ARG(n_edges >= 0 && channels >= 0, "edge_features_forward: bad sizes");
+    return launch_edge_feat_fwd(x, pos, pos_c, src, dst, n_edges, channels, out, (hipStream_t)stream);
+}
+int t2p_edge_features_backward(const float* d_out, const int32_t* src, int64_t n_edges, int32_t channels, float* dx,
+                               t2p_stream_t stream) {
+    T2P_CHECK_ARG(d_out && src && (dx || channels == 0), "edge_features_backward: NULL argument");
+    T2P_CHECK_ARG(n_edges >= 0 && channels >= 0, "edge_features_backward: bad sizes");
+    return launch_edge_feat_bwd(d_out, src, n_edges, channels, dx, (hipStream_t)stream);
+}
+int t2p_pair_features_forward(const float* x, const int32_t* tgt, const int32_t* src, int64_t n_edges, int32_t dim, float* out,
+                              t2p_stream_t stream) {
+    T2P_CHECK_ARG(x && tgt && src && out, "pair_features_forward: NULL argument");
+    T2P_CHECK_ARG(n_edges >= 0 && dim >= 1, "pair_features_forward: bad sizes");
+    return launch_pair_feat_fwd(x, tgt, src, n_edges, dim, out, (hipStream_t)stream);
+}
+int t2p_pair_features_backward(const float* d_out, const int32_t* tgt, const int32_t* src, int64_t n_edges, int32_t dim,
+                               float* dx, t2p_stream_t stream) {
+    T2P_CHECK_ARG(d_out && tgt && src && dx, "pair_features_backward: NULL argument");
+    T2P_CHECK_ARG(n_edges >= 0 && dim >= 1, "pair_features_backward: bad sizes");
+    return launch_pair_feat_bwd(d_out, tgt, src, n_edges, dim, dx, (hipStream_t)stream);
+}
+int t2p_rownorm_backward(const float* x, const float* dy, int64_t n_rows, int32_t dim, float* dx, t2p_stream_t stream) {
+    T2P_CHECK_ARG(x && dy && dx, "rownorm_backward: NULL argument");
+    T2P_CHECK_ARG(n_rows >= 0 && dim >= 1, "rownorm_backward: bad sizes");
+    return launch_rownorm_bwd(x, dy, n_rows, dim, dx, (hipStream_t)stream);
+}
+
 int t2p_segment_max_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, float* out, int32_t* arg,
                             t2p_stream_t stream) {
     T2P_CHECK_ARG(x && seg_ptr && out && arg, "segment_max_forward: NULL argument");

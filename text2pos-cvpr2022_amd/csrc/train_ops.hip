@@ -203,7 +203,110 @@ __global__ __launch_bounds__(256) void k_segment_max_backward(const float* __res
     for (int r = seg_ptr[s] + rl; r < seg_ptr[s + 1]; r += kRowsPar) dx[(int64_t)r * C + c] = r == who ? g : 0.f;
 }
 
+// PointConv message input of every edge: out[e] = [x[src[e]] | pos[src[e]] - pos_c[dst[e]]]  (models/pointcloud/pointnet2.py:31-35:
+// cat([x_j, pos_j - pos_i])); one thread per output element
+__global__ void k_edge_feat_fwd(const float* __restrict__ x, const float* __restrict__ pos, const float* __restrict__ pos_c,
+                                const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E, int C,
+                                float* __restrict__ out) {
+    const int W = C + 3;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= E * W) return;
+    const int64_t e = i / W;
+    const int c = (int)(i % W);
+    const int s = src[e];
+    out[i] = c < C ? x[(int64_t)s * C + c] : pos[(int64_t)s * 3 + (c - C)] - pos_c[(int64_t)dst[e] * 3 + (c - C)];
+}
+// its backward with respect to x (positions are inputs): dx[src[e]] += dout[e][:C]; dx zeroed by the caller
+__global__ void k_edge_feat_bwd(const float* __restrict__ dout, const int32_t* __restrict__ src, int64_t E, int C,
+                                float* __restrict__ dx) {
+    const int W = C + 3;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= E * C) return;
+    const int64_t e = i / C;
+    const int c = (int)(i % C);
+    atomicAdd(dx + (int64_t)src[e] * C + c, dout[e * W + c]);
+}
+// DynamicEdgeConv message input: out[e] = [x[tgt[e]] | x[src[e]] - x[tgt[e]]]  (models/cell_retrieval.py:46-48)
+__global__ void k_pair_feat_fwd(const float* __restrict__ x, const int32_t* __restrict__ tgt, const int32_t* __restrict__ src,
+                                int64_t E, int D, float* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= E * 2 * D) return;
+    const int64_t e = i / (2 * D);
+    const int c = (int)(i % (2 * D));
+    const float xt = x[(int64_t)tgt[e] * D + (c % D)];
+    out[i] = c < D ? xt : x[(int64_t)src[e] * D + (c - D)] - xt;
+}
+// dx[tgt] += dA - dB, dx[src] += dB
+__global__ void k_pair_feat_bwd(const float* __restrict__ dout, const int32_t* __restrict__ tgt,
+                                const int32_t* __restrict__ src, int64_t E, int D, float* __restrict__ dx) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= E * D) return;
+    const int64_t e = i / D;
+    const int c = (int)(i % D);
+    const float da = dout[e * 2 * D + c], db = dout[e * 2 * D + D + c];
+    atomicAdd(dx + (int64_t)tgt[e] * D + c, da - db);
+    atomicAdd(dx + (int64_t)src[e] * D + c, db);
+}
+// backward of F.normalize(x, dim=-1) (eps 1e-12): dx = (dy - x_n <x_n, dy>) / max(|x|, eps); one wavefront per row
+__global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ x, const float* __restrict__ dy, int64_t n_rows,
+                                                     int dim, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const float* xr = x + r * dim;
+    const float* gr = dy + r * dim;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+        ss += xr[c] * xr[c];
+        dot += xr[c] * gr[c];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ss += __shfl_xor(ss, off, 64);
+        dot += __shfl_xor(dot, off, 64);
+    }
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = 1.f / nrm;
+    const float proj = dot * inv * inv;  // <x_n, dy> / |x|
+    for (int c = lane; c < dim; c += 64) dx[r * dim + c] = (gr[c] - xr[c] * proj) * inv;
+}
+
 }  // namespace
+
+int launch_edge_feat_fwd(const float* x, const float* pos, const float* pos_c, const int32_t* src, const int32_t* dst, int64_t E,
+                         int C, float* out, hipStream_t st) {
+    const int64_t n = E * (C + 3);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_edge_feat_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, pos, pos_c, src, dst, E, C, out);
+    T2P_CHECK_LAUNCH("edge_feat_fwd");
+    return 0;
+}
+int launch_edge_feat_bwd(const float* dout, const int32_t* src, int64_t E, int C, float* dx, hipStream_t st) {
+    const int64_t n = E * C;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_edge_feat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, src, E, C, dx);
+    T2P_CHECK_LAUNCH("edge_feat_bwd");
+    return 0;
+}
+int launch_pair_feat_fwd(const float* x, const int32_t* tgt, const int32_t* src, int64_t E, int D, float* out, hipStream_t st) {
+    const int64_t n = E * 2 * D;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_pair_feat_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, tgt, src, E, D, out);
+    T2P_CHECK_LAUNCH("pair_feat_fwd");
+    return 0;
+}
+int launch_pair_feat_bwd(const float* dout, const int32_t* tgt, const int32_t* src, int64_t E, int D, float* dx, hipStream_t st) {
+    const int64_t n = E * D;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_pair_feat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, tgt, src, E, D, dx);
+    T2P_CHECK_LAUNCH("pair_feat_bwd");
+    return 0;
+}
+int launch_rownorm_bwd(const float* x, const float* dy, int64_t n_rows, int dim, float* dx, hipStream_t st) {
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(k_rownorm_bwd, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, x, dy, n_rows, dim, dx);
+    T2P_CHECK_LAUNCH("rownorm_bwd");
+    return 0;
+}
 
 // row chunks per segment: ~4 k rows per block for balanced segments, so that one big segment still fills the chip
 static int bn_chunks(int64_t rows, int n_seg) {

@@ -8,14 +8,15 @@ Same graph as the inference kernels, but every BatchNorm1d normalises with the s
     flows through them in the reference either;
   * the arithmetic runs on the HIP building blocks of train_ops.py (Linear on the tiled GEMM, batch-statistics
     BatchNorm + ReLU per segment, segment max with arg-max routing);
-  * edge lists, gathers, concatenations, ReLU of the two plain Linear heads and F.normalize are torch tensor ops (with
-    their autograd): data movement around the kernels.
+  * the message inputs of the two graph operators and F.normalize are HIP kernels with backward kernels as well
+    (t2p_edge_features_*, t2p_pair_features_*, t2p_rownorm / t2p_rownorm_backward); what is left to torch tensor ops is
+    integer plumbing (edge lists, row pointers), the concatenation of the three object feature parts and the ReLU behind
+    the two plain Linear heads.
 The PointConv self-loop rewrite of torch_geometric (remove edges whose two CELL-local indices agree, append (i, i) for
 every centroid row i of the cell: dense row i of the cell feeds centroid row i) is reproduced on the edge lists exactly as
 the inference path encodes it in its row tables."""
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from . import train_ops as TO
@@ -94,7 +95,7 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr):
             src, dst = _sa_edges(gt["nbr"][lvl], gt["cnt"][lvl], first_obj, nd, nc, model.add_self_loops)
             cent_ptr = _ptr_from_counts(torch.bincount(dst, minlength=n_obj * nc))
             cell_edge_ptr = _ptr_from_counts(torch.bincount(cell_of_obj[dst // nc], minlength=n_cells))
-            msg = torch.cat([x[src], pos[src] - pos_c[dst]], dim=1)
+            msg = TO.edge_features(x, pos, pos_c, _i32(src), _i32(dst))
             h = _mlp_train(msg, sa.point_conv.local_nn, cell_edge_ptr)
             x, pos, nd = TO.segment_max(h, cent_ptr), pos_c, nc
         h = _mlp_train(torch.cat([x, pos], dim=1), pn.ga.mlp, _i32(cell_ptr_dev.long() * nd))
@@ -102,13 +103,13 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr):
         f1 = torch.relu(TO.linear(f0, pn.lin1))
         f2 = torch.relu(TO.linear(f1, pn.lin2))
         feats = (f0, f1, f2)[a.pointnet_features]
-        parts.append(F.normalize(_mlp_train(feats, oe.mlp_pointnet, one(n_obj)), dim=-1))
+        parts.append(TO.normalize(_mlp_train(feats, oe.mlp_pointnet, one(n_obj))))
     if "color" in a.use_features:
-        parts.append(F.normalize(_mlp_train(mean_rgb.float(), oe.color_encoder, one(n_obj)), dim=-1))
+        parts.append(TO.normalize(_mlp_train(mean_rgb.float(), oe.color_encoder, one(n_obj))))
     if "position" in a.use_features:
-        parts.append(F.normalize(_mlp_train(center.float(), oe.pos_encoder, one(n_obj)), dim=-1))
+        parts.append(TO.normalize(_mlp_train(center.float(), oe.pos_encoder, one(n_obj))))
     emb = _mlp_train(torch.cat(parts, dim=-1), oe.mlp_merge, one(n_obj)) if len(parts) > 1 else parts[0]
-    emb = F.normalize(emb, dim=-1)
+    emb = TO.normalize(emb)
 
     # DynamicEdgeConv(k = 8, max) inside each cell (models/cell_retrieval.py:46-48, :97), pool, lin, normalize (:98-106)
     k = model.graph1.k
@@ -116,8 +117,8 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr):
     valid = knn >= 0
     tgt = torch.arange(n_obj, device=dev)[:, None].expand(-1, k)[valid]
     srcn = knn[valid].long()
-    msg = torch.cat([emb[tgt], emb[srcn] - emb[tgt]], dim=-1)
+    msg = TO.pair_features(emb, _i32(tgt), _i32(srcn))
     h = _mlp_train(msg, model.graph1.nn, one(msg.shape[0]))
     xg = TO.segment_max(h, _ptr_from_counts(valid.sum(1)))
     xc = TO.segment_max(xg, cell_ptr_dev)
-    return F.normalize(_mlp_train(xc, model.lin, one(n_cells)), dim=-1)
+    return TO.normalize(_mlp_train(xc, model.lin, one(n_cells)))

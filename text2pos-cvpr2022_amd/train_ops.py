@@ -99,6 +99,77 @@ def segment_max(x, seg_ptr):
     return _SegmentMaxFn.apply(x.contiguous(), seg_ptr)
 
 
+class _EdgeFeaturesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos, pos_c, src, dst):
+        dev = pos.device
+        e, c = src.numel(), x.shape[1]
+        out = torch.empty((e, c + 3), dtype=torch.float32, device=dev)
+        L.check(L.lib().t2p_edge_features_forward(_ptr(x), _ptr(pos), _ptr(pos_c), _ptr(src), _ptr(dst), e, c, _ptr(out),
+                                                  _stream(dev)), "t2p_edge_features_forward")
+        ctx.save_for_backward(src)
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (src,) = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().t2p_edge_features_backward(_ptr(dout.contiguous()), _ptr(src), src.numel(), ctx.shape[1], _ptr(dx),
+                                                   _stream(dout.device)), "t2p_edge_features_backward")
+        return dx, None, None, None, None
+
+
+def edge_features(x, pos, pos_c, src, dst):
+    """[x[src] | pos[src] - pos_c[dst]] per edge; src / dst int32 (device); gradient to x only (positions are inputs)."""
+    return _EdgeFeaturesFn.apply(x.contiguous(), pos.contiguous(), pos_c.contiguous(), src, dst)
+
+
+class _PairFeaturesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tgt, src):
+        e, d = tgt.numel(), x.shape[1]
+        out = torch.empty((e, 2 * d), dtype=torch.float32, device=x.device)
+        L.check(L.lib().t2p_pair_features_forward(_ptr(x), _ptr(tgt), _ptr(src), e, d, _ptr(out), _stream(x.device)),
+                "t2p_pair_features_forward")
+        ctx.save_for_backward(tgt, src)
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tgt, src = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().t2p_pair_features_backward(_ptr(dout.contiguous()), _ptr(tgt), _ptr(src), tgt.numel(), ctx.shape[1],
+                                                   _ptr(dx), _stream(dout.device)), "t2p_pair_features_backward")
+        return dx, None, None
+
+
+def pair_features(x, tgt, src):
+    """[x[tgt] | x[src] - x[tgt]] per edge (DynamicEdgeConv message input); tgt / src int32 (device)."""
+    return _PairFeaturesFn.apply(x.contiguous(), tgt, src)
+
+
+class _NormalizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.rownorm(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        L.check(L.lib().t2p_rownorm_backward(_ptr(x), _ptr(dy.contiguous()), x.shape[0], x.shape[1], _ptr(dx), _stream(x.device)),
+                "t2p_rownorm_backward")
+        return dx
+
+
+def normalize(x):
+    """F.normalize(x, dim=-1) on t2p_rownorm with its backward kernel."""
+    return _NormalizeFn.apply(x.contiguous())
+
+
 class _LinearFn(torch.autograd.Function):
     """x [M, K] @ weight[N, K]^T + bias on the tiled fp32-MFMA GEMM (t2p_gemm); dX on the same GEMM (weight is its k-major
     operand), dW / db are reductions over the rows (library GEMM)."""
