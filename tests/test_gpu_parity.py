@@ -695,6 +695,38 @@ def test_coarse_training_loop_lowers_the_loss(vocab):
     assert (out.norm(dim=1) - 1).abs().max().item() < 1e-5
 
 
+def test_train_epoch_through_the_reference_signatures(vocab):
+    """training.train_epoch == training/coarse.py:31-62 fed with collate_fn-shaped batches (texts, List[List[Object3d]],
+    List[Batch]): two epochs over two batches on the HIP path; the mean loss falls and is what the packed entry points give."""
+    import weights as W
+    import text2pos_amd as t2p
+    from text2pos_amd import data as D, synthetic as S, training as T
+    model = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
+    W.fill_state_dict(model, 37)
+    model = model.to(_dev())
+
+    def batch(seed, n_cells):
+        xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(seed, n_cells)
+        objects, points = [], []
+        for c in range(n_cells):
+            lo, hi = int(cell_ptr[c]), int(cell_ptr[c + 1])
+            objects.append([D.Object3d(i, i, np.tile(center[i].astype(np.float64), (2, 1)),
+                                       np.tile(mean_rgb[i].astype(np.float64), (2, 1)), "box") for i in range(lo, hi)])
+            points.append(D.Batch(x=torch.from_numpy(rgb[lo:hi].reshape(-1, 3)), pos=torch.from_numpy(xyz[lo:hi].reshape(-1, 3)),
+                                  batch=torch.arange(hi - lo).repeat_interleave(256)))
+        return dict(texts=S.make_texts(seed, 0, n_cells, n_hints=2), objects=objects, object_points=points)
+
+    loader = [batch(51, 6), batch(52, 5)]
+    crit = T.make_criterion(S.default_args(margin=0.35, ranking_loss="pairwise"))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    first, seen = T.train_epoch(model, loader, opt, crit)
+    assert len(seen) == 2 and np.isfinite(first)
+    for _ in range(3):
+        last, _ = T.train_epoch(model, loader, opt, crit)
+    assert last < 0.9 * first, (first, last)
+    assert T.train_epoch(model, loader, opt, crit, max_batches=1)[1] == loader[:1]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # retrieval
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,35 @@
+"""Host loop of the reference's coarse training (training/coarse.py:31-62, `train_epoch`) on the HIP path: same batch
+dictionary (`texts`, `objects`, `object_points` as the reference's Kitti360CoarseDataset.collate_fn yields them), same
+order of calls; the arithmetic is DESIGN.md 4.8.  The data side (datasets, augmentation, plotting) stays with the caller."""
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+
+from .losses import PairwiseRankingLoss
+
+
+def make_criterion(args) -> torch.nn.Module:
+    """training/coarse.py:279-284 for --ranking_loss pairwise (the default, training/args.py:48)."""
+    kind = getattr(args, "ranking_loss", "pairwise")
+    if kind != "pairwise":
+        raise NotImplementedError(f"ranking_loss={kind!r}: only 'pairwise' (the reference's default) is built")
+    return PairwiseRankingLoss(margin=getattr(args, "margin", 0.35))
+
+
+def train_epoch(model, dataloader: Iterable[dict], optimizer, criterion, max_batches: Optional[int] = None):
+    """One pass over `dataloader` (training/coarse.py:31-62).  Returns (mean loss, the batches seen)."""
+    model.train()
+    epoch_losses, batches = [], []
+    for i_batch, batch in enumerate(dataloader):
+        if max_batches is not None and i_batch >= max_batches:
+            break
+        optimizer.zero_grad()
+        anchor = model.encode_text(batch["texts"])
+        positive = model.encode_objects(batch["objects"], batch["object_points"])
+        loss = criterion(anchor, positive)
+        loss.backward()
+        optimizer.step()
+        epoch_losses.append(loss.item())
+        batches.append(batch)
+    return float(np.mean(epoch_losses)) if epoch_losses else float("nan"), batches
