@@ -663,6 +663,48 @@ def test_cell_branch_training_step_matches_autograd(vocab, use_features, pointne
             assert int(b) == int(rb[name]), name
 
 
+def test_cell_branch_training_with_embedding_ablations(vocab):
+    """--class_embed / --color_embed in train() mode (models/object_encoder.py:74-84, :103-120: embedding rows instead of
+    the PointNet++ / the colour MLP): output and gradients (embedding tables included) against the oracle."""
+    import weights as W
+    import text2pos_amd as t2p
+    from oracle import model as OM
+    from text2pos_amd import synthetic as S
+    kw = dict(class_embed=True, color_embed=True)
+    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(**kw))
+    W.fill_state_dict(om, 19)
+    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(**kw))
+    hm.load_state_dict(om.state_dict(), strict=True)
+    hm = hm.to(_dev())
+    om.train()
+    hm.train()
+    for p in om.parameters():
+        p.requires_grad_(True)
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(33, 5)
+    rng = np.random.default_rng(2)
+    cls = rng.integers(0, len(vocab["classes"]) + 1, xyz.shape[0]).astype(np.int32)
+    col = rng.integers(0, 8, xyz.shape[0]).astype(np.int32)
+    coef = torch.randn(len(cell_ptr) - 1, 256, generator=torch.Generator().manual_seed(6))
+    want = om.encode_objects_packed_grad(xyz, rgb, center, mean_rgb, cell_ptr, class_idx=cls, color_idx=col)
+    (want * coef).sum().backward()
+    got = hm.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr, class_idx=_to_dev(cls)[0],
+                                   color_idx=_to_dev(col)[0])
+    (got * coef.to(_dev())).sum().backward()
+    assert (got.detach().cpu() - want.detach()).abs().max().item() < TOL
+    ref = dict(om.named_parameters())
+    g_all = max(float(q.grad.abs().max()) for q in ref.values() if q.grad is not None)
+    n = 0
+    for name, p in hm.named_parameters():
+        g_ref = ref[name].grad
+        if g_ref is None or name.endswith(".0.bias"):
+            continue
+        assert p.grad is not None, name
+        err = (p.grad.cpu() - g_ref).abs().max().item()
+        assert err < 2e-2 * max(1e-2 * g_all, g_ref.abs().max().item()), (name, err, g_ref.abs().max().item())
+        n += 1
+    assert n >= 15 and hm.object_encoder.class_embedding.weight.grad is not None
+
+
 def test_coarse_training_loop_lowers_the_loss(vocab):
     """training/coarse.py:31-62 (train_epoch) on the HIP path: model.train(); anchor = encode_text(texts); positive =
     encode_objects(...); loss = PairwiseRankingLoss(0.35)(anchor, positive); backward; Adam step - a handful of steps on

@@ -92,9 +92,9 @@ class CellRetrievalNetwork(nn.Module):
         cell_ptr int32 [B+1] on the host.  Returns [B, D] L2-normalised.  In train() mode (training/coarse.py:32) the
         batch-statistics path of train_cell.py runs instead of the folded inference kernels and the result carries a
         grad_fn."""
-        if self.training and not want_trace and class_idx is None and color_idx is None:
+        if self.training and not want_trace:
             from .train_cell import encode_objects_train
-            return encode_objects_train(self, xyz, rgb, center, mean_rgb, cell_ptr)
+            return encode_objects_train(self, xyz, rgb, center, mean_rgb, cell_ptr, class_idx, color_idx)
         self._check_forward_only()
         cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int32)
         if cell_ptr_dev is None:

@@ -61,12 +61,13 @@ def _sa_edges(nbr, cnt, first_obj, nd, nc, self_loops):
     return src, dst
 
 
-def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr):
+def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=None, color_idx=None):
     """model: CellRetrievalNetwork in train(); packed device inputs as encode_objects_packed.  Returns [B, D] unit rows with
     a grad_fn; BatchNorm running estimates are updated as the reference's per-cell / per-batch module calls would."""
     a = model.args
-    if getattr(a, "class_embed", False) or getattr(a, "color_embed", False):
-        raise NotImplementedError("training with --class_embed / --color_embed is not built")
+    class_embed, color_embed = bool(getattr(a, "class_embed", False)), bool(getattr(a, "color_embed", False))
+    if class_embed != (class_idx is not None) or color_embed != (color_idx is not None):
+        raise RuntimeError("args.class_embed / args.color_embed need the per-object class / colour indices")
     if model.variation != 0:
         raise NotImplementedError("training with variation=1 (mean aggregation) is not built")
     dev = xyz.device
@@ -81,7 +82,9 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr):
     one = lambda n: torch.tensor([0, n], dtype=torch.int32, device=dev)
 
     parts = []
-    if "class" in a.use_features:
+    if "class" in a.use_features and class_embed:               # models/object_encoder.py:103-109: no PointNet++ at all
+        parts.append(TO.normalize(oe.class_embedding(class_idx.long())))
+    elif "class" in a.use_features:
         gt = ops.sample_group(xyz.contiguous(), pn.radii)
         pos = xyz.reshape(n_obj * n_pts, 3)
         x = rgb.reshape(n_obj * n_pts, 3)
@@ -104,7 +107,9 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr):
         f2 = torch.relu(TO.linear(f1, pn.lin2))
         feats = (f0, f1, f2)[a.pointnet_features]
         parts.append(TO.normalize(_mlp_train(feats, oe.mlp_pointnet, one(n_obj))))
-    if "color" in a.use_features:
+    if "color" in a.use_features and color_embed:               # models/object_encoder.py:112-120
+        parts.append(TO.normalize(oe.color_embedding(color_idx.long())))
+    elif "color" in a.use_features:
         parts.append(TO.normalize(_mlp_train(mean_rgb.float(), oe.color_encoder, one(n_obj))))
     if "position" in a.use_features:
         parts.append(TO.normalize(_mlp_train(center.float(), oe.pos_encoder, one(n_obj))))
