@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 12
+#define T2P_ABI_VERSION 13
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -303,6 +303,11 @@ int t2p_segment_max_forward(const float* x, const int32_t* seg_ptr, int32_t n_se
                             t2p_stream_t stream);
 int t2p_segment_max_backward(const float* dout, const int32_t* arg, const int32_t* seg_ptr, int32_t n_seg, int32_t channels,
                              float* dx, t2p_stream_t stream);
+/* segment mean (variation 1: DynamicEdgeConv aggr="mean", gnn.global_mean_pool; models/cell_retrieval.py:50-54, :100-103) */
+int t2p_segment_mean_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, float* out,
+                             t2p_stream_t stream);
+int t2p_segment_mean_backward(const float* dout, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, float* dx,
+                              t2p_stream_t stream);
 
 /* Message inputs of the two graph operators and F.normalize, with their backward (training mode):
  *   edge features  out [E][C+3] = [x[src] | pos[src] - pos_c[dst]]   (PointConv, models/pointcloud/pointnet2.py:31-35);

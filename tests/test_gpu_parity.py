@@ -664,13 +664,14 @@ def test_cell_branch_training_step_matches_autograd(vocab, use_features, pointne
 
 
 def test_cell_branch_training_with_embedding_ablations(vocab):
-    """--class_embed / --color_embed in train() mode (models/object_encoder.py:74-84, :103-120: embedding rows instead of
-    the PointNet++ / the colour MLP): output and gradients (embedding tables included) against the oracle."""
+    """--class_embed / --color_embed and --variation 1 in train() mode (models/object_encoder.py:74-84, :103-120: embedding
+    rows instead of the PointNet++ / the colour MLP; models/cell_retrieval.py:50-54, :100-103: mean aggregation, mean
+    pool): output and gradients (embedding tables included) against the oracle."""
     import weights as W
     import text2pos_amd as t2p
     from oracle import model as OM
     from text2pos_amd import synthetic as S
-    kw = dict(class_embed=True, color_embed=True)
+    kw = dict(class_embed=True, color_embed=True, variation=1)      # + mean aggregation / mean pool (variation 1)
     om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(**kw))
     W.fill_state_dict(om, 19)
     hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(**kw))

@@ -654,6 +654,19 @@ int t2p_rownorm_backward(const float* x, const float* dy, int64_t n_rows, int32_
     return launch_rownorm_bwd(x, dy, n_rows, dim, dx, (hipStream_t)stream);
 }
 
+int t2p_segment_mean_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, float* out,
+                             t2p_stream_t stream) {
+    T2P_CHECK_ARG(x && seg_ptr && out, "segment_mean_forward: NULL argument");
+    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1, "segment_mean_forward: bad sizes");
+    return launch_segment_mean(x, seg_ptr, n_seg, channels, out, (hipStream_t)stream);
+}
+int t2p_segment_mean_backward(const float* dout, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, float* dx,
+                              t2p_stream_t stream) {
+    T2P_CHECK_ARG(dout && seg_ptr && dx, "segment_mean_backward: NULL argument");
+    T2P_CHECK_ARG(n_seg >= 0 && channels >= 1, "segment_mean_backward: bad sizes");
+    return launch_segment_mean_backward(dout, seg_ptr, n_seg, channels, dx, (hipStream_t)stream);
+}
+
 int t2p_segment_max_forward(const float* x, const int32_t* seg_ptr, int32_t n_seg, int32_t channels, float* out, int32_t* arg,
                             t2p_stream_t stream) {
     T2P_CHECK_ARG(x && seg_ptr && out && arg, "segment_max_forward: NULL argument");

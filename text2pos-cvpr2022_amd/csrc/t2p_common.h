@@ -193,6 +193,8 @@ int launch_edge_feat_fwd(const float* x, const float* pos, const float* pos_c, c
 int launch_edge_feat_bwd(const float* dout, const int32_t* src, int64_t E, int C, float* dx, hipStream_t st);
 int launch_pair_feat_fwd(const float* x, const int32_t* tgt, const int32_t* src, int64_t E, int D, float* out, hipStream_t st);
 int launch_pair_feat_bwd(const float* dout, const int32_t* tgt, const int32_t* src, int64_t E, int D, float* dx, hipStream_t st);
+int launch_segment_mean(const float* x, const int32_t* seg_ptr, int n_seg, int C, float* out, hipStream_t st);
+int launch_segment_mean_backward(const float* dout, const int32_t* seg_ptr, int n_seg, int C, float* dx, hipStream_t st);
 int launch_rownorm_bwd(const float* x, const float* dy, int64_t n_rows, int dim, float* dx, hipStream_t st);
 int launch_segment_max(const float* x, const int32_t* seg_ptr, int n_seg, int C, float* out, int32_t* arg, hipStream_t st);
 int launch_segment_max_backward(const float* dout, const int32_t* arg, const int32_t* seg_ptr, int n_seg, int C, float* dx,

@@ -203,6 +203,31 @@ __global__ __launch_bounds__(256) void k_segment_max_backward(const float* __res
     for (int r = seg_ptr[s] + rl; r < seg_ptr[s + 1]; r += kRowsPar) dx[(int64_t)r * C + c] = r == who ? g : 0.f;
 }
 
+// out[s][c] = mean over the rows of segment s (0 for an empty one); fixed order (4 row lanes, then combined)
+__global__ __launch_bounds__(256) void k_segment_mean(const float* __restrict__ x, const int32_t* __restrict__ seg_ptr, int C,
+                                                      float* __restrict__ out) {
+    __shared__ double red[kRowsPar][kCols];
+    const int s = blockIdx.x, cl = threadIdx.x % kCols, rl = threadIdx.x / kCols;
+    const int c = blockIdx.y * kCols + cl;
+    const int r0 = seg_ptr[s], r1 = seg_ptr[s + 1];
+    const bool ok = c < C;
+    double acc = 0.0;
+    for (int r = r0 + rl; r < r1; r += kRowsPar) acc += ok ? (double)x[(int64_t)r * C + c] : 0.0;
+    const double t = combine4(red, rl, cl, acc);
+    if (ok && rl == 0) out[(int64_t)s * C + c] = r1 > r0 ? (float)(t / (double)(r1 - r0)) : 0.f;
+}
+// dx[r][c] = dout[s][c] / n_s for the rows of segment s
+__global__ __launch_bounds__(256) void k_segment_mean_backward(const float* __restrict__ dout,
+                                                               const int32_t* __restrict__ seg_ptr, int C,
+                                                               float* __restrict__ dx) {
+    const int s = blockIdx.x, cl = threadIdx.x % kCols, rl = threadIdx.x / kCols;
+    const int c = blockIdx.y * kCols + cl;
+    if (c >= C) return;
+    const int r0 = seg_ptr[s], r1 = seg_ptr[s + 1];
+    const float g = r1 > r0 ? dout[(int64_t)s * C + c] / (float)(r1 - r0) : 0.f;
+    for (int r = r0 + rl; r < r1; r += kRowsPar) dx[(int64_t)r * C + c] = g;
+}
+
 // PointConv message input of every edge: out[e] = [x[src[e]] | pos[src[e]] - pos_c[dst[e]]]  (models/pointcloud/pointnet2.py:31-35:
 // cat([x_j, pos_j - pos_i])); one thread per output element
 __global__ void k_edge_feat_fwd(const float* __restrict__ x, const float* __restrict__ pos, const float* __restrict__ pos_c,
@@ -299,6 +324,20 @@ int launch_pair_feat_bwd(const float* dout, const int32_t* tgt, const int32_t* s
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_pair_feat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, tgt, src, E, D, dx);
     T2P_CHECK_LAUNCH("pair_feat_bwd");
+    return 0;
+}
+int launch_segment_mean(const float* x, const int32_t* seg_ptr, int n_seg, int C, float* out, hipStream_t st) {
+    if (n_seg == 0) return 0;
+    hipLaunchKernelGGL(k_segment_mean, dim3((unsigned)n_seg, (unsigned)((C + kCols - 1) / kCols)), dim3(256), 0, st, x, seg_ptr,
+                       C, out);
+    T2P_CHECK_LAUNCH("segment_mean");
+    return 0;
+}
+int launch_segment_mean_backward(const float* dout, const int32_t* seg_ptr, int n_seg, int C, float* dx, hipStream_t st) {
+    if (n_seg == 0) return 0;
+    hipLaunchKernelGGL(k_segment_mean_backward, dim3((unsigned)n_seg, (unsigned)((C + kCols - 1) / kCols)), dim3(256), 0, st,
+                       dout, seg_ptr, C, dx);
+    T2P_CHECK_LAUNCH("segment_mean_backward");
     return 0;
 }
 int launch_rownorm_bwd(const float* x, const float* dy, int64_t n_rows, int dim, float* dx, hipStream_t st) {

@@ -68,8 +68,6 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
     class_embed, color_embed = bool(getattr(a, "class_embed", False)), bool(getattr(a, "color_embed", False))
     if class_embed != (class_idx is not None) or color_embed != (color_idx is not None):
         raise RuntimeError("args.class_embed / args.color_embed need the per-object class / colour indices")
-    if model.variation != 0:
-        raise NotImplementedError("training with variation=1 (mean aggregation) is not built")
     dev = xyz.device
     oe, pn = model.object_encoder, model.object_encoder.pointnet
     n_obj, n_pts = xyz.shape[0], xyz.shape[1]
@@ -124,6 +122,7 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
     srcn = knn[valid].long()
     msg = TO.pair_features(emb, _i32(tgt), _i32(srcn))
     h = _mlp_train(msg, model.graph1.nn, one(msg.shape[0]))
-    xg = TO.segment_max(h, _ptr_from_counts(valid.sum(1)))
-    xc = TO.segment_max(xg, cell_ptr_dev)
+    pool = TO.segment_max if model.variation == 0 else TO.segment_mean    # models/cell_retrieval.py:46-54, :98-103
+    xg = pool(h, _ptr_from_counts(valid.sum(1)))
+    xc = pool(xg, cell_ptr_dev)
     return TO.normalize(_mlp_train(xc, model.lin, one(n_cells)))

@@ -99,6 +99,32 @@ def segment_max(x, seg_ptr):
     return _SegmentMaxFn.apply(x.contiguous(), seg_ptr)
 
 
+class _SegmentMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg_ptr):
+        n_seg, c = seg_ptr.numel() - 1, x.shape[1]
+        out = torch.empty((n_seg, c), dtype=torch.float32, device=x.device)
+        L.check(L.lib().t2p_segment_mean_forward(_ptr(x), _ptr(seg_ptr), n_seg, c, _ptr(out), _stream(x.device)),
+                "t2p_segment_mean_forward")
+        ctx.save_for_backward(seg_ptr)
+        ctx.rows = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (seg_ptr,) = ctx.saved_tensors
+        n_seg, c = dout.shape
+        dx = torch.zeros((ctx.rows, c), dtype=torch.float32, device=dout.device)
+        L.check(L.lib().t2p_segment_mean_backward(_ptr(dout.contiguous()), _ptr(seg_ptr), n_seg, c, _ptr(dx),
+                                                  _stream(dout.device)), "t2p_segment_mean_backward")
+        return dx, None
+
+
+def segment_mean(x, seg_ptr):
+    """Row-segment mean [S, C] of x [M, C] (variation 1: aggr="mean" / global_mean_pool)."""
+    return _SegmentMeanFn.apply(x.contiguous(), seg_ptr)
+
+
 class _EdgeFeaturesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, pos_c, src, dst):
