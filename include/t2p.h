@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 13
+#define T2P_ABI_VERSION 14
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -329,6 +329,12 @@ int t2p_rownorm_backward(const float* x, const float* dy, int64_t n_rows, int32_
  * d_scores [B][B] = dLoss / dScores, row_count [B] scratch.  Deterministic (fixed-order reductions). */
 int t2p_pairwise_ranking(const float* scores, int32_t batch, float margin, float* row_loss, float* d_scores, float* row_count,
                          t2p_stream_t stream);
+
+/* HardestRankingLoss (training/losses.py:167-201, --ranking_loss hardest) on the same score matrix: best [2B] = the largest
+ * hinge of every row (first B) and column (last B), where [2B] = its position (-1 if none is positive),
+ * d_scores [B][B] = dLoss / dScores; loss = (sum best[:B] + sum best[B:]) / B. */
+int t2p_hardest_ranking(const float* scores, int32_t batch, float margin, float* best, int32_t* where, float* d_scores,
+                        t2p_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Stage-level exports (used by the stage-wise parity tests).

@@ -504,6 +504,37 @@ def test_pairwise_ranking_loss_matches_reference_formula(b):
     assert again.item() == got.item()                                   # fixed-order reductions
 
 
+@pytest.mark.parametrize("b", [2, 9, 64, 257])
+def test_hardest_ranking_loss_matches_reference_formula(b):
+    """HardestRankingLoss (training/losses.py:174-201, restated with autograd in fp64): value and both input gradients."""
+    import text2pos_amd as t2p
+    g = torch.Generator().manual_seed(100 + b)
+    im = torch.randn(b, 256, generator=g)
+    s = 0.7 * im + 0.6 * torch.randn(b, 256, generator=g)
+    margin = 0.35
+
+    def reference(images, captions):
+        images = images / torch.norm(images, dim=1, keepdim=True)
+        captions = captions / torch.norm(captions, dim=1, keepdim=True)
+        n = len(images)
+        sim = torch.mm(images, captions.transpose(1, 0))
+        eye = torch.eye(n, dtype=torch.bool)
+        ci = torch.relu((margin + sim - sim.diag().view(n, 1)).masked_fill(eye, 0)).max(dim=1).values.mean()
+        cc = torch.relu((margin + sim.transpose(1, 0) - sim.diag().view(n, 1)).masked_fill(eye, 0)).max(dim=1).values.mean()
+        return ci + cc
+
+    a, c = im.double().requires_grad_(True), s.double().requires_grad_(True)
+    want = reference(a, c)
+    want.backward()
+    x, y = im.to(_dev()).requires_grad_(True), s.to(_dev()).requires_grad_(True)
+    got = t2p.HardestRankingLoss(margin)(x, y)
+    got.backward()
+    assert abs(got.item() - want.item()) < 1e-5 * max(1.0, abs(want.item()))
+    scale = max(1e-6, a.grad.abs().max().item())
+    assert (x.grad.cpu().double() - a.grad).abs().max().item() < 1e-4 * scale
+    assert (y.grad.cpu().double() - c.grad).abs().max().item() < 1e-4 * scale
+
+
 def test_text_branch_learns_against_fixed_cell_embeddings(hip_model, vocab):
     """A few Adam steps of the text branch alone on the HIP path (encode_text with gradients + PairwiseRankingLoss)
     against frozen cell embeddings lower the loss: the pieces of training/coarse.py:31-62 that exist so far work together."""

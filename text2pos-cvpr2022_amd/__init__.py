@@ -7,7 +7,7 @@ modules.py, data.py, superglue_matcher.py for the fine stage), retrieval.py (top
 The directory name contains '-', so import it through the `text2pos_amd` alias module at the repository root.
 """
 from .cell_retrieval import CellRetrievalNetwork  # noqa: F401
-from .losses import PairwiseRankingLoss  # noqa: F401
+from .losses import HardestRankingLoss, PairwiseRankingLoss  # noqa: F401
 from .modules import LanguageEncoder, get_mlp  # noqa: F401
 from .object_encoder import ObjectEncoder  # noqa: F401
 from .pointnet2 import PointNet2  # noqa: F401

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -88,6 +88,7 @@ SYMBOLS = {
     "t2p_segment_mean_backward": (C.c_int, [c_void, c_void, C.c_int32, C.c_int32, c_void, c_void]),
     "t2p_segment_max_forward": (C.c_int, [c_void, c_void, C.c_int32, C.c_int32, c_void, c_void, c_void]),
     "t2p_segment_max_backward": (C.c_int, [c_void, c_void, c_void, C.c_int32, C.c_int32, c_void, c_void]),
+    "t2p_hardest_ranking": (C.c_int, [c_void, C.c_int32, C.c_float, c_void, c_void, c_void, c_void]),
     "t2p_pairwise_ranking": (C.c_int, [c_void, C.c_int32, C.c_float, c_void, c_void, c_void, c_void]),
     "t2p_pack_objects": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, c_void, c_void, c_void, c_void,
                                    c_void]),

@@ -681,6 +681,13 @@ int t2p_segment_max_backward(const float* dout, const int32_t* arg, const int32_
     return launch_segment_max_backward(dout, arg, seg_ptr, n_seg, channels, dx, (hipStream_t)stream);
 }
 
+int t2p_hardest_ranking(const float* scores, int32_t batch, float margin, float* best, int32_t* where, float* d_scores,
+                        t2p_stream_t stream) {
+    T2P_CHECK_ARG(scores && best && where && d_scores, "hardest_ranking: NULL argument");
+    T2P_CHECK_ARG(batch >= 0 && batch <= 32768, "hardest_ranking: batch=%d outside [0, 32768]", batch);
+    return launch_hardest_ranking(scores, batch, margin, best, where, d_scores, (hipStream_t)stream);
+}
+
 size_t t2p_sim_topk_workspace_bytes(int64_t nq, int64_t nc, int32_t k) { return sim_topk_workspace_bytes(nq, nc, k); }
 
 int t2p_sim_topk(const float* queries, const float* cells, int64_t nq, int64_t nc, int32_t dim, int32_t k,

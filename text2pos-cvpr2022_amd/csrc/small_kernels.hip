@@ -311,6 +311,57 @@ __global__ __launch_bounds__(256) void k_rank_diag(const float* __restrict__ S, 
     if (tid == 0) dS[(int64_t)j * B + j] = -(red[0] + row_cnt[j]) / (float)B;
 }
 
+// HardestRankingLoss (training/losses.py:167-201): per row i the largest hinge margin + S[i][j] - S[i][i] over j != i, per
+// column j the largest margin + S[i][j] - S[j][j] over i != j; loss = mean of the row maxima + mean of the column maxima.
+// Block b < B: row b; block b >= B: column b - B.  Writes the maximum (>= 0) and its position (-1: nothing above 0; first
+// position on ties, torch.max's choice on the CPU path the reference was written against).
+__global__ __launch_bounds__(256) void k_hardest_scan(const float* __restrict__ S, int B, float margin, float* __restrict__ best,
+                                                      int32_t* __restrict__ where) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool is_row = b < B;
+    const int a = is_row ? b : b - B;
+    const float d = S[(int64_t)a * B + a];
+    float v = 0.f;
+    int w = -1;
+    for (int k = tid; k < B; k += 256) {
+        if (k == a) continue;
+        const float h = margin + (is_row ? S[(int64_t)a * B + k] : S[(int64_t)k * B + a]) - d;
+        if (h > v) { v = h; w = k; }
+    }
+    bv[tid] = v;
+    bi[tid] = w;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float ov = bv[tid + s];
+            const int ow = bi[tid + s];
+            if (ow >= 0 && (ov > bv[tid] || (ov == bv[tid] && (bi[tid] < 0 || ow < bi[tid])))) {
+                bv[tid] = ov;
+                bi[tid] = ow;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        best[b] = bv[0];
+        where[b] = bi[0];
+    }
+}
+// dLoss/dS from the winners: +1/B at the winning entry, -1/B on the diagonal of its row (row maxima) / column (column maxima)
+__global__ void k_hardest_grad(const int32_t* __restrict__ where, int B, float* __restrict__ dS) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= 2 * B) return;
+    const int w = where[b];
+    if (w < 0) return;
+    const bool is_row = b < B;
+    const int a = is_row ? b : b - B;
+    const float g = 1.f / (float)B;
+    atomicAdd(dS + (is_row ? (int64_t)a * B + w : (int64_t)w * B + a), g);
+    atomicAdd(dS + (int64_t)a * B + a, -g);
+}
+
 __global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, int32_t o_lo,
                              int32_t* __restrict__ seg_ptr_local, int32_t* __restrict__ first) {
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= n_cells; c += gridDim.x * blockDim.x) {
@@ -383,6 +434,21 @@ int launch_pairwise_ranking(const float* scores, int batch, float margin, float*
     T2P_CHECK_LAUNCH("rank_rows");
     hipLaunchKernelGGL(k_rank_diag, dim3((unsigned)batch), dim3(256), 0, st, scores, batch, margin, row_cnt, d_scores);
     T2P_CHECK_LAUNCH("rank_diag");
+    return 0;
+}
+
+int launch_hardest_ranking(const float* scores, int batch, float margin, float* best, int32_t* where, float* d_scores,
+                           hipStream_t st) {
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(k_hardest_scan, dim3((unsigned)(2 * batch)), dim3(256), 0, st, scores, batch, margin, best, where);
+    T2P_CHECK_LAUNCH("hardest_scan");
+    hipError_t e = hipMemsetAsync(d_scores, 0, sizeof(float) * (size_t)batch * batch, st);
+    if (e != hipSuccess) {
+        set_error("hardest_ranking: memset failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    hipLaunchKernelGGL(k_hardest_grad, dim3((unsigned)((2 * batch + 255) / 256)), dim3(256), 0, st, where, batch, d_scores);
+    T2P_CHECK_LAUNCH("hardest_grad");
     return 0;
 }
 

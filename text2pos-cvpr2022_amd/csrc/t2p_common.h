@@ -100,6 +100,8 @@ int launch_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_
                         hipStream_t st);
 int launch_pairwise_ranking(const float* scores, int batch, float margin, float* row_loss, float* d_scores, float* row_cnt,
                             hipStream_t st);
+int launch_hardest_ranking(const float* scores, int batch, float margin, float* best, int32_t* where, float* d_scores,
+                           hipStream_t st);
 int launch_cell_index(const int32_t* cell_ptr, int n_cells, int32_t o_lo, int32_t* seg_ptr_local, int32_t* first,
                       hipStream_t st);
 

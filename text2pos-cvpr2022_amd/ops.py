@@ -380,6 +380,21 @@ def pairwise_ranking(scores: torch.Tensor, margin: float):
     return row_loss, d_scores
 
 
+def hardest_ranking(scores: torch.Tensor, margin: float):
+    """scores [B, B] fp32 -> (best [2B], d_scores [B, B]) of HardestRankingLoss (t2p_hardest_ranking)."""
+    _need(scores, "scores", torch.float32, 2)
+    b = scores.shape[0]
+    if scores.shape[1] != b:
+        raise RuntimeError("hardest_ranking: scores must be square")
+    dev = scores.device
+    best = torch.empty((2 * b,), dtype=torch.float32, device=dev)
+    where = torch.empty((2 * b,), dtype=torch.int32, device=dev)
+    d_scores = torch.empty_like(scores)
+    L.check(L.lib().t2p_hardest_ranking(_ptr(scores), b, float(margin), _ptr(best), _ptr(where), _ptr(d_scores), _stream(dev)),
+            "t2p_hardest_ranking")
+    return best, d_scores
+
+
 def lstm_cell_forward(pre, table, tokens, lengths, step: int, reverse: bool, c_prev, h_prev, gates, c, h):
     """One training-mode LSTM step (t2p_lstm_cell_forward): pre [B,4D] = h_prev @ W_hh^T, table [V,4D]; writes gates
     [B,4D] (i, f, g, o), c, h [B,D] in place."""

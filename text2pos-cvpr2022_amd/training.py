@@ -6,15 +6,19 @@ from typing import Iterable, Optional
 import numpy as np
 import torch
 
-from .losses import PairwiseRankingLoss
+from .losses import HardestRankingLoss, PairwiseRankingLoss
 
 
 def make_criterion(args) -> torch.nn.Module:
-    """training/coarse.py:279-284 for --ranking_loss pairwise (the default, training/args.py:48)."""
+    """training/coarse.py:279-284: --ranking_loss pairwise (the default, training/args.py:48) or hardest; triplet needs the
+    dataset's negative cells and is not built."""
     kind = getattr(args, "ranking_loss", "pairwise")
-    if kind != "pairwise":
-        raise NotImplementedError(f"ranking_loss={kind!r}: only 'pairwise' (the reference's default) is built")
-    return PairwiseRankingLoss(margin=getattr(args, "margin", 0.35))
+    margin = getattr(args, "margin", 0.35)
+    if kind == "pairwise":
+        return PairwiseRankingLoss(margin=margin)
+    if kind == "hardest":
+        return HardestRankingLoss(margin=margin)
+    raise NotImplementedError(f"ranking_loss={kind!r}: 'pairwise' and 'hardest' are built")
 
 
 def train_epoch(model, dataloader: Iterable[dict], optimizer, criterion, max_batches: Optional[int] = None):
