@@ -64,9 +64,29 @@ def generate_cells(S, seed, n_cells_total, cell_lo, cell_hi, workers, fixed_n=0)
     return xyz, rgb, center, mean_rgb, (ptr[cell_lo: cell_hi + 1] - o_lo).astype(np.int32)
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median_time(fn, reps=3):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
+
+
 def cpu_baseline(S, seed, n_cells_sample, n_query_sample):
     """The oracle timed on the host: one PointNet++ forward per cell, eager fp32, BN un-folded, then the NumPy float64
-    matvec + full argsort per query of training/coarse.py:134-140.  Extrapolated linearly to the per-GPU workload."""
+    matvec + full argsort per query of training/coarse.py:134-140.  Median of 3 runs per leg; extrapolated
+    linearly to the per-GPU workload."""
     import torch
     from oracle import model as OM
     # intra-op threads: the per-cell eager graph is made of tiny ops and stops scaling past ~16 threads (measured on
@@ -80,39 +100,64 @@ def cpu_baseline(S, seed, n_cells_sample, n_query_sample):
     texts = S.make_texts(seed, 0, n_query_sample)
     om.encode_objects_packed(xyz[: cell_ptr[1]], rgb[: cell_ptr[1]], center[: cell_ptr[1]], mean_rgb[: cell_ptr[1]],
                              cell_ptr[:2])  # warm-up: 1 cell
-    t0 = time.perf_counter()
-    for lo in range(0, n_cells_sample, 64):  # batch_size 64 cells per call, as eval_epoch does
-        hi = min(lo + 64, n_cells_sample)
-        a, b = cell_ptr[lo], cell_ptr[hi]
-        om.encode_objects_packed(xyz[a:b], rgb[a:b], center[a:b], mean_rgb[a:b], cell_ptr[lo: hi + 1] - a)
-    t_cell = (time.perf_counter() - t0) / n_cells_sample
+
+    def cells_leg():
+        for lo in range(0, n_cells_sample, 64):  # batch_size 64 cells per call, as eval_epoch does
+            hi = min(lo + 64, n_cells_sample)
+            a, b = cell_ptr[lo], cell_ptr[hi]
+            om.encode_objects_packed(xyz[a:b], rgb[a:b], center[a:b], mean_rgb[a:b], cell_ptr[lo: hi + 1] - a)
+    t_cells, runs_cells = _median_time(cells_leg)
+    t_cell = t_cells / n_cells_sample
     om.encode_text(texts[:8])
-    t0 = time.perf_counter()
-    for lo in range(0, n_query_sample, 64):
-        om.encode_text(texts[lo: lo + 64])
-    t_query = (time.perf_counter() - t0) / n_query_sample
+
+    def text_leg():
+        for lo in range(0, n_query_sample, 64):
+            om.encode_text(texts[lo: lo + 64])
+    t_text, _ = _median_time(text_leg)
+    t_query = t_text / n_query_sample
+    # retrieval leg: the reference's NumPy statements (one [12000 x 256] @ [256] float64 product + argsort per query).
+    # The BLAS pool is pinned: on a 2-socket host an un-pinned OpenBLAS / MKL pool (256 threads for a 25 MB matvec) is
+    # ~10x slower than 8-16 threads.  Best of the candidate pool sizes, each the median of 3.
     rng = np.random.default_rng(0)
     c = rng.standard_normal((CELLS_PER_GPU, 256)).astype(np.float32)
     q = rng.standard_normal((QUERIES_PER_GPU, 256)).astype(np.float32)
-    t0 = time.perf_counter()
-    OM.retrieve_topk_f64(c, q, TOPK)
-    t_retr = time.perf_counter() - t0
+    best = None
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    for nthr in ([1, 8, 16] if threadpool_limits else [0]):
+        def retr_leg():
+            OM.retrieve_topk_f64(c, q, TOPK)
+        if threadpool_limits:
+            with threadpool_limits(limits=nthr, user_api="blas"):
+                t, _ = _median_time(retr_leg)
+        else:
+            t, _ = _median_time(retr_leg)
+        if best is None or t < best[0]:
+            best = (t, nthr)
+    t_retr, blas_threads = best
     total = CELLS_PER_GPU * t_cell + QUERIES_PER_GPU * t_query + t_retr
     # the same cell encoder on ONE thread (SURVEY 8(d) asks for both), on a 16-cell slice
     torch.set_num_threads(1)
     n1 = min(16, n_cells_sample)
-    t0 = time.perf_counter()
     a, b = cell_ptr[0], cell_ptr[n1]
-    om.encode_objects_packed(xyz[a:b], rgb[a:b], center[a:b], mean_rgb[a:b], cell_ptr[: n1 + 1] - a)
-    t_cell_1 = (time.perf_counter() - t0) / n1
+    t1, _ = _median_time(lambda: om.encode_objects_packed(xyz[a:b], rgb[a:b], center[a:b], mean_rgb[a:b],
+                                                          cell_ptr[: n1 + 1] - a))
+    t_cell_1 = t1 / n1
     torch.set_num_threads(cores)
     return {
         "value": (CELLS_PER_GPU + QUERIES_PER_GPU) / total, "unit": "cells+queries/s", "cores": cores, "kind": "port",
         "sample": (f"{n_cells_sample} cells + {n_query_sample} queries encoded by the CPU oracle (torch "
                    f"{cores} threads, one PointNet++ forward per cell), full {QUERIES_PER_GPU}x{CELLS_PER_GPU} float64 "
-                   "NumPy retrieval; extrapolated linearly to 12000 cells + 1000 queries"),
+                   f"NumPy retrieval (BLAS pool {blas_threads or 'default'} threads); median of 3 runs per leg; "
+                   "extrapolated linearly to 12000 cells + 1000 queries"),
+        "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "torch_threads": cores,
+        "blas_threads_retrieval": blas_threads, "runs": 3,
         "cells_per_s": 1.0 / t_cell, "queries_per_s": 1.0 / t_query, "retrieval_qps": QUERIES_PER_GPU / t_retr,
-        "cells_per_s_single_thread": 1.0 / t_cell_1,
+        "cells_per_s_single_thread": 1.0 / t_cell_1, "cell_leg_runs_s": [round(x, 3) for x in runs_cells],
+        "retrieval_sort": ("np.argsort(kind='stable') (ties -> lower cell index, the order this repo pins); the reference "
+                           "calls np.argsort with the default kind (training/coarse.py:136-140), whose tie order is unspecified"),
     }
 
 
@@ -128,6 +173,11 @@ def main():
     ap.add_argument("--chunk-objects", type=int, default=0)
     ap.add_argument("--cell-variant", choices=["ragged", "fixed16", "single"], default="ragged",
                     help="objects per cell: n~U{6..26} (default, the headline workload), 16, or 1 (SURVEY 8(d) variants)")
+    ap.add_argument("--bn", choices=["calibrated", "random"], default="calibrated",
+                    help="BatchNorm running statistics of the random-init model: calibrated on 64 cells of the workload "
+                         "(default) or drawn at random (SURVEY 8(d); embeddings then collapse onto one direction)")
+    ap.add_argument("--no-fp32-pass", action="store_true", help="skip the extra exact-fp32 pass behind the timed region")
+    ap.add_argument("--fp32-steps", type=int, default=2)
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="arithmetic of the MFMA-heavy layers: f16x3 split-precision (default) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -175,6 +225,25 @@ def main():
     # ---- inputs -> HBM (outside the timed region) ---------------------------------------------------------------------
     d_xyz, d_rgb, d_center, d_mean = (torch.from_numpy(a).to(dev) for a in (xyz, rgb, center, mean_rgb))
     d_ptr = torch.from_numpy(cell_ptr).to(dev)
+    if args.bn == "calibrated":
+        # With random weights AND random BatchNorm statistics every cell embedding collapses onto one direction (pairwise
+        # cosine > 0.99999), which would make the f16x3-vs-fp32 comparison below vacuous.  Like a trained checkpoint, the
+        # model gets running statistics that match its data: one train-mode pass (HIP training path, cumulative
+        # averaging) over this rank's first 64 cells, identical on every rank of a weak-scaling run.
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+        for m in bns:
+            m.reset_running_stats()
+            m.momentum = None
+        model.train()
+        n64 = min(64, len(cell_ptr) - 1)
+        o64 = int(cell_ptr[n64])
+        g_xyz, g_rgb, g_center, g_mean, g_ptr = generate_cells(S, SEED, n_cells_total, 0, n64, 1, fixed_n)
+        with torch.no_grad():
+            model.encode_objects_packed(*(torch.from_numpy(a).to(dev) for a in (g_xyz, g_rgb, g_center, g_mean)), g_ptr)
+        model.eval()
+        for m in bns:
+            m.momentum = 0.1
+        del o64
     from text2pos_amd.modules import tokenize
     tok, lens = tokenize(S.make_texts(SEED, q_lo, q_hi), model.language_encoder.known_words)
     d_tok, d_len = torch.from_numpy(tok).to(dev), torch.from_numpy(lens).to(dev)
@@ -184,16 +253,23 @@ def main():
     side = torch.cuda.Stream(device=dev)   # the text branch is independent of the cell branch: its (latency-bound)
                                            # biLSTM runs on a second HIP stream underneath the cell kernels
 
+    gather_events = []   # (start, end) torch events around the one exchange step, on the stream it runs on
+
     def step():
         with torch.no_grad():
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 queries = model.language_encoder.encode_tokens(d_tok, d_len, normalize=True)
+            # the fp16-range guard accumulates in a device word during the step; it is read once after the timed region
             cells = model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
-                                                chunk_objects=args.chunk_objects)
+                                                chunk_objects=args.chunk_objects, check_overflow=False)
             if world > 1:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(main)
                 cells = TD.all_gather_rows(cells, n_cells_total)       # the one exchange step (RCCL over xGMI)
+                ev[1].record(main)
+                gather_events.append(ev)
             main.wait_stream(side)
             queries.record_stream(main)
             return ops.sim_topk(queries, cells, TOPK)
@@ -209,6 +285,7 @@ def main():
         step()
     barrier()
     log("timed region")
+    gather_events.clear()
     ops.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -218,10 +295,82 @@ def main():
     ops.profile_enable(False)
     prof = ops.profile_report()
     log(f"{args.steps} steps in {elapsed:.3f}s")
+    guard_code = model.overflow_detected() if args.precision == "f16x3" else 0
+    if guard_code:
+        raise SystemExit(f"fp16-range guard fired during the timed region (code {guard_code:#x}): the f16x3 numbers are invalid")
+    exchange = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # self-check of the first multi-GPU runs: per-rank time of the all-gather and what RCCL reports about itself
+        mine = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else 0.0
+        per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+        per_rank[rank] = mine
+        dist.all_reduce(per_rank)
+        exchange = {"collective": "all_gather_into_tensor (RCCL)", "backend": dist.get_backend(),
+                    "world_size": dist.get_world_size(), "bytes_per_rank": int((c_hi - c_lo) * 256 * 4),
+                    "bytes_gathered": int(n_cells_total * 256 * 4),
+                    "all_gather_ms_per_rank": [round(float(v), 4) for v in per_rank.tolist()],
+                    "note": "mean over the timed steps of the event-bracketed collective on each rank (includes waiting "
+                            "for the slowest rank's encoder)"}
+
+    # ---- one pass of the same step on the exact fp32 MFMA path (outside the headline timing), and the precision evidence
+    fp32_info = None
+    if args.precision == "f16x3" and not args.no_fp32_pass:
+        light = ("obj_emb", "knn_idx")
+        with torch.no_grad():
+            x3_cells, x3_tr = model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
+                                                          chunk_objects=args.chunk_objects, want_trace=light)
+            model.precision = "fp32"
+            try:
+                step()                                           # warm-up (packs nothing new: the fp32 weights are shared)
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.fp32_steps):
+                    step()
+                barrier()
+                fp32_elapsed = time.perf_counter() - t1
+                f32_cells, f32_tr = model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
+                                                                chunk_objects=args.chunk_objects, want_trace=light)
+            finally:
+                model.precision = "f16x3"
+            # The path is continuous up to the object embeddings; DynamicEdgeConv's kNN graph is a discrete step: where an
+            # object's 8th / 9th neighbour distances nearly tie, two evaluations pick different neighbours and that cell's
+            # embedding moves by O(1e-2) (in the reference as much as here).  Report the continuous part over all objects,
+            # the cells hit by such a flip, and the cell embeddings over all other cells.
+            d_obj = float((x3_tr["obj_emb"] - f32_tr["obj_emb"]).abs().max().item())
+            flip_obj = (x3_tr["knn_idx"] != f32_tr["knn_idx"]).any(dim=1)
+            cell_of = torch.repeat_interleave(torch.arange(c_hi - c_lo, device=dev), (d_ptr[1:] - d_ptr[:-1]).long())
+            flip_cell = torch.zeros(c_hi - c_lo, dtype=torch.bool, device=dev)
+            flip_cell[cell_of[flip_obj]] = True
+            per_cell = (x3_cells - f32_cells).abs().max(dim=1).values
+            delta = float(per_cell[~flip_cell].max().item())
+            delta_all = float(per_cell.max().item())
+            n_flip = int(flip_cell.sum().item())
+            samp = x3_cells[:512]
+            cosm = (samp @ samp.T)[torch.triu(torch.ones(samp.shape[0], samp.shape[0], dtype=torch.bool, device=dev), 1)]
+            cos_mean = float(cosm.mean().item())
+        if world > 1:
+            t = torch.tensor([fp32_elapsed, delta, delta_all, d_obj], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fp32_elapsed, delta, delta_all, d_obj = (float(v) for v in t.tolist())
+            t = torch.tensor([n_flip], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            n_flip = int(t.item())
+        fp32_info = {"fp32_ms_per_step": fp32_elapsed / args.fp32_steps * 1e3, "fp32_steps": args.fp32_steps,
+                     "f16x3_vs_fp32_max_abs": delta,
+                     "f16x3_vs_fp32": {"max_abs_object_embeddings_all_objects": d_obj,
+                                       "max_abs_cell_embeddings_cells_with_identical_knn_graph": delta,
+                                       "cells_with_a_knn_tie_flip": n_flip, "cells": n_cells_total,
+                                       "max_abs_cell_embeddings_all_cells": delta_all,
+                                       "mean_pairwise_cosine_of_512_cell_embeddings": cos_mean,
+                                       "note": "DynamicEdgeConv's kNN graph is discrete: an object whose 8th / 9th neighbour "
+                                               "distances nearly tie gets different neighbours from two evaluations that "
+                                               "differ by 1e-5, and its cell's embedding then moves by O(1e-2)"}}
+        del x3_cells, f32_cells, x3_tr, f32_tr
+        log(f"fp32 pass: {fp32_info['fp32_ms_per_step']:.1f} ms per step, max|f16x3 - fp32| = {delta:.2e} "
+            f"({n_flip} cells with a kNN tie flip: {delta_all:.2e})")
 
     # per-phase rates (outside the timed region; SURVEY 8(d) sub-metrics): each phase alone, events on torch's stream
     def timed(fn, reps):
@@ -284,7 +433,7 @@ def main():
                                                        "frac": gbps / 8000.0, "ms_per_step": sg_ms / args.steps}
         # HBM traffic of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this command;
         # bench.py cannot host rocprofv3 itself): newest profiles/*_pmc_traffic.json, kernel k_ws_sa<256, 256, ...>
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
@@ -293,6 +442,8 @@ def main():
                 key = [k for k in kern if k.startswith("k_ws_sa2<256, 256") or k.startswith("k_ws_sa<256, 256")]
                 if key:
                     traffic = kern[key[0]]["hbm_bytes_per_launch"]
+                    traffic_source = ("profiles/" + os.path.basename(files[-1]) + " (separate rocprofv3 --pmc FETCH_SIZE / "
+                                      "WRITE_SIZE passes of this command; not measured in this run)")
         except Exception:
             traffic = None
         out = {
@@ -306,17 +457,24 @@ def main():
             "config": {"workload": (f"{args.cells} cells/GPU ({dict(ragged='n~U{6..26}', fixed16='16', single='1')[args.cell_variant]} objects x 256 pts, {n_obj} objects on rank 0) "
                                     f"+ {args.queries} queries/GPU (6 hints), embed_dim=256, top-{TOPK} over {n_cells_total} cells"),
                        "cells_total": n_cells_total, "queries_total": n_q_total, "objects_rank0": n_obj,
+                       "weights": "random init (torch.manual_seed(1234)), BatchNorm statistics " +
+                                  ("calibrated by one train-mode pass over 64 cells" if args.bn == "calibrated" else "random"),
                        "parallelism": f"cells+queries sharded x{world}, 1 all-gather" if world > 1 else "single GPU"},
             "kernel_ms_per_step": phases, "phase_rates": phase_rates,
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
-                         "traffic": traffic, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
+                         "traffic": traffic, "traffic_source": traffic_source, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
                          "algorithmic_flop_per_step": flops_per_step, "sa3_edge_rows_per_step": e3,
                          "note": ("algorithmic FLOPs = 2*256*256 per SA3 edge row; the f16x3 path executes 3 f16 MFMA FLOPs per "
                                   "algorithmic FLOP, so its ceiling on this metric is peak/3 = 833 TFLOP/s"
                                   if args.precision == "f16x3" else "exact fp32 MFMA path")},
             "host_generation_s": round(gen_s, 2),
+            "fp16_range_guard": "clear" if args.precision == "f16x3" else "n/a (fp32)",
         }
+        if fp32_info:
+            out.update(fp32_info)
+        if exchange:
+            out["exchange"] = exchange
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
             big_host = (os.cpu_count() or 1) >= 32
             n_cells_cpu = args.cpu_cells or (256 if big_host else 16)

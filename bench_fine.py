@@ -58,7 +58,7 @@ def main():
 
     def step():
         with torch.no_grad():
-            return model.forward_packed(*d_in, cell_ptr, hints)
+            return model.forward_packed(*d_in, cell_ptr, hints, check_overflow=False)
 
     for _ in range(args.warmup):
         step()
@@ -74,6 +74,7 @@ def main():
     phases = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
     matcher_ms = sum(v for k, v in phases.items() if k.startswith("match_"))
     assert bool((out.P >= 0).all()) and bool((out.matches0 >= -1).all()) and bool((out.matches0 < 6).all())
+    assert model.overflow_detected() == 0, "fp16-range guard fired: the f16x3 numbers are invalid"
     print(json.dumps({
         "metric": "fine stage: (query, candidate cell) pairs matched per second (16 objects x 6 hints, embed_dim 128)",
         "value": n_pairs / (elapsed / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 14
+#define T2P_ABI_VERSION 15
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -116,6 +116,11 @@ typedef struct t2p_cell_weights {
      * --color_embed ablations only: [n_classes + 1][D], [8][D] */
     const float* class_embedding;
     const float* color_embedding;
+    /* fp16-range guard (cfg->overflow_flag): bound of GA layer 1's output from its input's magnitude,
+     * |gh| <= ga_w1_l1 * max(|F_3|, 1) + ga_b1_absmax with ga_w1_l1 = max over output columns of sum_k |ga_w1[k][col]|
+     * and ga_b1_absmax = max |ga_b1| (that kernel's epilogue is too tight for a running maximum of its own). */
+    float ga_w1_l1;
+    float ga_b1_absmax;
 } t2p_cell_weights;
 
 typedef struct t2p_cell_config {
@@ -145,13 +150,21 @@ typedef struct t2p_cell_config {
      * uses (SuperGlueMatch.forward, models/superglue_matcher.py:101-103); embed_dim may then be any multiple of 64
      * up to 512 (the fine stage trains with 128, README.md:62). */
     int32_t objects_only;
+    /* fp16-range guard of the f16x3 path (precision == 1): the split-precision kernels convert fp32 activations to fp16
+     * (round toward zero: a magnitude past 65504 would saturate silently).  When non-NULL, this DEVICE word receives a
+     * sticky OR of a non-zero code whenever a conversion site of the call may have left fp16's range (bits 0-2: SA level
+     * 1-3 edge inputs, judged by max|A_l| + max|B_l|; bit 3: SA output rows split by the dense table kernels; bit 4: GA
+     * hidden planes, judged by a norm bound; bit 5: rows of the LDS-tiled GEMMs).  The tests are conservative: they may
+     * fire for a checkpoint that would just have fitted, never the other way round.  The caller clears it, reads it after the stream has drained, and must
+     * not trust the call's output when it is set (the Python host raises or re-runs with precision = 0).  NULL: no check. */
+    int32_t* overflow_flag;
 } t2p_cell_config;
 
 /* Optional stage outputs for parity tests (any member may be NULL).  Layouts:
  *   fps_idx[l] uint8 [n_obj][n_cent_l]      local FPS indices into level l's dense ordering
  *   nbr[l]     uint8 [n_obj][n_cent_l][32]  ball-query neighbours (first cnt valid), cnt[l] uint8 [n_obj][n_cent_l]
  *   sa_out[l]  fp32  [n_obj*n_cent_l][C_l+32] rows = [features C_l | centroid xyz | 0 x 29]
- *   features0  fp32  [n_obj][1024]; features2 [n_obj][256]; obj_emb [n_obj][D] (ObjectEncoder output)
+ *   features0  fp32  [n_obj][1024]; features1 [n_obj][512]; features2 [n_obj][256]; obj_emb [n_obj][D] (ObjectEncoder output)
  *   knn_idx    int32 [n_obj][knn_k] global object rows (-1 = none) */
 typedef struct t2p_cell_trace {
     uint8_t* fps_idx[3];
@@ -162,6 +175,7 @@ typedef struct t2p_cell_trace {
     float* features2;
     float* obj_emb;
     int32_t* knn_idx;
+    float* features1;
 } t2p_cell_trace;
 
 size_t t2p_encode_cells_workspace_bytes(int64_t n_obj, int64_t n_cells, const t2p_cell_config* cfg);

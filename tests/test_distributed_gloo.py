@@ -65,6 +65,72 @@ def test_sharded_retrieval_equals_single_process(tmp_path, world, n_cells, n_q):
         assert torch.equal(sc, want_sc), f"rank {r}"
 
 
+# ---- BASELINE configs[2] shard shapes: 100,000 (and 100,001) cells over 8 ranks, 10,000 queries -----------------------
+_DIM3 = 32     # the sharding / gather / index logic does not depend on D; 32 keeps the float64 products small on CPU
+
+
+def _embeddings_c3(n, seed, world):
+    from text2pos_amd import distributed as TD
+    g = torch.Generator().manual_seed(seed)
+    x = torch.nn.functional.normalize(torch.randn(n, _DIM3, generator=g), dim=-1)
+    # exact duplicates sitting on both sides of every shard edge (and of a far-away row): the tie order must survive the
+    # partition, the padding of uneven shards and the gather
+    for r in range(1, world):
+        edge = TD.shard_range(n, r, world)[0]
+        x[edge - 1] = x[5 * r]
+        x[edge] = x[5 * r]
+    return x
+
+
+def _topk_blocked(q, c, k):
+    """float64 scores + argsort(kind="stable") semantics (ties -> lower index) without sorting 100k scores per query:
+    the k-th largest score bounds a small candidate set, which is ordered exactly."""
+    c64, idx, sc = c.double().numpy(), np.zeros((q.shape[0], k), np.int64), np.zeros((q.shape[0], k), np.float64)
+    for lo in range(0, q.shape[0], 250):
+        s = q[lo: lo + 250].double().numpy() @ c64.T
+        kth = -np.partition(-s, k - 1, axis=1)[:, k - 1]
+        for i in range(s.shape[0]):
+            cand = np.flatnonzero(s[i] >= kth[i])
+            order = cand[np.lexsort((cand, -s[i, cand]))][:k]
+            idx[lo + i], sc[lo + i] = order, s[i, order]
+    return torch.from_numpy(idx), torch.from_numpy(sc)
+
+
+def _worker_c3(rank, world, port, n_cells, n_q, k, out_dir):
+    import text2pos_amd  # noqa: F401
+    from text2pos_amd import distributed as TD
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cells, queries = _embeddings_c3(n_cells, 1, world), _embeddings_c3(n_q, 2, world)
+    idx, sc = TD.sharded_retrieval(lambda lo, hi: cells[lo:hi].clone(), lambda lo, hi: queries[lo:hi].clone(), _topk_blocked,
+                                   n_cells, n_q, k, gather_result=False)
+    q_lo, q_hi = TD.shard_range(n_q, rank, world)
+    assert idx.shape == (q_hi - q_lo, k)
+    torch.save((idx, sc), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_cells", [100_000, 100_001])
+def test_sharded_retrieval_world8_config3_shapes(tmp_path, n_cells):
+    """8 ranks x 12,500 (or 12,501 / 12,500: uneven, padded) cells, one all-gather of the shards, 10,000 queries in blocks
+    of 1,250: every rank's block of the top-10 equals the single-process result bit for bit, duplicates across the shard
+    edges included."""
+    from text2pos_amd import distributed as TD
+    world, n_q, k = 8, 10_000, 10
+    mp.spawn(_worker_c3, args=(world, _free_port(), n_cells, n_q, k, str(tmp_path)), nprocs=world, join=True)
+    want_idx, want_sc = _topk_blocked(_embeddings_c3(n_q, 2, world), _embeddings_c3(n_cells, 1, world), k)
+    for r in range(world):
+        lo, hi = TD.shard_range(n_q, r, world)
+        idx, sc = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
+        assert torch.equal(idx, want_idx[lo:hi]), f"rank {r}"
+        assert torch.equal(sc, want_sc[lo:hi]), f"rank {r}"
+    # the duplicated rows do compete: a query equal to the duplicated vector ranks its copies first, in index order
+    cells = _embeddings_c3(n_cells, 1, world)
+    probe_idx, _ = _topk_blocked(cells[5:6], cells, 3)
+    assert probe_idx[0].tolist() == sorted(probe_idx[0].tolist()) and probe_idx[0, 0].item() == 5
+
+
 def test_all_gather_rows_single_process_is_identity():
     import text2pos_amd  # noqa: F401
     from text2pos_amd import distributed as TD

@@ -1,0 +1,520 @@
+"""GPU parity gates (-m gpu) at BASELINE.json's headline size and over the option matrix of the folded inference kernels.
+
+  * the bench's 12,000 cells (seed 20220002) on both arithmetic paths (f16x3 / exact fp32 MFMA): full-size agreement,
+    a drawn sample + the extreme cell sizes against the CPU oracle, and the top-10 of 1,000 ENCODED queries over the
+    12,000 ENCODED cells bit-exact against the reference's float64 NumPy ranking (training/coarse.py:100-140);
+  * the fp16-range guard of the f16x3 path (a checkpoint whose BatchNorm pushes an SA activation past 65504 must raise or
+    be recomputed in fp32, never saturate silently);
+  * eval-mode options: pointnet_features x use_features (models/object_encoder.py:53-58, :86-90, :137-140);
+  * evaluation.pipeline coarse + fine on a synthetic scene against the same pipeline driven by the oracle
+    (evaluation/pipeline.py:38-137, :172-279, evaluation/utils.py:31-54).
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+SEED = 20220002          # bench.py: 20220000 + config id
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _to_dev(*arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(_dev()) for a in arrs]
+
+
+@pytest.fixture(autouse=True)
+def _restore_torch_threads():
+    """_oracle_threads() below changes torch's intra-op pool for the oracle's sake; other test modules (the training-gradient
+    comparisons, whose float32 reduction order depends on it) must see the pool they always saw."""
+    n = torch.get_num_threads()
+    yield
+    torch.set_num_threads(n)
+
+
+def _oracle_threads():
+    # the oracle's per-cell eager graph is made of tiny ops: 8-16 intra-op threads are fastest, the box's 256 pathological
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
+def _sub_batch(arrs, cell_ptr, cells):
+    """Objects of the chosen cells, concatenated, with their own CSR pointer."""
+    idx = np.concatenate([np.arange(cell_ptr[c], cell_ptr[c + 1]) for c in cells])
+    ptr = np.zeros(len(cells) + 1, dtype=np.int32)
+    ptr[1:] = np.cumsum([cell_ptr[c + 1] - cell_ptr[c] for c in cells])
+    return [a[idx] for a in arrs], ptr
+
+
+def _calibrate_batchnorm_packed(om, xyz, rgb, center, mean_rgb, cell_ptr):
+    """Random weights give nearly identical cell embeddings (pairwise cosine > 0.99999: rankings are near-ties and a 1e-4
+    bar on the unit-norm output says little about the layers in front).  Like a trained checkpoint, the test model gets
+    BatchNorm running statistics that match its data: one train-mode pass of the oracle over a sample with cumulative
+    averaging (momentum=None; the PointNet++ layers average their per-cell statistics), then eval()."""
+    bns = [m for m in om.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    for m in bns:
+        m.reset_running_stats()
+        m.momentum = None
+    om.train()
+    with torch.no_grad():
+        om.encode_objects_packed_grad(xyz, rgb, center, mean_rgb, cell_ptr)
+    om.eval()
+    for m in bns:
+        m.momentum = 0.1
+
+
+def _knn_flips(knn_a, knn_b, embn64, cell_ptr):
+    """Objects whose DynamicEdgeConv neighbour lists differ between two runs, and the evidence that every such difference
+    is a near-tie: the squared distances (float64, from one run's normalised object embeddings) of the neighbours that
+    appear in only one of the two lists differ by less than 1e-4.  Returns (cells containing such an object, worst gap)."""
+    diff = np.flatnonzero((knn_a != knn_b).any(axis=1))
+    cell_of = np.repeat(np.arange(len(cell_ptr) - 1), np.diff(cell_ptr))
+    worst = 0.0
+    for i in diff:
+        only = sorted((set(knn_a[i].tolist()) ^ set(knn_b[i].tolist())) - {-1})
+        if not only:      # same set, different order: distances tied to the last bit
+            continue
+        d2 = ((embn64[only] - embn64[i]) ** 2).sum(axis=1)
+        worst = max(worst, float(d2.max() - d2.min()))
+    return np.unique(cell_of[diff]), worst
+
+
+@pytest.mark.parametrize("checkpoint", ["golden", "calibrated"])
+def test_headline_config_full_size_parity(oracle_model, vocab, checkpoint):
+    """BASELINE configs[1] under a parity gate: 12,000 cells + 1,000 queries, embed_dim 256, top-10.  Twice: with the
+    golden random weights, and with the same weights after a BatchNorm calibration pass over 48 of the cells (embeddings
+    spread out like a trained model's: pairwise cosine well below 1, so the 1e-4 bar bites).
+
+    The path is continuous up to the object embeddings and then takes a DISCRETE step: DynamicEdgeConv's kNN graph
+    (models/cell_retrieval.py:46-48).  Two evaluations whose object embeddings differ by 1e-5 pick a different 8th
+    neighbour wherever the 8th and 9th distances nearly tie (measured: 8 of 191,749 objects between the f16x3 and fp32
+    paths), and such a cell's embedding then moves by up to ~5e-2 - in the reference as much as here.  So the gate is:
+    object embeddings within 1e-4 everywhere; every neighbour-list difference a proven near-tie; cell embeddings within
+    1e-4 for every cell without such a difference; such cells rare."""
+    import copy
+    import ctypes as C
+    import text2pos_amd as t2p
+    from oracle import lib as oracle_lib
+    from oracle.model import retrieve_topk_f64
+    from text2pos_amd import synthetic as S
+    n_cells, n_q = 12000, 1000
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(SEED, n_cells)
+    assert xyz.shape[0] == int(cell_ptr[-1]) and 180_000 < xyz.shape[0] < 200_000
+    _oracle_threads()
+    if checkpoint == "calibrated":
+        oracle_model = copy.deepcopy(oracle_model)
+        n0 = int(cell_ptr[48])
+        _calibrate_batchnorm_packed(oracle_model, xyz[:n0], rgb[:n0], center[:n0], mean_rgb[:n0], cell_ptr[:49])
+    dargs = _to_dev(xyz, rgb, center, mean_rgb)
+    models = {}
+    for precision in ("f16x3", "fp32"):
+        m = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(), precision=precision)
+        m.load_state_dict(oracle_model.state_dict(), strict=True)
+        models[precision] = m.to(_dev()).eval()
+    hip_model, fp32_model = models["f16x3"], models["fp32"]
+    light = ("obj_emb", "knn_idx")                                       # (the full stage trace would be 24 GB here)
+    with torch.no_grad():
+        x3, tr3 = hip_model.encode_objects_packed(*dargs, cell_ptr, want_trace=light)   # check_overflow: guard stays clear
+        f32, tr32 = fp32_model.encode_objects_packed(*dargs, cell_ptr, want_trace=light)
+    assert x3.shape == (n_cells, 256) and bool(torch.isfinite(x3).all())
+    if checkpoint == "calibrated":
+        sample = x3[:512]
+        cos = (sample @ sample.T)[torch.triu(torch.ones(512, 512, dtype=torch.bool, device=x3.device), 1)]
+        assert cos.max().item() < 0.999 and cos.mean().item() < 0.9, "calibrated embeddings should be spread out"
+    # (a) the two arithmetic paths at full size: continuous part everywhere, cell embeddings wherever the graphs agree
+    d_obj = (tr3["obj_emb"] - tr32["obj_emb"]).abs().max().item()
+    assert d_obj < TOL, f"object embeddings, f16x3 vs fp32 over {xyz.shape[0]} objects: {d_obj:.3e}"
+    embn64 = torch.nn.functional.normalize(tr32["obj_emb"].double(), dim=-1).cpu().numpy()
+    # (knn_idx rows are local to the internal chunk; both runs chunk alike, and the distances only need the members)
+    chunk0 = np.zeros(xyz.shape[0], dtype=np.int64)
+    lo = 0
+    for c in range(n_cells):                                            # chunk starts: whole cells, <= 32768 objects
+        if cell_ptr[c + 1] - lo > 32768:
+            lo = cell_ptr[c]
+        chunk0[cell_ptr[c]: cell_ptr[c + 1]] = lo
+    ka, kb = tr3["knn_idx"].cpu().numpy().astype(np.int64), tr32["knn_idx"].cpu().numpy().astype(np.int64)
+    ka, kb = np.where(ka >= 0, ka + chunk0[:, None], -1), np.where(kb >= 0, kb + chunk0[:, None], -1)
+    cell_of = np.repeat(np.arange(n_cells), np.diff(cell_ptr))
+    assert (cell_of[np.maximum(ka, 0)] == cell_of[:, None])[ka >= 0].all()       # neighbours stay inside their cell
+    flip_cells, worst = _knn_flips(ka, kb, embn64, cell_ptr)
+    assert worst < 1e-4, f"a neighbour-list difference that is not a near-tie (distance gap {worst:.2e})"
+    assert len(flip_cells) <= n_cells // 200, f"{len(flip_cells)} cells with kNN tie flips"
+    same = np.ones(n_cells, dtype=bool)
+    same[flip_cells] = False
+    per_cell = (x3 - f32).abs().max(dim=1).values.cpu().numpy()
+    d = float(per_cell[same].max())
+    assert d < TOL, f"f16x3 vs fp32 over the {int(same.sum())} cells with identical graphs: max|delta| = {d:.3e}"
+    # (b) both against the oracle on >= 128 drawn cells + the extreme sizes the generator produces (n = 6 and n = 26),
+    #     stage by stage: the sub-batch is its own call (cells do not depend on their neighbours in a batch: bit-identical)
+    sizes = cell_ptr[1:] - cell_ptr[:-1]
+    assert sizes.min() == 6 and sizes.max() == 26
+    rng = np.random.default_rng(7)
+    pick = set(rng.choice(n_cells, 128, replace=False).tolist())
+    pick |= set(np.flatnonzero(sizes == 6)[:8].tolist()) | set(np.flatnonzero(sizes == 26)[:8].tolist())
+    pick = sorted(pick)
+    sel = torch.tensor(pick)
+    sub, sub_ptr = _sub_batch((xyz, rgb, center, mean_rgb), cell_ptr, pick)
+    otr = []
+    want = oracle_model.encode_objects_packed(*sub, sub_ptr, trace=otr)
+    want_emb = [t for t in otr if "object_embeddings" in t][0]["object_embeddings"]
+    want_embn = np.ascontiguousarray(torch.nn.functional.normalize(want_emb, dim=-1).numpy())
+    want_knn = np.zeros((want_embn.shape[0], 8), np.int32)
+    fp = lambda a_, t_: a_.ctypes.data_as(C.POINTER(t_))
+    oracle_lib().t2p_oracle_knn(fp(want_embn, C.c_float), fp(sub_ptr, C.c_int32), C.c_int32(len(pick)), C.c_int32(256),
+                                C.c_int32(8), fp(want_knn, C.c_int32))
+    for name, model, full in (("f16x3", hip_model, x3), ("fp32", fp32_model, f32)):
+        with torch.no_grad():
+            got, gtr = model.encode_objects_packed(*_to_dev(*sub), sub_ptr, want_trace=light)
+        assert torch.equal(got, full[sel.to(full.device)]), f"{name}: a cell's embedding depends on its batch"
+        e_obj = (gtr["obj_emb"].cpu() - want_emb).abs().max().item()
+        assert e_obj < TOL, f"{name} object embeddings vs oracle: {e_obj:.3e}"
+        flips, worst = _knn_flips(gtr["knn_idx"].cpu().numpy().astype(np.int64), want_knn.astype(np.int64),
+                                  want_embn.astype(np.float64), sub_ptr)
+        assert worst < 1e-4 and len(flips) <= max(1, len(pick) // 50), (name, worst, len(flips))
+        ok = np.ones(len(pick), dtype=bool)
+        ok[flips] = False
+        err = (got.cpu() - want).abs().max(dim=1).values.numpy()[ok].max()
+        assert err < TOL, f"{name} vs oracle on {int(ok.sum())} of the 12,000 cells: {err:.3e}"
+    # (c) retrieval of the ENCODED queries over the ENCODED cells: bit-exact indices against the reference's float64 NumPy
+    texts = S.make_texts(SEED, 0, n_q)
+    with torch.no_grad():
+        q = hip_model.encode_text(texts)
+    idx, score = t2p.retrieve_topk(x3, q, 10)
+    widx, wscore = retrieve_topk_f64(x3.cpu().numpy(), q.cpu().numpy(), 10)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    assert np.abs(score.cpu().numpy() - wscore).max() < 1e-12
+    # the ranking is also stable across the two arithmetic paths: eps = the largest score change any (query, cell) pair
+    # sees between them (cells with a tie flip aside); a query whose top-11 gaps all exceed 2 eps, with no flipped cell
+    # among either run's top-11, must keep its top-10 exactly
+    flipped = torch.from_numpy(~same).to(x3.device)
+    eps = (q @ (x3 - f32)[~flipped].T).abs().max().item()
+    idx32, _ = t2p.retrieve_topk(f32, q, 11)
+    idx11, score11 = t2p.retrieve_topk(x3, q, 11)
+    gap = (score11[:, :-1] - score11[:, 1:]).min(dim=1).values
+    stable = (gap > 2.02 * eps) & ~flipped[idx11].any(dim=1) & ~flipped[idx32].any(dim=1)
+    assert torch.equal(idx11[stable][:, :10], idx32[stable][:, :10])
+    if checkpoint == "calibrated":          # (the golden weights' collapsed embeddings leave few queries with a clear gap)
+        assert int(stable.sum()) > n_q // 4, (int(stable.sum()), eps)
+    # queries against the oracle too (drawn sample)
+    qs = rng.choice(n_q, 64, replace=False)
+    want_q = oracle_model.encode_text([texts[i] for i in qs])
+    assert (q.cpu()[torch.from_numpy(qs)] - want_q).abs().max().item() < TOL
+
+
+def _hot_checkpoint(oracle_model, factor):
+    """The golden weights with the BatchNorm behind SA3's first Linear scaled: its activations grow by `factor`."""
+    import copy
+    sd = copy.deepcopy(oracle_model.state_dict())
+    key = "object_encoder.pointnet.sa3.point_conv.local_nn.0.1."
+    sd[key + "weight"] = sd[key + "weight"] * factor
+    sd[key + "bias"] = sd[key + "bias"] * factor
+    return sd
+
+
+def test_f16x3_activation_overflow_is_caught(oracle_model, vocab):
+    """A checkpoint with a hot channel: relu(A_j - B_i) of SA level 3 exceeds fp16's 65504.  The f16x3 path must not return
+    saturated numbers: on_overflow="raise" raises FloatingPointError, on_overflow="fp32" recomputes the call on the exact
+    fp32 path (== the fp32 model, bit for bit); a moderately hot checkpoint (activations ~1e3) passes the guard and still
+    meets the oracle."""
+    import text2pos_amd as t2p
+    from oracle import model as OM
+    from text2pos_amd import synthetic as S
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(91, 4)
+    dargs = _to_dev(xyz, rgb, center, mean_rgb)
+
+    def build(sd, **kw):
+        m = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(), **kw)
+        m.load_state_dict(sd, strict=True)
+        return m.to(_dev()).eval()
+
+    hot = _hot_checkpoint(oracle_model, 3.0e5)
+    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args()).eval()
+    om.load_state_dict(hot, strict=True)
+    tr = []
+    want = om.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr, trace=tr)
+    sa3_in_scale = max(float(d["out"].abs().max()) for t in tr if "sa" in t for d in t["sa"])
+    assert np.isfinite(want.numpy()).all() and sa3_in_scale > 1.0      # the oracle itself is fine in fp32
+    with torch.no_grad():
+        with pytest.raises(FloatingPointError, match="fp16"):
+            build(hot).encode_objects_packed(*dargs, cell_ptr)
+        exact = build(hot, precision="fp32").encode_objects_packed(*dargs, cell_ptr)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            redo = build(hot, on_overflow="fp32").encode_objects_packed(*dargs, cell_ptr)
+        assert any("fp32" in str(x.message) for x in w)
+    assert torch.equal(redo, exact)
+    assert (exact.cpu() - want).abs().max().item() < 5e-4      # fp32 at activations ~1e6: the bar scales with them
+    # deferred form used by pipelined callers: no synchronisation inside the call, one check afterwards
+    m = build(hot)
+    with torch.no_grad():
+        m.encode_objects_packed(*dargs, cell_ptr, check_overflow=False)
+    assert m.overflow_detected() & 4 and m.overflow_detected() == 0     # bit 2 = SA level 3; reading clears
+    # warm, not hot: two orders of magnitude below the limit -> guard silent, parity holds
+    warm = _hot_checkpoint(oracle_model, 3.0e2)
+    om.load_state_dict(warm, strict=True)
+    want_w = om.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)
+    with torch.no_grad():
+        got_w = build(warm).encode_objects_packed(*dargs, cell_ptr)
+    assert (got_w.cpu() - want_w).abs().max().item() < TOL
+
+
+def test_f16x3_weight_out_of_range_is_refused(oracle_model, vocab):
+    """A folded weight past fp16's range cannot enter the f16x3 images: packing raises and names precision="fp32"."""
+    import copy
+    import text2pos_amd as t2p
+    from text2pos_amd import packing, synthetic as S
+    sd = copy.deepcopy(oracle_model.state_dict())
+    sd["object_encoder.pointnet.ga.mlp.1.0.weight"][3, 5] = 1.0e9
+    m = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    args = _to_dev(*S.make_objects(5, 0, 6))
+    with torch.no_grad(), pytest.raises(packing.Fp16RangeError, match="fp32"):
+        m.encode_objects_packed(*args, np.array([0, 6], dtype=np.int32))
+
+
+_FEATURE_SETS = {"all": ["class", "color", "position"], "class+position": ["class", "position"], "color": ["color"],
+                 "class": ["class"]}
+
+
+@pytest.mark.parametrize("use", list(_FEATURE_SETS))
+@pytest.mark.parametrize("pointnet_features", [0, 1, 2])
+def test_eval_option_matrix_vs_oracle(vocab, pointnet_features, use):
+    """The folded inference kernels under every --pointnet_features x --use_features combination: PointNet++ feature
+    vectors (features0 [1024] / features1 [512] / features2 [256]), ObjectEncoder output and cell embeddings against the
+    oracle.  Without "color" the PointNet++ sees zeroed colours (models/object_encoder.py:86-90); with one feature the
+    merge MLP is skipped (:137-140); without "class" the PointNet++ output is not used at all.
+    (The reference reads `.features2` whatever the flag (models/object_encoder.py:93), so its own forward only runs with
+    pointnet_features = 2; 0 / 1 follow the constructor's widths, :53-58, as the oracle does.)"""
+    import weights as W
+    import text2pos_amd as t2p
+    from oracle import model as OM
+    from text2pos_amd import synthetic as S
+    kw = dict(use_features=_FEATURE_SETS[use], pointnet_features=pointnet_features)
+    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(**kw)).eval()
+    W.fill_state_dict(om, 17)
+    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(**kw))
+    hm.load_state_dict(om.state_dict(), strict=True)
+    hm = hm.to(_dev()).eval()
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(300 + pointnet_features, 3)
+    tr = []
+    want = om.encode_objects_packed(xyz, rgb.copy(), center, mean_rgb, cell_ptr, trace=tr)
+    with torch.no_grad():
+        got, gtr = hm.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr, want_trace=True)
+    assert (got.cpu() - want).abs().max().item() < TOL
+    emb = [d for d in tr if "object_embeddings" in d][0]["object_embeddings"]
+    assert (gtr["obj_emb"].cpu() - emb).abs().max().item() < TOL
+    if "class" in _FEATURE_SETS[use]:
+        pn = [d for d in tr if "sa" in d]
+        for name in ("features0", "features1", "features2"):
+            ref = torch.cat([d[name] for d in pn])
+            assert (gtr[name].cpu() - ref).abs().max().item() < TOL, name
+    # the reference-signature entry point zeroes the colours itself when "color" is not a feature
+    if "color" not in _FEATURE_SETS[use]:
+        from text2pos_amd import data as D
+        objects, points = [], []
+        for c in range(len(cell_ptr) - 1):
+            lo, hi = int(cell_ptr[c]), int(cell_ptr[c + 1])
+            objects.append([D.Object3d(i, i, np.tile(center[i].astype(np.float64), (2, 1)),
+                                       np.tile(mean_rgb[i].astype(np.float64), (2, 1)), "box") for i in range(lo, hi)])
+            points.append(D.Batch(x=torch.from_numpy(rgb[lo:hi].reshape(-1, 3).copy()),
+                                  pos=torch.from_numpy(xyz[lo:hi].reshape(-1, 3).copy()),
+                                  batch=torch.arange(hi - lo).repeat_interleave(256)))
+        with torch.no_grad():
+            assert torch.equal(hm.encode_objects(objects, points), got)
+
+
+# ---- end-to-end pipeline against the oracle --------------------------------------------------------------------------
+def _toy_scene(n_cells=24, n_poses=24, seed=11):
+    from text2pos_amd import data as D, synthetic as S
+    rng = np.random.default_rng(seed)
+    cells, poses = [], []
+    dirs = ["north", "south", "east", "west", "on-top"]
+    for i in range(n_cells):
+        objs = []
+        for j in range(int(rng.integers(6, 20))):
+            c = rng.random(3) * np.array([1.0, 1.0, 0.3])
+            n = int(rng.integers(30, 400))
+            col = np.clip(rng.random(3), 0, 1)
+            objs.append(D.Object3d(j, 1000 * i + j, c + 0.05 * rng.standard_normal((n, 3)),
+                                   np.clip(col + 0.05 * rng.standard_normal((n, 3)), 0, 1),
+                                   S.LABELS[int(rng.integers(0, len(S.LABELS)))]))
+        x, y = 30.0 * (i % 6), 30.0 * (i // 6)
+        cells.append(D.Cell(i, "toy1", objs, 30.0, np.array([x, y, 0.0, x + 30.0, y + 30.0, 10.0])))
+    for q in range(n_poses):
+        c = cells[int(rng.integers(0, n_cells))]
+        descs = [D.DescriptionBestCell(dirs[int(rng.integers(0, 5))], o.get_color_text(), o.label, o.id, True)
+                 for o in [c.objects[int(k)] for k in rng.choice(len(c.objects), 6, replace=False)]]   # distinct objects:
+        # a repeated hint sentence would tie two columns of the matching matrix exactly
+        poses.append(D.Pose(rng.random(3), c.bbox_w[0:3] + rng.random(3) * 30.0, c.id, "toy1", descs))
+    return cells, poses
+
+
+class _OracleCoarse:
+    """The oracle behind the reference's model interface (encode_objects / encode_text), host tensors."""
+
+    def __init__(self, om):
+        self.om = om
+
+    def encode_objects(self, objects, object_points):
+        from text2pos_amd.data import pack_cells
+        xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, 256)
+        return self.om.encode_objects_packed(xyz.numpy(), rgb.numpy(), center.numpy(), mean_rgb.numpy(), cell_ptr)
+
+    def encode_text(self, texts):
+        return self.om.encode_text(texts)
+
+
+class _OracleFine:
+    def __init__(self, orc):
+        self.orc = orc
+
+    def __call__(self, objects, hints, object_points):
+        from text2pos_amd.data import pack_cells
+        from text2pos_amd.superglue_matcher import MatchOutputs
+        xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, 256)
+        out = self.orc.forward_packed(xyz.numpy(), rgb.numpy(), center.numpy(), mean_rgb.numpy(), cell_ptr, hints)
+        return MatchOutputs(**out)
+
+
+def _calibrate_batchnorm(om, cells, seed):
+    """_calibrate_batchnorm_packed over the cells of a scene (resampled with their own seeded T.FixedPoints draw)."""
+    from text2pos_amd import data as D, pipeline as PL
+    from text2pos_amd.data import pack_cells
+    tf = PL.default_transform(256, seed)
+    objs = [list(c.objects) for c in cells]
+    xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objs, [D.batch_object_points(o, tf) for o in objs], 256)
+    _calibrate_batchnorm_packed(om, xyz.numpy(), rgb.numpy(), center.numpy(), mean_rgb.numpy(), cell_ptr)
+
+
+def _calibrated_fine_pair(vocab, cells, pad):
+    """(product SuperGlueMatch on the GPU, oracle) with the object encoder's BatchNorm calibrated on the scene (distinct
+    object encodings) and final_proj scaled up so that the matcher's scores peak: with the plain random weights every score
+    sits at the uniform 1/16 and nothing is ever matched - a comparison of all -1 lists would prove little."""
+    from conftest import make_fine_pair
+    from text2pos_amd import data as D, pipeline as PL
+    from text2pos_amd.data import pack_cells
+    prod, orc = make_fine_pair(vocab, 2, 14)
+    bns = [m for m in orc.object_encoder.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    for m in bns:
+        m.reset_running_stats()
+        m.momentum = None
+    orc.object_encoder.train()
+    objs = [(list(c.objects)[:pad] + [D.Object3d.create_padding()] * pad)[:pad] for c in cells]
+    tf = PL.default_transform(256, 98)
+    xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objs, [D.batch_object_points(o, tf) for o in objs], 256)
+    orc.forward_packed(xyz.numpy(), rgb.numpy(), center.numpy(), mean_rgb.numpy(), cell_ptr,
+                       [["The pose is north of a gray road."] * 6] * len(objs))       # (no_grad; train-mode statistics only)
+    orc.eval()
+    for m in bns:
+        m.momentum = 0.1
+    with torch.no_grad():
+        for t in (orc.superglue.final_proj.weight, orc.superglue.final_proj.bias,
+                  prod.superglue.final_proj.weight, prod.superglue.final_proj.bias):
+            t.mul_(4.0)
+    prod.object_encoder.load_state_dict(orc.object_encoder.state_dict(), strict=True)
+    return prod.to(_dev()).eval(), orc
+
+
+def test_pipeline_end_to_end_vs_oracle(tmp_path, oracle_model, vocab):
+    """pipeline.run_coarse + evaluation.run_fine (io -> coarse retrieval -> fine localisation -> accuracy tables) on the
+    HIP path against the same pipeline driven by the oracle: identical retrieval lists, bit-exact matches, poses within
+    1e-4, equal accuracy tables.  The T.FixedPoints draws are seeded per stage, so both runs see the same resampled
+    objects.  Queries whose ORACLE ranking has a float64 score gap below 1e-3 inside the top-(k+1) are left out of the
+    scene (a gap below the 1e-4 embedding tolerance would make "identical lists" a coin toss, not a parity statement)."""
+    import copy
+    import text2pos_amd as t2p
+    from oracle.model import retrieve_topk_f64
+    from text2pos_amd import data as D, evaluation as E, io as IO, pipeline as PL, synthetic as S
+    top_k, threshs, pad, n_keep = (1, 2, 3), (5, 10, 15), 16, 24
+    cells, poses = _toy_scene(n_poses=60)
+    _oracle_threads()
+    prod_fine, orc_fine = _calibrated_fine_pair(vocab, cells, pad)
+    om = copy.deepcopy(oracle_model)
+    _calibrate_batchnorm(om, cells, seed=99)
+    hip = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
+    hip.load_state_dict(om.state_dict(), strict=True)
+    hip = hip.to(_dev()).eval()
+
+    # ---- oracle coarse stage (evaluation/pipeline.py:60-137): encode, NumPy float64 ranking; pick the scene's queries
+    IO.save_scene(str(tmp_path / "all"), "toy1", cells, poses)
+    sc_all = IO.load_scenes(str(tmp_path / "all"), ["toy1"])
+    oc = _OracleCoarse(om)
+    tf = PL.default_transform(256, 1)
+    enc = []
+    for lo in range(0, len(sc_all.all_cells), 64):
+        objs = [list(c.objects) for c in sc_all.all_cells[lo: lo + 64]]
+        enc.append(oc.encode_objects(objs, [D.batch_object_points(o, tf) for o in objs]))
+    cell_enc, text_enc = torch.cat(enc).numpy(), oc.encode_text(sc_all.texts).numpy()
+    cos = (cell_enc @ cell_enc.T)[np.triu_indices(len(cells), 1)]
+    assert cos.max() < 0.9, "calibrated embeddings should be well separated"
+    widx, wscore = retrieve_topk_f64(cell_enc, text_enc, max(top_k) + 1)
+    clear = np.flatnonzero((wscore[:, :-1] - wscore[:, 1:]).min(axis=1) > 1e-3)
+    assert len(clear) >= n_keep, f"only {len(clear)} of {len(poses)} queries have unambiguous rankings"
+    keep = clear[:n_keep]
+    widx = widx[keep]
+    IO.save_scene(str(tmp_path / "kept"), "toy1", cells, [poses[i] for i in keep])
+    sc = IO.load_scenes(str(tmp_path / "kept"), ["toy1"])
+    assert len(sc.all_poses) == n_keep
+
+    # ---- HIP path: the product's own drivers, stage by stage so that each stage gets its own seeded draw
+    retr, acc = PL.run_coarse(hip, sc, PL.default_transform(256, 1), top_k, threshs)
+    seen = {}
+
+    class Spy:                                  # records what the fine model returned per (query, candidate)
+        def __call__(self, objects, hints, points):
+            out = prod_fine(objects, hints, points)
+            seen.setdefault("m0", []).append(out.matches0.cpu().numpy())
+            seen.setdefault("off", []).append(out.offsets.cpu().numpy())
+            seen.setdefault("P", []).append(out.P.cpu().numpy())
+            return out
+    np.random.seed(2022)   # Object3d.create_padding draws its 8 points from np.random (imports.py:81): same pads in both runs
+    fine_tables = E.run_fine(Spy(), sc.all_poses, sc.cells_dict, retr, PL.default_transform(256, 2), pad, list(top_k),
+                             list(threshs), queries_per_call=8)
+
+    # ---- comparison
+    db_ids = [c.id for c in sc.all_cells]
+    want_retr = [[db_ids[j] for j in row[:max(top_k)]] for row in widx]
+    assert retr == want_retr                                            # identical retrieval lists
+    centers = np.array([c.get_center()[0:2] for c in sc.all_cells])
+    w_hit, w_close, _ = E.retrieval_accuracies(widx[:, :max(top_k)], db_ids, [p.cell_id for p in sc.all_poses],
+                                               np.array([p.pose_w for p in sc.all_poses]), centers, 30.0, list(top_k))
+    assert acc["hit"] == w_hit and acc["close"] == w_close
+    assert acc["localisation"] == E.localisation_accuracies(sc.all_poses, want_retr, sc.cells_dict, list(top_k), list(threshs))
+    oseen = {}
+
+    class OSpy:
+        def __call__(self, objects, hints, points):
+            out = _OracleFine(orc_fine)(objects, hints, points)
+            oseen.setdefault("m0", []).append(out.matches0.numpy())
+            oseen.setdefault("off", []).append(out.offsets.numpy())
+            oseen.setdefault("P", []).append(out.P.numpy())
+            return out
+    np.random.seed(2022)
+    want_tables = E.run_fine(OSpy(), sc.all_poses, sc.cells_dict, want_retr, PL.default_transform(256, 2), pad, list(top_k),
+                             list(threshs), queries_per_call=8)
+    m0, om0 = np.concatenate(seen["m0"]), np.concatenate(oseen["m0"])
+    if not np.array_equal(m0, om0):
+        bad = np.argwhere(m0 != om0)
+        P_h, P_o = np.concatenate(seen["P"]), np.concatenate(oseen["P"])
+        print("DIFF", len(bad), "max|dP|", np.abs(P_h - P_o).max())
+        for b, o in bad[:10]:
+            print(b, o, "hip", m0[b, o], "oracle", om0[b, o], "P row hip", np.round(P_h[b, o], 4), "P row oracle", np.round(P_o[b, o], 4))
+    assert np.array_equal(m0, om0) and (m0 >= 0).any() and (m0 < 0).any()       # matches bit-exact, both kinds present
+    assert np.abs(np.concatenate(seen["off"]) - np.concatenate(oseen["off"])).max() < TOL
+    assert np.abs(np.concatenate(seen["P"]) - np.concatenate(oseen["P"])).max() < TOL
+    # poses in the cell from matches + offsets (models/superglue_matcher.py:139-161), per (query, candidate)
+    from text2pos_amd.superglue_matcher import get_pos_in_cell
+    k = max(top_k)
+    pad_objs = lambda cid: (list(sc.cells_dict[cid].objects)[:pad] + [D.Object3d.create_padding()] * pad)[:pad]
+    # (a padding object's centre is ~0.0005: which of them stands in here moves the compared positions by < 1e-3 * 1e-3)
+    off, ooff = np.concatenate(seen["off"]), np.concatenate(oseen["off"])
+    for i in range(m0.shape[0]):
+        objs = pad_objs(retr[i // k][i % k])
+        assert np.abs(get_pos_in_cell(objs, m0[i], off[i]) - get_pos_in_cell(objs, om0[i], ooff[i])).max() < TOL
+    assert fine_tables == want_tables                                   # the three accuracy tables (mean / offset / conf)

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -27,7 +27,8 @@ class CellWeights(C.Structure):
                  ("g_wq_x3", c_void), ("lin1_scale", C.c_float), ("lin2_scale", C.c_float), ("merge_scale", C.c_float),
                  ("pn_scale", C.c_float), ("g_wp_scale", C.c_float), ("g_wq_scale", C.c_float),
                  ("sa_w1_x3", c_void * 3), ("ga_w1_x3", c_void),
-                 ("class_embedding", c_void), ("color_embedding", c_void)])
+                 ("class_embedding", c_void), ("color_embedding", c_void),
+                 ("ga_w1_l1", C.c_float), ("ga_b1_absmax", C.c_float)])
 
 
 class CellConfig(C.Structure):
@@ -36,12 +37,13 @@ class CellConfig(C.Structure):
                 ("self_loops", C.c_int32), ("knn_k", C.c_int32), ("variation", C.c_int32),
                 ("radius", C.c_float * 3), ("chunk_objects", C.c_int32), ("precision", C.c_int32),
                 ("class_embed", C.c_int32), ("color_embed", C.c_int32), ("class_idx", c_void), ("color_idx", c_void),
-                ("objects_only", C.c_int32)]
+                ("objects_only", C.c_int32), ("overflow_flag", c_void)]
 
 
 class CellTrace(C.Structure):
     _fields_ = [("fps_idx", c_void * 3), ("nbr", c_void * 3), ("cnt", c_void * 3), ("sa_out", c_void * 3),
-                ("features0", c_void), ("features2", c_void), ("obj_emb", c_void), ("knn_idx", c_void)]
+                ("features0", c_void), ("features2", c_void), ("obj_emb", c_void), ("knn_idx", c_void),
+                ("features1", c_void)]
 
 
 class MatchWeights(C.Structure):

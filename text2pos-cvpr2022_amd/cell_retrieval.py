@@ -2,10 +2,13 @@
 `device` / `get_device()` and state_dict layout as models/cell_retrieval.py::CellRetrievalNetwork, with the forward
 arithmetic executed by libt2p_hip.so on an MI355X.
 
-Callers that drop in unchanged: training/coarse.py:111,124 (eval_epoch) and evaluation/pipeline.py:73-75,111-113.
-Forward-only (the reference evaluates under torch.no_grad(), training/coarse.py:68); training-mode BatchNorm and
-autograd are not built and raise instead of silently falling back to another implementation.
+Callers that drop in unchanged: training/coarse.py:111,124 (eval_epoch), evaluation/pipeline.py:73-75,111-113 and the
+training step training/coarse.py:31-62.  eval() + torch.no_grad() runs the folded inference kernels (t2p_encode_cells /
+t2p_encode_text); train() runs the batch-statistics path of train_cell.py / modules._LstmTrainFn with backward kernels
+(SURVEY.md 8(f) #4).  Anything else (gradients through the folded kernels, the stage trace in train mode) raises; nothing
+falls back to another implementation.
 """
+import warnings
 from typing import List
 
 import numpy as np
@@ -28,9 +31,12 @@ class DynamicEdgeConv(nn.Module):
 
 class CellRetrievalNetwork(nn.Module):
     def __init__(self, known_classes: List[str], known_colors: List[str], known_words: List[str], args,
-                 add_self_loops: bool = True, precision: str = "f16x3"):
+                 add_self_loops: bool = True, precision: str = "f16x3", on_overflow: str = "raise"):
         """add_self_loops=True reproduces torch_geometric's PointConv default, which the reference relies on
-        (models/pointcloud/pointnet2.py:23); False gives the plain ball-query neighbourhoods."""
+        (models/pointcloud/pointnet2.py:23); False gives the plain ball-query neighbourhoods.
+        on_overflow: what encode_objects* do when the fp16-range guard of the f16x3 path fires (an activation of this
+        checkpoint on this input left fp16's range, include/t2p.h t2p_cell_config.overflow_flag): "raise"
+        (FloatingPointError) or "fp32" (warn and recompute the call on the exact fp32 MFMA path)."""
         super().__init__()
         self.embed_dim = args.embed_dim
         self.use_features = args.use_features
@@ -40,6 +46,10 @@ class CellRetrievalNetwork(nn.Module):
         # "f16x3": the MFMA-heavy layer-2 GEMMs run as three fp16 MFMAs on hi/lo-split operands with fp32 accumulation
         # (split error ~5e-7, below an fp32 fma chain's own rounding); "fp32": exact fp32 MFMA everywhere.
         self.precision = precision
+        if on_overflow not in ("raise", "fp32"):
+            raise ValueError("on_overflow must be 'raise' or 'fp32'")
+        self.on_overflow = on_overflow
+        self._overflow = None
         d = self.embed_dim
         assert args.variation in (0, 1)
         self.graph1 = DynamicEdgeConv(get_mlp([2 * d, d, d], add_batchnorm=True), k=8,
@@ -52,19 +62,35 @@ class CellRetrievalNetwork(nn.Module):
     # ---- text branch -----------------------------------------------------------------------------------------
     def encode_text(self, descriptions):
         """List[str] -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:69-75).  With gradients enabled the text
-        branch runs its training-mode recurrence and the result carries a grad_fn (training/coarse.py:44); the cell branch
-        is forward-only."""
+        branch runs its training-mode recurrence and the result carries a grad_fn (training/coarse.py:44)."""
         return self.language_encoder(descriptions, normalize=True)
 
     # ---- cell branch -----------------------------------------------------------------------------------------
-    def _cell_pack(self):
+    def _cell_pack(self, precision=None):
+        x3 = (precision or self.precision) == "f16x3"
         ver = (packing.params_version(self), str(self.device))
-        if self._pack is None or self._pack[0] != ver:
-            tensors = packing.pack_cell_weights(self, self.device)
-            self._pack = (ver, tensors, ops.make_cell_weights(tensors))
+        if self._pack is None or self._pack[0] != ver or (x3 and not self._pack[3]):
+            tensors = packing.pack_cell_weights(self, self.device, x3=x3)
+            self._pack = (ver, tensors, ops.make_cell_weights(tensors), x3)
         return self._pack[2]
 
-    def _cell_config(self, n_pts, chunk_objects=0, class_idx=None, color_idx=None):
+    def _overflow_word(self):
+        """The sticky fp16-range guard word of this model's f16x3 calls (int32 [1] on the device)."""
+        if self._overflow is None or self._overflow.device != self.device:
+            self._overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._overflow
+
+    def overflow_detected(self) -> int:
+        """Reads (synchronises) and clears the guard word: non-zero = some f16x3 call since the last check converted an
+        activation outside fp16's range and its result must not be used (bit meanings: include/t2p.h)."""
+        if self._overflow is None:
+            return 0
+        code = int(self._overflow.item())
+        if code:
+            self._overflow.zero_()
+        return code
+
+    def _cell_config(self, n_pts, chunk_objects=0, class_idx=None, color_idx=None, precision=None):
         a = self.args
         if bool(getattr(a, "class_embed", False)) != (class_idx is not None) or \
                 bool(getattr(a, "color_embed", False)) != (color_idx is not None):
@@ -75,8 +101,9 @@ class CellRetrievalNetwork(nn.Module):
         return ops.make_cell_config(n_pts=n_pts, embed_dim=self.embed_dim, pointnet_features=a.pointnet_features,
                                     use_features=tuple(a.use_features), self_loops=self.add_self_loops,
                                     knn_k=self.graph1.k, variation=self.variation, radius=radii,
-                                    chunk_objects=chunk_objects, precision=self.precision, class_idx=class_idx,
-                                    color_idx=color_idx)
+                                    chunk_objects=chunk_objects, precision=precision or self.precision,
+                                    class_idx=class_idx, color_idx=color_idx,
+                                    overflow_flag=self._overflow_word() if (precision or self.precision) == "f16x3" else None)
 
     def _check_forward_only(self):
         if self.training:
@@ -87,11 +114,14 @@ class CellRetrievalNetwork(nn.Module):
                                       "torch.no_grad(), or put the model in train() for the training-mode path")
 
     def encode_objects_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, cell_ptr_dev=None, want_trace=False,
-                              chunk_objects=0, class_idx=None, color_idx=None):
+                              chunk_objects=0, class_idx=None, color_idx=None, check_overflow=True):
         """Device-resident packed inputs: xyz/rgb [Nobj, P, 3], center/mean_rgb [Nobj, 3] (fp32, on self.device),
         cell_ptr int32 [B+1] on the host.  Returns [B, D] L2-normalised.  In train() mode (training/coarse.py:32) the
         batch-statistics path of train_cell.py runs instead of the folded inference kernels and the result carries a
-        grad_fn."""
+        grad_fn.
+        check_overflow (f16x3 only): read the fp16-range guard word after the launch (one host synchronisation; the
+        reference's callers move the result to the host right away, training/coarse.py:115) and act as `on_overflow` says.
+        Pipelined callers pass False and call overflow_detected() once their stream has drained."""
         if self.training and not want_trace:
             from .train_cell import encode_objects_train
             return encode_objects_train(self, xyz, rgb, center, mean_rgb, cell_ptr, class_idx, color_idx)
@@ -99,8 +129,21 @@ class CellRetrievalNetwork(nn.Module):
         cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int32)
         if cell_ptr_dev is None:
             cell_ptr_dev = torch.from_numpy(cp).to(self.device)
+        if "color" not in self.args.use_features and not getattr(self.args, "class_embed", False):
+            rgb = torch.zeros_like(rgb)   # models/object_encoder.py:86-90: the PointNet++ then sees x = 0
         cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx)
-        return ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
+        out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
+        if check_overflow and self.precision == "f16x3" and cp.shape[0] > 1:
+            code = self.overflow_detected()
+            if code:
+                msg = (f"f16x3 path: an activation left fp16's range (guard code {code:#x}: bits 0-2 = SA level 1-3 edge "
+                       "inputs, 3 = dense table rows, 4 = GA hidden planes, 5 = GEMM rows)")
+                if self.on_overflow != "fp32":
+                    raise FloatingPointError(msg + "; construct the model with precision=\"fp32\" or on_overflow=\"fp32\"")
+                warnings.warn(msg + "; recomputing this call on the exact fp32 path", RuntimeWarning)
+                cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx, precision="fp32")
+                out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
+        return out
 
     def encode_objects_packed_host(self, xyz, rgb, center, mean_rgb, cell_ptr, cells_per_chunk=2048):
         """The same for HOST tensors (pinned for real overlap): the cells travel in blocks of `cells_per_chunk`; the
@@ -138,7 +181,17 @@ class CellRetrievalNetwork(nn.Module):
             main.wait_event(ev)
             for t in d:
                 t.record_stream(main)
-            outs.append(self.encode_objects_packed(d[0], d[1], d[2], d[3], cpb, d[4]))
+            outs.append(self.encode_objects_packed(d[0], d[1], d[2], d[3], cpb, d[4], check_overflow=False))
+        if self.precision == "f16x3" and self.overflow_detected():   # one check for all blocks (keeps the copies overlapped)
+            if self.on_overflow != "fp32":
+                raise FloatingPointError("f16x3 path: an activation left fp16's range; construct the model with "
+                                         "precision=\"fp32\" or on_overflow=\"fp32\"")
+            warnings.warn("f16x3 path: an activation left fp16's range; recomputing on the exact fp32 path", RuntimeWarning)
+            saved, self.precision = self.precision, "fp32"
+            try:
+                return self.encode_objects_packed_host(xyz, rgb, center, mean_rgb, cell_ptr, cells_per_chunk)
+            finally:
+                self.precision = saved
         return outs[0] if len(outs) == 1 else torch.cat(outs)
 
     def encode_objects(self, objects, object_points):

@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "../../include/t2p.h"
 #include "t2p_common.h"
 
@@ -28,28 +32,61 @@ int num_cus() {
     return cached;
 }
 
+int reserve_lds(const void* kernel, size_t bytes, const char* what) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return 0;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        set_error("%s: cannot reserve %zu B of LDS on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+        return (int)e;
+    }
+    done.insert({dev, kernel});
+    return 0;
+}
+
 // ---- opt-in kernel timing ---------------------------------------------------------------------------------------
+// The only process-global state of the library besides the caches above: a ring of event pairs, guarded by one mutex
+// (launches from several host threads may be recorded; the lock is taken only while profiling is on).
 struct ProfRec {
     const char* name;
     hipEvent_t a, b;
 };
-static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static volatile bool g_prof_on = false;
 static ProfRec g_prof[8192];
 static int g_prof_n = 0;
 
 ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), st(s) {
-    if (!g_prof_on || g_prof_n >= 8192) return;
-    slot = g_prof_n++;
-    g_prof[slot].name = name;
-    if (hipEventCreate(&g_prof[slot].a) != hipSuccess || hipEventCreate(&g_prof[slot].b) != hipSuccess) {
-        slot = -1;
-        g_prof_n--;
+    if (!g_prof_on) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return;
+    if (hipEventCreate(&b) != hipSuccess) {
+        (void)hipEventDestroy(a);
         return;
     }
-    (void)hipEventRecord(g_prof[slot].a, st);
+    {
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (g_prof_n < 8192) {
+            slot = g_prof_n++;
+            g_prof[slot].name = name;
+            g_prof[slot].a = a;
+            g_prof[slot].b = b;
+        }
+    }
+    if (slot < 0) {
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        return;
+    }
+    ev_end = b;
+    (void)hipEventRecord(a, st);
 }
 ProfScope::~ProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+    if (slot >= 0) (void)hipEventRecord((hipEvent_t)ev_end, st);
 }
 
 namespace {
@@ -91,6 +128,7 @@ struct CellWs {
     float *A[3], *B[3], *F[3];
     float *gh, *f0, *f1, *f2, *cat, *emb, *embn, *P, *Q, *x1, *pool, *l1, *l2;
     int32_t *knn, *seg_ptr, *first, *prefix[3], *bounds[3];
+    uint32_t* guard;  // [G_SLOTS] fp16-range guard words of the chunk (t2p_common.h)
 };
 
 // Carve the per-chunk workspace (n objects, nb cells).  With base == nullptr this only measures.
@@ -128,6 +166,7 @@ size_t carve(Bump& b, int64_t n, int64_t nb, const t2p_cell_config& cfg, CellWs*
         w.bounds[l] = b.take<int32_t>(1024 + 1);
     }
     w.seg_ptr = b.take<int32_t>(nb + 1);
+    w.guard = b.take<uint32_t>(G_SLOTS);
     w.pool = b.take<float>(nb * D);
     w.l1 = b.take<float>(nb * D);
     w.l2 = b.take<float>(nb * D);
@@ -186,7 +225,10 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
                  const t2p_cell_trace* tr, int64_t trace_obj0, CellWs& ws, hipStream_t st) {
     Geo g(cfg.n_pts);
     const int D = cfg.embed_dim;
-    T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st));
+    // fp16-range guard (f16x3 only): the chunk's words are cleared by the first kernel and judged by the last
+    uint32_t* guard = (cfg.precision == 1 && cfg.overflow_flag != nullptr) ? ws.guard : nullptr;
+    auto gslot = [&](int i) -> uint32_t* { return guard ? guard + i : nullptr; };
+    T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st, guard));
     // models/object_encoder.py:86: the PointNet++ only runs when the "class" feature does not come from class_embedding
     const bool run_pointnet = cfg.use_class && !cfg.class_embed;
     if (run_pointnet) {
@@ -212,6 +254,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         gt.b1 = W.sa_b1[0];
         gt.rgb = rgb;
         gt.H1 = Geo::H[0];
+        gt.guard = guard;
         T2P_TRY(launch_sample_group(xyz, n, cfg.n_pts, cfg.radius, gt, st));
         // the per-centroid row counts of all three levels exist now: cut every level's balanced object ranges at once
         SaParams bp[3] = {};
@@ -246,6 +289,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
             p.ldo = H;
             p.relu = 0;
             p.M = n * g.nd[l];
+            p.amax_out = gslot(l == 1 ? G_A2 : G_A3);
             T2P_TRY(launch_ws(WS_DENSE_STORE, Geo::LD[l - 1], H, p, st));
         }
         // per-edge ReLU(A_j - B_i) -> layer 2 -> max per centroid
@@ -271,6 +315,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.prefix_ws = ws.prefix[l];
         p.bounds_ws = ws.bounds[l];
         p.balanced = 1;
+        p.amax_out = gslot(G_F1 + l);
         T2P_TRY(launch_ws_sa(H, C, p, st));
     }
     // ---- global abstraction: [x | pos] -> 512 -> 1024, max over the object's 32 points ------------------------
@@ -314,8 +359,8 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     }
     // ---- PointNet2 heads + ObjectEncoder ------------------------------------------------------------------------
     if (cfg.precision == 1 && W.lin1_x3 && W.lin2_x3) {
-        T2P_TRY(launch_gemm_x3(ws.f0, 1024, W.lin1_x3, W.lin1_scale, W.lin1_b, ws.f1, 512, 0, n, 1024, 512, 1, st));
-        T2P_TRY(launch_gemm_x3(ws.f1, 512, W.lin2_x3, W.lin2_scale, W.lin2_b, ws.f2, 256, 0, n, 512, 256, 1, st));
+        T2P_TRY(launch_gemm_x3(ws.f0, 1024, W.lin1_x3, W.lin1_scale, W.lin1_b, ws.f1, 512, 0, n, 1024, 512, 1, st, nullptr, 0, gslot(G_GEMM_IN)));
+        T2P_TRY(launch_gemm_x3(ws.f1, 512, W.lin2_x3, W.lin2_scale, W.lin2_b, ws.f2, 256, 0, n, 512, 256, 1, st, nullptr, 0, gslot(G_GEMM_IN)));
     } else {
         T2P_TRY(launch_gemm(ws.f0, 1024, W.lin1_w, W.lin1_b, ws.f1, 512, 0, n, 1024, 512, 1, st));
         T2P_TRY(launch_gemm(ws.f1, 512, W.lin2_w, W.lin2_b, ws.f2, 256, 0, n, 512, 256, 1, st));
@@ -332,7 +377,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         const int kin = cfg.pointnet_features == 0 ? 1024 : (cfg.pointnet_features == 1 ? 512 : 256);
         // mlp_pointnet into P (scratch), then F.normalize into the concat slot
         if (cfg.precision == 1 && W.pn_x3)
-            T2P_TRY(launch_gemm_x3(fin, kin, W.pn_x3, W.pn_scale, W.pn_b, ws.P, D, 0, n, kin, D, 1, st));
+            T2P_TRY(launch_gemm_x3(fin, kin, W.pn_x3, W.pn_scale, W.pn_b, ws.P, D, 0, n, kin, D, 1, st, nullptr, 0, gslot(G_GEMM_IN)));
         else
             T2P_TRY(launch_gemm(fin, kin, W.pn_w, W.pn_b, ws.P, D, 0, n, kin, D, 1, st));
         T2P_TRY(launch_rownorm(ws.P, D, n, D, ws.cat, ldcat, slot * D, st));
@@ -352,20 +397,21 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     const float* emb = ws.cat;  // single feature: embeddings[0] is returned un-merged (object_encoder.py:137-140)
     if (nfeat > 1) {
         if (cfg.precision == 1 && W.merge_x3)
-            T2P_TRY(launch_gemm_x3(ws.cat, ldcat, W.merge_x3, W.merge_scale, W.merge_b, ws.emb, D, 0, n, ldcat, D, 1, st));
+            T2P_TRY(launch_gemm_x3(ws.cat, ldcat, W.merge_x3, W.merge_scale, W.merge_b, ws.emb, D, 0, n, ldcat, D, 1, st, nullptr, 0, gslot(G_GEMM_IN)));
         else
             T2P_TRY(launch_gemm(ws.cat, ldcat, W.merge_w, W.merge_b, ws.emb, D, 0, n, ldcat, D, 1, st));
         emb = ws.emb;
     }
     if (cfg.objects_only) {  // the fine stage consumes ObjectEncoder.forward's output as is
         T2P_TRY(copy_trace(tr->obj_emb + trace_obj0 * D, emb, (size_t)n * D, st));
+        T2P_TRY(launch_guard_check(guard, cfg.overflow_flag, W.ga_w1_l1, W.ga_b1_absmax, st));
         return 0;
     }
     // ---- cell head: normalize, DynamicEdgeConv(k, max), global max pool, lin, normalize -------------------------
     T2P_TRY(launch_rownorm(emb, D, n, D, ws.embn, D, 0, st));
     if (cfg.precision == 1 && W.g_wp_x3 && W.g_wq_x3) {
-        T2P_TRY(launch_gemm_x3(ws.embn, D, W.g_wp_x3, W.g_wp_scale, W.g_bp, ws.P, D, 0, n, D, D, 0, st));
-        T2P_TRY(launch_gemm_x3(ws.embn, D, W.g_wq_x3, W.g_wq_scale, nullptr, ws.Q, D, 0, n, D, D, 0, st));
+        T2P_TRY(launch_gemm_x3(ws.embn, D, W.g_wp_x3, W.g_wp_scale, W.g_bp, ws.P, D, 0, n, D, D, 0, st, nullptr, 0, gslot(G_GEMM_IN)));
+        T2P_TRY(launch_gemm_x3(ws.embn, D, W.g_wq_x3, W.g_wq_scale, nullptr, ws.Q, D, 0, n, D, D, 0, st, nullptr, 0, gslot(G_GEMM_IN)));
     } else {
         T2P_TRY(launch_gemm(ws.embn, D, W.g_wp, W.g_bp, ws.P, D, 0, n, D, D, 0, st));
         T2P_TRY(launch_gemm(ws.embn, D, W.g_wq, nullptr, ws.Q, D, 0, n, D, D, 0, st));
@@ -393,6 +439,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     T2P_TRY(launch_gemm(ws.pool, D, W.lin_w1, W.lin_b1, ws.l1, D, 0, nb, D, D, 1, st));
     T2P_TRY(launch_gemm(ws.l1, D, W.lin_w2, W.lin_b2, ws.l2, D, 0, nb, D, D, 1, st));
     T2P_TRY(launch_rownorm(ws.l2, D, nb, D, out, D, 0, st));
+    T2P_TRY(launch_guard_check(guard, cfg.overflow_flag, W.ga_w1_l1, W.ga_b1_absmax, st));
 
     if (tr && run_pointnet) {
         for (int l = 0; l < 3; l++) {
@@ -406,6 +453,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
                                (size_t)n * g.nc[l] * Geo::LD[l], st));
         }
         T2P_TRY(copy_trace(tr->features0 ? tr->features0 + trace_obj0 * 1024 : nullptr, ws.f0, (size_t)n * 1024, st));
+        T2P_TRY(copy_trace(tr->features1 ? tr->features1 + trace_obj0 * 512 : nullptr, ws.f1, (size_t)n * 512, st));
         T2P_TRY(copy_trace(tr->features2 ? tr->features2 + trace_obj0 * 256 : nullptr, ws.f2, (size_t)n * 256, st));
     }
     if (tr) {
@@ -433,10 +481,14 @@ extern "C" {
 
 int t2p_abi_version(void) { return T2P_ABI_VERSION; }
 
-void t2p_profile_enable(int on) { g_prof_on = on != 0; }
+void t2p_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof_on = on != 0;
+}
 
 // Waits for the recorded launches, writes one line per kernel name: "<name> <launches> <total_ms>\n", clears.
 int t2p_profile_report(char* buf, size_t n) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     size_t off = 0;
     if (n > 0) buf[0] = 0;
     for (int i = 0; i < g_prof_n; i++) {
@@ -495,6 +547,9 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
                           w->sa_w1_x3[1] && w->sa_w1_x3[2] &&
                           w->ga_w1_x3 && w->ga_w2_x3,
                       "encode_cells: precision = f16x3 needs the packed *_x3 weight images");
+    if (cfg->precision == 1 && cfg->overflow_flag != nullptr)
+        T2P_CHECK_ARG(w->ga_w1_l1 > 0.f && w->ga_b1_absmax >= 0.f,
+                      "encode_cells: the fp16-range guard needs ga_w1_l1 / ga_b1_absmax (packing.py)");
     T2P_CHECK_ARG(cell_ptr_host[0] == 0 && cell_ptr_host[n_cells] == n_obj,
                   "encode_cells: cell_ptr must start at 0 and end at n_obj=%lld (got %d..%d)", (long long)n_obj,
                   cell_ptr_host[0], cell_ptr_host[n_cells]);

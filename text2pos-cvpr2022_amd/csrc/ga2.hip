@@ -151,15 +151,7 @@ __global__ __launch_bounds__(NT, 2) void k_ga2(WsParams p, int n_slices) {
 
 // out[M/32][ldo] (columns [0, 1024)) = max over each 32-row group of relu(A W + b); A as fp16 hi / lo planes [M][lda]
 int launch_ga2(const WsParams& p_in, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ga2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        if (e != hipSuccess) {
-            set_error("ga2: cannot reserve %zu B of LDS: %s", kLds, hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    T2P_TRY(reserve_lds((const void*)k_ga2, kLds, "ga2"));
     WsParams p = p_in;
     p.n_groups = p.M / 32;
     if (p.n_groups <= 0) return 0;

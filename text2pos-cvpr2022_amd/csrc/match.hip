@@ -277,16 +277,7 @@ int t2p_match(const float* desc0, const float* desc1, int64_t batch, int32_t n_o
         T2P_CHECK_LAUNCH("match_concat");
     }
     auto attn = D == 64 ? k_attn<16> : (D == 128 ? k_attn<32> : k_attn<64>);
-    static bool attr_set[3] = {false, false, false};
-    const int ai = D == 64 ? 0 : (D == 128 ? 1 : 2);
-    if (!attr_set[ai]) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("match: cannot reserve LDS: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set[ai] = true;
-    }
+    T2P_TRY(reserve_lds((const void*)attn, 160 * 1024, "match"));
     for (int l = 0; l < w->n_layers; l++) {
         const float* wqkv = w->wqkv + (size_t)l * D * 3 * D;
         const float* bqkv = w->bqkv + (size_t)l * 3 * D;

@@ -363,7 +363,8 @@ __global__ void k_hardest_grad(const int32_t* __restrict__ where, int B, float* 
 }
 
 __global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, int32_t o_lo,
-                             int32_t* __restrict__ seg_ptr_local, int32_t* __restrict__ first) {
+                             int32_t* __restrict__ seg_ptr_local, int32_t* __restrict__ first, uint32_t* guard) {
+    if (guard != nullptr && blockIdx.x == 0 && threadIdx.x < G_SLOTS) guard[threadIdx.x] = 0u;  // new chunk: guard words start at 0
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= n_cells; c += gridDim.x * blockDim.x) {
         const int32_t lo = cell_ptr[c] - o_lo;
         seg_ptr_local[c] = lo;
@@ -374,8 +375,33 @@ __global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, 
     }
 }
 
+// fp16-range verdict of one chunk (t2p_common.h GuardSlot): bit 0..2 = SA level l may have staged relu(A_j - B_i) past
+// fp16's largest finite value, bit 3 = an SA output row (split by the next dense kernel) did, bit 4 = the GA hidden planes
+// may have (bound ||W1||_1 max(F_3, 1) + max|b1|), bit 5 = a row of the LDS-tiled GEMMs did
+__global__ void k_guard_check(const uint32_t* __restrict__ guard, int32_t* flag, float ga1_l1, float ga1_bmax) {
+    if (threadIdx.x != 0) return;
+    const float lim = 65504.f;
+    int code = 0;
+    for (int l = 0; l < 3; l++) {
+        // a word below kGuardFloor was never published: count it as the floor
+        const float a = fmaxf(__uint_as_float(guard[G_A1 + 2 * l]), kGuardFloor);
+        const float b = fmaxf(__uint_as_float(guard[G_B1 + 2 * l]), kGuardFloor);
+        if (!(a + b < lim)) code |= 1 << l;   // also catches inf patterns
+        if (!(__uint_as_float(guard[G_F1 + l]) < lim)) code |= 8;
+    }
+    if (!(fmaxf(__uint_as_float(guard[G_F3]), 1.f) * ga1_l1 + ga1_bmax < lim)) code |= 16;
+    if (!(__uint_as_float(guard[G_GEMM_IN]) < lim)) code |= 32;
+    if (code != 0) atomicOr(flag, code);
+}
 
 }  // namespace
+
+int launch_guard_check(const uint32_t* guard, int32_t* overflow_flag, float ga1_l1, float ga1_bmax, hipStream_t st) {
+    if (guard == nullptr || overflow_flag == nullptr) return 0;
+    hipLaunchKernelGGL(k_guard_check, dim3(1), dim3(64), 0, st, guard, overflow_flag, ga1_l1, ga1_bmax);
+    T2P_CHECK_LAUNCH("guard_check");
+    return 0;
+}
 
 int launch_rownorm(const float* in, int ld_in, int64_t n_rows, int dim, float* out, int ld_out, int col0,
                    hipStream_t st) {
@@ -453,10 +479,10 @@ int launch_hardest_ranking(const float* scores, int batch, float margin, float* 
 }
 
 int launch_cell_index(const int32_t* cell_ptr, int n_cells, int32_t o_lo, int32_t* seg_ptr_local, int32_t* first,
-                      hipStream_t st) {
+                      hipStream_t st, uint32_t* guard_to_clear) {
     ProfScope ps_("cell_index", st);
     hipLaunchKernelGGL(k_cell_index, dim3((unsigned)((n_cells + 1 + 255) / 256)), dim3(256), 0, st, cell_ptr, n_cells,
-                       o_lo, seg_ptr_local, first);
+                       o_lo, seg_ptr_local, first, guard_to_clear);
     T2P_CHECK_LAUNCH("cell_index");
     return 0;
 }
@@ -469,12 +495,7 @@ int launch_knn(const float* x, int dim, const int32_t* seg_ptr, int n_seg, int m
     T2P_CHECK_ARG(max_seg_rows >= 0 && max_seg_rows <= kMaxRows, "knn: a cell with %d objects exceeds the %d-row limit",
                   max_seg_rows, kMaxRows);
     size_t lds = (size_t)(max_seg_rows > 0 ? max_seg_rows : 1) * max_seg_rows * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_knn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(kMaxRows * kMaxRows * sizeof(float)));
-        attr_set = true;
-    }
+    T2P_TRY(reserve_lds((const void*)k_knn, (size_t)kMaxRows * kMaxRows * sizeof(float), "knn"));
     ProfScope ps_("knn", st);
     hipLaunchKernelGGL(k_knn, dim3(n_seg), dim3(256), lds, st, x, dim, seg_ptr, k, out_idx);
     T2P_CHECK_LAUNCH("knn");

@@ -42,6 +42,51 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 int num_cus();  // cached multiProcessorCount of the current device
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: set once per (device, kernel), under a
+// lock; returns 0 or the hipError_t (message kept for t2p_last_error)
+int reserve_lds(const void* kernel, size_t bytes, const char* what);
+
+// ---- fp16-range guard of the f16x3 path -------------------------------------------------------------------------
+// The split-precision path converts fp32 activations to fp16 (hi = fp16(v) toward zero: a value past 65504 would
+// SATURATE silently).  Every kernel that performs such a conversion reports the largest magnitude it converted into one
+// of these per-chunk device words (float bits, atomicMax on the unsigned pattern); k_guard_check turns them into the
+// caller's sticky overflow flag.  The SA edge kernels convert relu(A_j - B_i) and are covered by the bound
+// max|A_l| + max|B_l| taken where the tables are produced, so their inner loop carries no check.
+enum GuardSlot {
+    G_A1 = 0, G_B1 = 1, G_A2 = 2, G_B2 = 3, G_A3 = 4, G_B3 = 5,  // layer-1 point / centroid tables of the SA levels
+    G_F1 = 6, G_F2 = 7, G_F3 = 8,  // SA outputs F_l = the rows the dense weight-stationary kernels split on the fly; exact
+                                   // maxima, reported by the SA kernels (their xyz tail is bounded by 1).  GA layer 1's
+                                   // output (handed on as fp16 planes) is bounded by ||W||_1 max(F_3, 1) + max|b|
+    G_GEMM_IN = 9,    // rows split on the fly by the LDS-tiled f16x3 GEMM (f0, f1, cat, emb)
+    G_SLOTS = 16
+};
+// Magnitudes below kGuardFloor are never published (no atomic traffic in the normal case: activations of a trained,
+// batch-normalised network are O(1..100)); k_guard_check counts an unpublished word as kGuardFloor.
+constexpr float kGuardFloor = 16384.f;
+#ifdef __HIPCC__
+// m >= 0 (a magnitude; NaN compares false everywhere and is caught by the table producers' own inputs); at most one
+// atomic per wavefront, and only when some lane saw a magnitude at or above the floor
+__device__ __forceinline__ void guard_publish(uint32_t* slot, float m) {
+    if (slot == nullptr) return;
+    if (!__any(m >= kGuardFloor)) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+// Exact form for the persistent SA kernels: `acc` is a wave-uniform bit pattern (an SGPR) that lives across the whole
+// launch; guard_flush publishes it once per wave at the end (no floor, no contention: ~2 k atomics per launch).
+__device__ __forceinline__ void guard_track_bits(uint32_t& acc, int lane_bits /* pattern of a non-negative float */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(lane_bits, o, 64);
+        lane_bits = other > lane_bits ? other : lane_bits;
+    }
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(lane_bits);
+    acc = b > acc ? b : acc;
+}
+#endif
+// ga1_l1 = max over GA layer 1's output columns of sum_k |W[k][col]|, ga1_bmax = max |b| (host, packing.py)
+int launch_guard_check(const uint32_t* guard, int32_t* overflow_flag, float ga1_l1, float ga1_bmax, hipStream_t st);  // small_kernels.hip
 
 // Opt-in per-kernel timing (t2p_profile_enable): brackets a launch with hipEvents on the launch stream.
 struct ProfScope {
@@ -49,6 +94,7 @@ struct ProfScope {
     ~ProfScope();
     int slot;
     hipStream_t st;
+    void* ev_end;  // hipEvent_t recorded by the destructor
 };
 
 // ---- sample_group.hip -------------------------------------------------------------------------------------
@@ -77,6 +123,7 @@ struct GroupTables {
     const float* b1;
     const float* rgb;       // [n_obj][n_pts][3]
     int H1;
+    uint32_t* guard;        // nullptr, or the chunk's GuardSlot words: max|A_1|, max|B_l| are reported here
 };
 int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float radius[3], GroupTables gt,
                         hipStream_t st);
@@ -103,7 +150,7 @@ int launch_pairwise_ranking(const float* scores, int batch, float margin, float*
 int launch_hardest_ranking(const float* scores, int batch, float margin, float* best, int32_t* where, float* d_scores,
                            hipStream_t st);
 int launch_cell_index(const int32_t* cell_ptr, int n_cells, int32_t o_lo, int32_t* seg_ptr_local, int32_t* first,
-                      hipStream_t st);
+                      hipStream_t st, uint32_t* guard_to_clear = nullptr);
 
 // ---- tg_gemm.hip: generic tiled fp32-MFMA GEMM ------------------------------------------------------------
 // C[M, N] (ldc, column offset c0) = act(A[M, K] (lda) * W[K, N] (row-major, ldw = N) + bias[N])
@@ -111,7 +158,8 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
                 int K, int N, int relu, hipStream_t st, const float* resid = nullptr, int ldr = 0);
 // tg_gemm_x3.hip: the same contract on the f16x3 matrix path (W as the image of packing.py::pack_gemm_x3)
 int launch_gemm_x3(const float* A, int lda, const void* Wx, float scale, const float* bias, float* C, int ldc, int c0,
-                   int64_t M, int K, int N, int relu, hipStream_t st, const float* resid = nullptr, int ldr = 0);
+                   int64_t M, int K, int N, int relu, hipStream_t st, const float* resid = nullptr, int ldr = 0,
+                   uint32_t* amax_in = nullptr /* f16x3 guard word for the rows of A */);
 
 // ---- ws_gemm.hip: weight-stationary streaming fp32-MFMA kernels ---------------------------------------------
 enum WsMode { WS_DENSE_STORE = 0, WS_DENSE_GROUPMAX = 1, WS_EDGE_KNN = 3 };
@@ -135,6 +183,7 @@ struct WsParams {
     int64_t n_groups;  // dense: ceil(M / rows_per_group); edge SA: objects; edge kNN: ceil(n_dst/32)
     int64_t M;         // dense: total rows
     // edge kNN
+    uint32_t* amax_out;     // f16x3 guard (nullable): largest output magnitude (a table the SA kernels split, or fp16 planes)
     const int32_t* knn_idx; // [n_dst, knn_k] (-1 = absent)
     int knn_k;
     int64_t n_dst;
@@ -163,6 +212,7 @@ struct SaParams {
     int32_t* prefix_ws;      // [n_obj+1] scratch (tile prefix sums)
     int32_t* bounds_ws;      // [n_workgroups+1] scratch (balanced contiguous object ranges)
     int balanced;            // 1: bounds_ws was filled by launch_sa_balance_levels for this level's launch shape
+    uint32_t* amax_out;      // f16x3 guard (nullable): largest output magnitude (the next dense kernel splits these rows)
 };
 int launch_ws_sa(int H, int C, const SaParams& p, hipStream_t st);
 // One launch that balances all three levels (their row counts are known once k_sample_group has run); fills

@@ -34,7 +34,7 @@ __device__ __forceinline__ float sub_half(float v, fp16x2 h) {
 __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A, int lda, const _Float16* __restrict__ Wx,
                                                     int kp /*padded K of the image*/, float inv_scale,
                                                     const float* __restrict__ bias, float* C, int ldc, int c0, int64_t M,
-                                                    int K, int N, int relu, const float* R, int ldr) {
+                                                    int K, int N, int relu, const float* R, int ldr, uint32_t* amax_in) {
     extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
     // buffer b: [A hi | A lo | W hi | W lo], each [128][LDT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
     const _Float16* wl_ptr = Wlo + (size_t)(n0 + s_row) * kp + s_k;
     f32x4 ra[4];
     uint4 rwh[2], rwl[2];
+    float gmax = 0.f;  // fp16-range guard: largest |a| split to fp16 by this thread
 
     auto load_tile = [&](int k0) {
 #pragma unroll
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const f32x4 v = ra[i];
+            gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
             const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(v[0], h01), sub_half<1>(v[1], h01));
             const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(v[2], h23), sub_half<1>(v[3], h23));
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
         __syncthreads();
     }
 
+    if (blockIdx.y == 0) guard_publish(amax_in, gmax);  // every column block stages the same rows
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int col = n0 + wc * 64 + j * 32 + l31;
@@ -154,24 +157,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
 
 // Wx: image of pack_gemm_x3 ([2][N][kp] fp16, kp = K rounded up to 32, zero padded), scale = its power-of-two factor.
 int launch_gemm_x3(const float* A, int lda, const void* Wx, float scale, const float* bias, float* C, int ldc, int c0,
-                   int64_t M, int K, int N, int relu, hipStream_t st, const float* resid, int ldr) {
+                   int64_t M, int K, int N, int relu, hipStream_t st, const float* resid, int ldr, uint32_t* amax_in) {
     T2P_CHECK_ARG(K % 4 == 0 && N % 8 == 0 && lda % 4 == 0 && scale > 0.f, "gemm_x3: K=%d %% 4, N=%d %% 8, lda=%d %% 4", K, N, lda);
     T2P_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)Wx) & 15) == 0, "gemm_x3: A and W must be 16-byte aligned");
     if (M == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        if (e != hipSuccess) {
-            set_error("gemm_x3: cannot reserve %zu B of LDS: %s", kLds, hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    T2P_TRY(reserve_lds((const void*)k_gemm_x3, kLds, "gemm_x3"));
     const int kp = (K + 31) / 32 * 32;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     ProfScope ps_("tg_gemm_x3", st);
     hipLaunchKernelGGL(k_gemm_x3, grid, dim3(256), kLds, st, A, lda, (const _Float16*)Wx, kp, 1.0f / scale, bias, C, ldc, c0,
-                       M, K, N, relu, resid, ldr);
+                       M, K, N, relu, resid, ldr, amax_in);
     T2P_CHECK_LAUNCH("gemm_x3");
     return 0;
 }

@@ -121,6 +121,9 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
 #pragma unroll
     for (int nt = 0; nt < C::NTW; nt++) bias[nt] = p.bias ? p.bias[ncol0 + nt * 32 + l31] : 0.f;
 
+    // fp16-range guard (f16x3 only, t2p_common.h): the rows these kernels split while staging are SA outputs, whose
+    // magnitude the SA kernels report; here only the magnitude of the layer-1 point tables (A_2, A_3) is published, per
+    // batch, by the epilogue (guard_publish: one ballot, no atomic below the floor)
     f32x4 sa[C::ITERS];                  // staged source rows (in flight behind the MFMA block)
     f32x4 sb[C::EDGE ? C::ITERS : 1];    // staged destination terms (kNN edge mode)
 
@@ -287,6 +290,8 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
             if (gn < p.n_groups) stage_load(gn, 0, rows_of(gn));
             f32x16 acc[RT][C::NTW];
             mfma_block(i & 1, acc);
+            float gmax_out = 0.f;
+            (void)gmax_out;
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 const int trow0 = (wm * RT + rt) * 32;
@@ -302,6 +307,10 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                             const int r = trow0 + 4 * h + rr;
                             float v = acc[rt][nt][e];
                             if (p.relu) v = fmaxf(v, 0.f);
+                            // (rows past M hold the bias only).  Not for the split-output form (GA layer 1): that kernel sits
+                            // at the register limit with a store-bound epilogue (a running maximum cost 14 %); its output
+                            // is bounded from its input's magnitude instead (k_guard_check)
+                            if constexpr (X3 && SPLIT_IO != 2) gmax_out = fmaxf(gmax_out, fabsf(v));
                             if constexpr (SPLIT_IO == 2) {  // hand the activations on already split into fp16 hi / lo
                                 const fp16x2 hv = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
                                 const fp16x2 lv = __builtin_amdgcn_cvt_pkrtz((v - (float)hv[0]) * 2048.f, 0.f);
@@ -323,6 +332,7 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                     }
                 }
             }
+            if constexpr (X3 && MODE == WS_DENSE_STORE && SPLIT_IO != 2) guard_publish(p.amax_out, gmax_out);
             if (gn < p.n_groups) stage_write((i + 1) & 1);
             __syncthreads();
         }
@@ -439,16 +449,7 @@ template <int K, int NW, int WN, int RT, int MODE, int X3, int SPLIT_IO, int W8 
 int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
     using C = WsCfg<K, NW, WN, RT, MODE, X3, W8>;
     auto kern = k_ws<K, NW, WN, RT, MODE, X3, SPLIT_IO, W8>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)C::lds_bytes());
-        if (e != hipSuccess) {
-            set_error("ws_gemm: cannot reserve %zu B of LDS: %s", C::lds_bytes(), hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    T2P_TRY(reserve_lds((const void*)kern, C::lds_bytes(), "ws_gemm"));
     WsParams p = p_in;
     if (MODE != WS_EDGE_KNN) p.n_groups = (p.M + C::TR - 1) / C::TR;  // dense: one group = one batch of TR rows
     if (p.n_groups <= 0) return 0;

@@ -336,16 +336,7 @@ template <int K, int N, int WN, int RT>
 int launch_sa_cfg(const SaParams& p_in, hipStream_t st, const char* name) {
     using C = SaCfg<K, N, WN, RT>;
     auto kern = k_ws_sa<K, N, WN, RT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)C::lds_bytes());
-        if (e != hipSuccess) {
-            set_error("ws_sa: cannot reserve %zu B of LDS: %s", C::lds_bytes(), hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    T2P_TRY(reserve_lds((const void*)kern, C::lds_bytes(), "ws_sa"));
     if (p_in.n_obj <= 0) return 0;
     T2P_CHECK_ARG(p_in.n_obj < (1 << 30) && p_in.n_obj * p_in.n_dense < 0x7fffffffLL, "ws_sa: chunk too large for 32-bit rows");
     int n_wg = num_cus();

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
     }
 
     for (int i = tid; i < C::ACC_BUFS * C::ACC_INTS; i += NT) acc_lds[i] = 0;
+    uint32_t gbits = 0;  // fp16-range guard: wave-uniform maximum (bit pattern, before out_scale) of the drained outputs
 
     const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
     const int rgrp = (tid / C::F4_PER_ROW) * C::ITERS;  // first of this thread's 4 staged rows inside a batch
@@ -241,11 +242,16 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         auto flush = [&](int64_t g, int abuf) {
             int* a = acc_lds + abuf * C::ACC_INTS;
             float* o = p.out + g * nc * (int64_t)p.ldo;
+            int top = 0;  // fp16-range guard: the object's largest output (bit patterns of non-negative floats order like ints)
             for (int i = tid; i < nc * N; i += NT) {
                 const int c = i / N, col = i % N;
-                o[c * (int64_t)p.ldo + col] = __int_as_float(a[i]) * p.out_scale;  // weight image scale (power of 2)
+                const int bits = a[i];
+                top = bits > top ? bits : top;
+                o[c * (int64_t)p.ldo + col] = __int_as_float(bits) * p.out_scale;  // weight image scale (power of 2)
                 a[i] = 0;
             }
+            // the next dense kernel splits these rows to fp16: fold the magnitude into the wave's running maximum
+            guard_track_bits(gbits, top);
         };
 
         BatchIt it_c{0, 0, (int)nr[0], sbase[0]};
@@ -440,6 +446,8 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             if (flush_g1 >= 0) flush(flush_g1, flush_buf1);
         }
     }
+    if (p.amax_out != nullptr && lane == 0 && gbits != 0u)
+        atomicMax(p.amax_out, __float_as_uint(__uint_as_float(gbits) * p.out_scale));
 }
 
 template <int K, int N, int WN, int RT, int NW, int WGS>
@@ -448,16 +456,7 @@ int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
     static_assert(WGS == 1 || K <= 128, "two workgroups per CU rely on the deferred atomics (K <= 128)");
     static_assert(C::lds_bytes() * WGS <= 160 * 1024, "LDS budget");
     auto kern = k_ws_sa2<K, N, WN, RT, NW, WGS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)C::lds_bytes());
-        if (e != hipSuccess) {
-            set_error("ws_sa2: cannot reserve %zu B of LDS: %s", C::lds_bytes(), hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    T2P_TRY(reserve_lds((const void*)kern, C::lds_bytes(), "ws_sa2"));
     if (p.n_obj <= 0) return 0;
     T2P_CHECK_ARG(p.n_obj < (1 << 30) && p.n_obj * p.n_dense * (int64_t)K * 4 < 0xffffffffLL &&
                       p.n_obj * p.n_cent * (int64_t)K * 4 < 0xffffffffLL,

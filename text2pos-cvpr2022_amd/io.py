@@ -26,12 +26,49 @@ _DATA_CLASSES = {"Object3d": D.Object3d, "Cell": D.Cell, "Pose": D.Pose, "Descri
                  "DescriptionBestCell": D.DescriptionBestCell}
 
 
+# Globals a pickle may resolve here.  Unpickling executes whatever callable a file names, so neither loader resolves
+# anything outside this allowlist: containers and scalars of builtins, NumPy's array reconstruction, torch's tensor /
+# parameter rebuild helpers and its nn module classes.  (What remains trusted: torch's own rebuild functions and the
+# `__setstate__` of torch.nn modules; do not load checkpoints from sources you would not run code from.)
+_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex",
+                  "slice", "range", "object"}
+_NUMPY_MODULES = ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric")
+_NUMPY_NAMES = {"_reconstruct", "ndarray", "dtype", "scalar", "_frombuffer"}
+
+
+def _allowed_global(module: str, name: str, torch_ok: bool) -> bool:
+    module = {"__builtin__": "builtins", "copy_reg": "copyreg"}.get(module, module)   # protocol <= 2 spells them the py2 way
+    if module == "builtins":
+        return name in _SAFE_BUILTINS
+    if module == "collections":
+        return name in ("OrderedDict", "defaultdict")
+    if module == "copyreg":          # object reconstruction helpers of pickle protocols 0-2 (they instantiate a resolved class)
+        return name in ("_reconstructor", "__newobj__", "__newobj_ex__")
+    if module in _NUMPY_MODULES:
+        return name in _NUMPY_NAMES
+    if not torch_ok:
+        return False
+    if module == "torch._utils":
+        return name.startswith("_rebuild_")
+    if module == "torch":
+        return name.endswith("Storage") or name in ("Size", "device", "Tensor", "dtype", "float32", "float64", "int64")
+    if module == "torch.nn.parameter":
+        return name in ("Parameter", "Buffer")
+    return module.startswith("torch.nn.modules.") or module == "torch.storage" and name in ("TypedStorage", "UntypedStorage")
+
+
 class _SceneUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module in _DATA_MODULES:
             if name not in _DATA_CLASSES:
                 raise pickle.UnpicklingError(f"{module}.{name} is not a KITTI360Pose data class this package knows")
             return _DATA_CLASSES[name]
+        # scenes written by save_scene carry this package's own module path (under either of its import names)
+        if module in (D.__name__, "text2pos_amd.data", "text2pos-cvpr2022_amd.data") and name in _DATA_CLASSES:
+            return _DATA_CLASSES[name]
+        if not _allowed_global(module, name, torch_ok=False):
+            raise pickle.UnpicklingError(f"scene pickle names {module}.{name}, which is not on the allowlist of data classes, "
+                                         "containers and NumPy array helpers")
         return super().find_class(module, name)
 
 
@@ -102,14 +139,18 @@ _shells: Dict[str, type] = {}
 
 class _CheckpointUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
-            return super().find_class(module, name)
-        except (ImportError, AttributeError):
-            key = f"{module}.{name}"
-            if key not in _shells:
-                base = _DictShell if module.startswith("easydict") or name in ("Namespace", "EasyDict") else _Shell
-                _shells[key] = type(name, (base,), {"__module__": module})
-            return _shells[key]
+        if _allowed_global(module, name, torch_ok=True):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                pass
+        # everything else (the reference's models.*, torch_geometric.*, easydict, argparse.Namespace, ... - importable or
+        # not) becomes an inert shell: a bare nn.Module or a dict that keeps the state the pickle assigns
+        key = f"{module}.{name}"
+        if key not in _shells:
+            base = _DictShell if module.startswith("easydict") or name in ("Namespace", "EasyDict") else _Shell
+            _shells[key] = type(name, (base,), {"__module__": module})
+        return _shells[key]
 
 
 class _CheckpointPickle:
@@ -122,11 +163,20 @@ class _CheckpointPickle:
         return _CheckpointUnpickler(f, **kw).load()
 
 
-def load_reference_checkpoint(path: str) -> Dict[str, torch.Tensor]:
-    """Whole-module `.pth` of the reference (or a plain state_dict file) -> state_dict on the CPU."""
+def load_reference_checkpoint(path: str, return_args: bool = False):
+    """Whole-module `.pth` of the reference (or a plain state_dict file) -> state_dict on the CPU.
+    return_args: also return the training arguments pickled inside a whole-module checkpoint (`model.args`, an EasyDict in
+    the reference: embed_dim, use_features, variation, pointnet_features, class_embed, color_embed, num_layers, ...) as a
+    plain dict ({} for a bare state_dict).  The reference evaluates the pickled module itself, so it honours them
+    (evaluation/pipeline.py:313-314); a state_dict alone does not say whether e.g. --variation 1 was trained."""
     obj = torch.load(path, map_location="cpu", pickle_module=_CheckpointPickle, weights_only=False)
     if isinstance(obj, nn.Module):
-        return obj.state_dict()
-    if isinstance(obj, dict):
-        return obj
-    raise RuntimeError(f"{path}: neither a module nor a state_dict ({type(obj)})")
+        sd, a = obj.state_dict(), getattr(obj, "args", None)
+        args = dict(a) if isinstance(a, dict) else dict(getattr(a, "__dict__", {}) or {})
+        if isinstance(a, dict):
+            args.update({k: v for k, v in getattr(a, "__dict__", {}).items() if not k.startswith("_")})
+    elif isinstance(obj, dict):
+        sd, args = obj, {}
+    else:
+        raise RuntimeError(f"{path}: neither a module nor a state_dict ({type(obj)})")
+    return (sd, args) if return_args else sd

@@ -131,8 +131,10 @@ def sim_topk(queries: torch.Tensor, cells: torch.Tensor, k: int, index_offset: i
 # ---------------------------------------------------------------------------------------------------------------
 def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features=("class", "color", "position"),
                      self_loops=True, knn_k=8, variation=0, radius=(0.2, 0.3, 0.4), chunk_objects=0,
-                     precision="f16x3", class_idx=None, color_idx=None, objects_only=False) -> L.CellConfig:
-    """class_idx / color_idx: int32 device tensors [n_obj] enabling the --class_embed / --color_embed ablations."""
+                     precision="f16x3", class_idx=None, color_idx=None, objects_only=False,
+                     overflow_flag=None) -> L.CellConfig:
+    """class_idx / color_idx: int32 device tensors [n_obj] enabling the --class_embed / --color_embed ablations.
+    overflow_flag: int32 device tensor [1], the sticky fp16-range guard word of the f16x3 path (include/t2p.h)."""
     cfg = L.CellConfig()
     cfg.n_pts, cfg.embed_dim, cfg.pointnet_features = int(n_pts), int(embed_dim), int(pointnet_features)
     cfg.use_class = int("class" in use_features)
@@ -150,7 +152,10 @@ def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features
             _need(t, name + "_idx", torch.int32, 1)
             setattr(cfg, name + "_embed", 1)
             setattr(cfg, name + "_idx", t.data_ptr())
-    cfg._keepalive = (class_idx, color_idx)
+    if overflow_flag is not None:
+        _need(overflow_flag, "overflow_flag", torch.int32, 1)
+        cfg.overflow_flag = overflow_flag.data_ptr()
+    cfg._keepalive = (class_idx, color_idx, overflow_flag)
     return cfg
 
 
@@ -190,6 +195,8 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
         if g is not None:
             _need(g, name, torch.int16)
             setattr(w, name, g.data_ptr())
+    if packed.get("ga_w1_l1") is not None:
+        w.ga_w1_l1, w.ga_b1_absmax = float(packed["ga_w1_l1"]), float(packed["ga_b1_absmax"])
     for name in ("class_embedding", "color_embedding"):
         t = packed.get(name)
         if t is not None:
@@ -199,8 +206,9 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
 
 
 def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr_dev, weights: L.CellWeights,
-                 cfg: L.CellConfig, want_trace: bool = False):
-    """Cell branch on packed, device-resident inputs.  Returns out [n_cells, D] (and a dict of stage outputs)."""
+                 cfg: L.CellConfig, want_trace=False):
+    """Cell branch on packed, device-resident inputs.  Returns out [n_cells, D] (and a dict of stage outputs when
+    want_trace is True or names some of them; knn_idx rows are local to the internal chunk of <= chunk_objects objects)."""
     _need(xyz, "xyz", torch.float32, 3)
     dev = xyz.device
     _need(rgb, "rgb", torch.float32, 3, dev)
@@ -231,24 +239,33 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
         obj_emb = torch.empty((n_obj, D), dtype=torch.float32, device=dev)
         tr.obj_emb = obj_emb.data_ptr()
     elif want_trace:
+        # want_trace: True = every stage output, or an iterable of names (the full set is ~130 KB per object)
+        names = set(("fps_idx", "nbr", "cnt", "sa_out", "features0", "features1", "features2", "obj_emb", "knn_idx")
+                    if want_trace is True else want_trace)
+        unknown = names - {"fps_idx", "nbr", "cnt", "sa_out", "features0", "features1", "features2", "obj_emb", "knn_idx"}
+        if unknown:
+            raise RuntimeError(f"encode_cells: unknown trace outputs {sorted(unknown)}")
         tr = L.CellTrace()
-        trace = dict(fps_idx=[], nbr=[], cnt=[], sa_out=[])
-        nd = n_pts
-        for l, c in enumerate((64, 128, 256)):
+        trace = {}
+        shapes, nd = [], n_pts
+        for c in (64, 128, 256):
             nc = (nd + 1) // 2
-            trace["fps_idx"].append(torch.empty((n_obj, nc), dtype=torch.uint8, device=dev))
-            trace["nbr"].append(torch.empty((n_obj, nc, 32), dtype=torch.uint8, device=dev))
-            trace["cnt"].append(torch.empty((n_obj, nc), dtype=torch.uint8, device=dev))
-            trace["sa_out"].append(torch.empty((n_obj * nc, c + 32), dtype=torch.float32, device=dev))
+            shapes.append((nc, c))
             nd = nc
-        trace["features0"] = torch.empty((n_obj, 1024), dtype=torch.float32, device=dev)
-        trace["features2"] = torch.empty((n_obj, 256), dtype=torch.float32, device=dev)
-        trace["obj_emb"] = torch.empty((n_obj, D), dtype=torch.float32, device=dev)
-        trace["knn_idx"] = torch.empty((n_obj, cfg.knn_k), dtype=torch.int32, device=dev)
-        for name in ("fps_idx", "nbr", "cnt", "sa_out"):
-            setattr(tr, name, (C.c_void_p * 3)(*[t.data_ptr() for t in trace[name]]))
-        for name in ("features0", "features2", "obj_emb", "knn_idx"):
-            setattr(tr, name, trace[name].data_ptr())
+        per_level = {"fps_idx": lambda nc, c: ((n_obj, nc), torch.uint8), "nbr": lambda nc, c: ((n_obj, nc, 32), torch.uint8),
+                     "cnt": lambda nc, c: ((n_obj, nc), torch.uint8),
+                     "sa_out": lambda nc, c: ((n_obj * nc, c + 32), torch.float32)}
+        for name, fn in per_level.items():
+            if name in names:
+                trace[name] = [torch.empty(fn(nc, c)[0], dtype=fn(nc, c)[1], device=dev) for nc, c in shapes]
+                setattr(tr, name, (C.c_void_p * 3)(*[t.data_ptr() for t in trace[name]]))
+        flat = {"features0": ((n_obj, 1024), torch.float32), "features1": ((n_obj, 512), torch.float32),
+                "features2": ((n_obj, 256), torch.float32), "obj_emb": ((n_obj, D), torch.float32),
+                "knn_idx": ((n_obj, cfg.knn_k), torch.int32)}
+        for name, (shape, dt) in flat.items():
+            if name in names:
+                trace[name] = torch.empty(shape, dtype=dt, device=dev)
+                setattr(tr, name, trace[name].data_ptr())
     nbytes = L.lib().t2p_encode_cells_workspace_bytes(n_obj, n_cells, C.byref(cfg))
     # a single cell larger than the chunk forms its own (bigger) chunk: size for it
     biggest = int((cp[1:] - cp[:-1]).max()) if n_cells > 0 else 0

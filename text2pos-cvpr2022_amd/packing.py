@@ -38,6 +38,17 @@ def f32(b: torch.Tensor) -> torch.Tensor:
     return b.float().contiguous()
 
 
+class Fp16RangeError(ValueError):
+    """A folded weight cannot be represented by the f16x3 split (|w| past fp16's range): use precision="fp32"."""
+
+
+def _check_fp16_range(w: torch.Tensor, what: str):
+    m = float(w.detach().abs().max()) if w.numel() else 0.0
+    if not np.isfinite(m) or m > 65504.0:
+        raise Fp16RangeError(f"{what}: max |w| = {m:g} does not fit the f16x3 weight image (fp16 range 65504); "
+                             "construct the model with precision=\"fp32\"")
+
+
 def pack_f16x3(w_kmajor: torch.Tensor) -> torch.Tensor:
     """fp32 [K][N] k-major weights -> int16 [2][N/32][K/16][2][32][8]: the f16x3 split w = hi + lo/2048 (hi, lo fp16,
     round-to-nearest) laid out exactly as the MFMA B-operand registers of csrc/ws_sa.hip / ws_gemm.hip read it:
@@ -45,6 +56,7 @@ def pack_f16x3(w_kmajor: torch.Tensor) -> torch.Tensor:
     k, n = w_kmajor.shape
     assert k % 32 == 0 and n % 32 == 0, (k, n)
     w = w_kmajor.detach().float().cpu()
+    _check_fp16_range(w, "pack_f16x3")
     hi = w.to(torch.float16)
     lo = ((w - hi.float()) * 2048.0).to(torch.float16)
     planes = []
@@ -71,6 +83,7 @@ def pack_f16x3_scaled(w_kmajor: torch.Tensor, scale: float) -> torch.Tensor:
     k, n = w_kmajor.shape
     assert k % 32 == 0 and n % 32 == 0, (k, n)
     w = w_kmajor.detach().double().cpu() * scale
+    _check_fp16_range(w, "pack_f16x3_scaled")
     hi = w.to(torch.float16)
     lo = (w - hi.double()).to(torch.float16)
     planes = [t.view(2, k // 16, 8, n // 32, 32).permute(3, 1, 0, 4, 2).contiguous() for t in (hi, lo)]
@@ -85,14 +98,39 @@ def pack_gemm_x3(w_kmajor: torch.Tensor, scale: float) -> torch.Tensor:
     kp = (k + 31) // 32 * 32
     w = torch.zeros((n, kp), dtype=torch.float64)
     w[:, :k] = w_kmajor.detach().double().cpu().t() * scale
+    _check_fp16_range(w, "pack_gemm_x3")
     hi = w.to(torch.float16)
     lo = (w - hi.double()).to(torch.float16)
     return torch.stack([hi, lo]).view(torch.int16).contiguous()
 
 
-def pack_cell_weights(model, device) -> Dict[str, object]:
+def pack_cell_weights(model, device, x3: bool = True) -> Dict[str, object]:
     """model: CellRetrievalNetwork or SuperGlueMatch (this package; the latter has no cell head).  Returns name -> fp32
-    device tensor(s) for ops.make_cell_weights."""
+    device tensor(s) for ops.make_cell_weights.  x3=False leaves the f16x3 images out (precision="fp32": weights outside
+    fp16's range are then fine)."""
+    p = _pack_cell_weights_fp32(model, device)
+    if x3:
+        _add_x3_images(p, device, hasattr(model, "graph1"))
+    return p
+
+
+def _add_x3_images(p: Dict[str, object], device, cell_head: bool):
+    scales = [f16x3_scale(t) for t in p["sa_w2"]]
+    p["sa_w2_scale"] = scales
+    p["sa_w2_x3"] = [pack_f16x3_scaled(t, sc).to(device) for t, sc in zip(p["sa_w2"], scales)]
+    p["sa_b2_x3"] = [f32(b.double() * sc).to(device) for b, sc in zip(p["sa_b2"], scales)]
+    p["sa_w1_x3"] = [None] + [pack_f16x3(t).to(device) for t in p["sa_w1"][1:]]
+    p.update(ga_w1_x3=pack_f16x3(p["ga_w1"]).to(device), ga_w2_x3=pack_f16x3(p["ga_w2"]).to(device))
+    # fp16-range guard: GA layer 1's output is bounded by ||W||_1 (largest column sum of |w|) * max|input| + max|b|
+    p["ga_w1_l1"] = float(p["ga_w1"].double().abs().sum(0).max())
+    p["ga_b1_absmax"] = float(p["ga_b1"].double().abs().max())
+    for name, src in (("lin1", "lin1_w"), ("lin2", "lin2_w"), ("pn", "pn_w"), ("merge", "merge_w")) + \
+            ((("g_wp", "g_wp"), ("g_wq", "g_wq")) if cell_head else ()):
+        sc = f16x3_scale(p[src])
+        p[name + "_scale"], p[name + "_x3"] = sc, pack_gemm_x3(p[src], sc).to(device)
+
+
+def _pack_cell_weights_fp32(model, device) -> Dict[str, object]:
     oe, pn = model.object_encoder, model.object_encoder.pointnet
     p: Dict[str, object] = {}
     sa_w1, sa_b1, sa_w2, sa_b2 = [], [], [], []
@@ -105,26 +143,15 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
         sa_w2.append(kmajor(w2).to(device))
         sa_b2.append(f32(b2).to(device))
     p.update(sa_w1=sa_w1, sa_b1=sa_b1, sa_w2=sa_w2, sa_b2=sa_b2)
-    scales = [f16x3_scale(t) for t in sa_w2]
-    p["sa_w2_scale"] = scales
-    p["sa_w2_x3"] = [pack_f16x3_scaled(t, sc).to(device) for t, sc in zip(sa_w2, scales)]
-    p["sa_b2_x3"] = [f32(b.double() * sc).to(device) for b, sc in zip(sa_b2, scales)]
-    p["sa_w1_x3"] = [None] + [pack_f16x3(t).to(device) for t in sa_w1[1:]]
     w1, b1 = fold_linear_bn(pn.ga.mlp[0])
     w2, b2 = fold_linear_bn(pn.ga.mlp[1])
     p.update(ga_w1=kmajor(w1, 288).to(device), ga_b1=f32(b1).to(device), ga_w2=kmajor(w2).to(device),
              ga_b2=f32(b2).to(device))
-    p.update(ga_w1_x3=pack_f16x3(p["ga_w1"]).to(device), ga_w2_x3=pack_f16x3(p["ga_w2"]).to(device))
     for name, lin in (("lin1", pn.lin1), ("lin2", pn.lin2)):
         p[name + "_w"] = kmajor(lin.weight.detach().double()).to(device)
         p[name + "_b"] = f32(lin.bias.detach().double()).to(device)
-    for name in ("lin1", "lin2"):
-        sc = f16x3_scale(p[name + "_w"])
-        p[name + "_scale"], p[name + "_x3"] = sc, pack_gemm_x3(p[name + "_w"], sc).to(device)
     w, b = fold_linear_bn(oe.mlp_pointnet[0])
     p.update(pn_w=kmajor(w).to(device), pn_b=f32(b).to(device))
-    p["pn_scale"] = f16x3_scale(p["pn_w"])
-    p["pn_x3"] = pack_gemm_x3(p["pn_w"], p["pn_scale"]).to(device)
     for pre, enc in (("col", oe.color_encoder), ("pos", oe.pos_encoder)):
         w1, b1 = fold_linear_bn(enc[0])
         w2, b2 = fold_linear_bn(enc[1])
@@ -132,8 +159,6 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
         p[pre + "_w2"], p[pre + "_b2"] = kmajor(w2).to(device), f32(b2).to(device)
     w, b = fold_linear_bn(oe.mlp_merge[0])
     p.update(merge_w=kmajor(w).to(device), merge_b=f32(b).to(device))
-    p["merge_scale"] = f16x3_scale(p["merge_w"])
-    p["merge_x3"] = pack_gemm_x3(p["merge_w"], p["merge_scale"]).to(device)
     p.update(class_embedding=f32(oe.class_embedding.weight.detach()).to(device),
              color_embedding=f32(oe.color_embedding.weight.detach()).to(device))
     if not hasattr(model, "graph1"):  # fine stage: ObjectEncoder only
@@ -144,9 +169,6 @@ def pack_cell_weights(model, device) -> Dict[str, object]:
     w2, b2 = fold_linear_bn(model.graph1.nn[1])
     p.update(g_wp=kmajor(w1[:, :d] - w1[:, d:]).to(device), g_bp=f32(b1).to(device), g_wq=kmajor(w1[:, d:]).to(device),
              g_w2=kmajor(w2).to(device), g_b2=f32(b2).to(device))
-    for name in ("g_wp", "g_wq"):
-        p[name + "_scale"] = f16x3_scale(p[name])
-        p[name + "_x3"] = pack_gemm_x3(p[name], p[name + "_scale"]).to(device)
     w1, b1 = fold_linear_bn(model.lin[0])
     w2, b2 = fold_linear_bn(model.lin[1])
     p.update(lin_w1=kmajor(w1).to(device), lin_b1=f32(b1).to(device), lin_w2=kmajor(w2).to(device),

@@ -74,6 +74,26 @@ def _model_args(embed_dim, num_layers=6, sinkhorn_iters=50, use_features=("class
                            sinkhorn_iters=sinkhorn_iters)
 
 
+_ARCH_KEYS = ("embed_dim", "use_features", "variation", "class_embed", "color_embed", "pointnet_features", "num_layers",
+              "sinkhorn_iters", "pointnet_numpoints")
+
+
+def args_from_checkpoint(cli_args: SimpleNamespace, ckpt_args: dict, what: str) -> SimpleNamespace:
+    """The architecture switches a state_dict cannot express (variation 0 / 1 share every key; so do use_features subsets
+    of equal size) come from the arguments pickled inside the reference's whole-module checkpoint, which is what the
+    reference evaluates with (evaluation/pipeline.py:313-314).  Values present in the checkpoint win over the command
+    line; a difference is reported."""
+    a = SimpleNamespace(**vars(cli_args))
+    for k in _ARCH_KEYS:
+        if k in ckpt_args and ckpt_args[k] is not None:
+            v = ckpt_args[k]
+            v = list(v) if k == "use_features" else v
+            if hasattr(a, k) and getattr(a, k) != v:
+                print(f"[{what}] checkpoint was trained with {k}={v!r} (command line / default: {getattr(a, k)!r}): using the checkpoint's")
+            setattr(a, k, v)
+    return a
+
+
 def main(argv: Optional[List[str]] = None):
     from . import CellRetrievalNetwork, SuperGlueMatch
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
@@ -95,16 +115,19 @@ def main(argv: Optional[List[str]] = None):
     print(f"{len(scenes.all_cells)} cells, {len(scenes.all_poses)} poses from {a.scenes}")
     words, classes = scenes.get_known_words(), scenes.get_known_classes()
     dev = torch.device("cuda", 0)
-    coarse = CellRetrievalNetwork(classes, D.COLOR_NAMES, words, _model_args(a.coarse_embed_dim, use_features=a.use_features))
-    coarse.load_state_dict(IO.load_reference_checkpoint(a.path_coarse))
+    sd, ck = IO.load_reference_checkpoint(a.path_coarse, return_args=True)
+    ca = args_from_checkpoint(_model_args(a.coarse_embed_dim, use_features=a.use_features), ck, "coarse")
+    coarse = CellRetrievalNetwork(classes, D.COLOR_NAMES, words, ca)
+    coarse.load_state_dict(sd)
     coarse = coarse.to(dev).eval()
-    fine = None
+    fine, n_pts = None, int(getattr(ca, "pointnet_numpoints", 256))
     if a.path_fine:
-        fine = SuperGlueMatch(classes, D.COLOR_NAMES, words, _model_args(a.fine_embed_dim, a.fine_num_layers, a.sinkhorn_iters,
-                                                                          a.use_features))
-        fine.load_state_dict(IO.load_reference_checkpoint(a.path_fine))
+        sd, ck = IO.load_reference_checkpoint(a.path_fine, return_args=True)
+        fa = args_from_checkpoint(_model_args(a.fine_embed_dim, a.fine_num_layers, a.sinkhorn_iters, a.use_features), ck, "fine")
+        fine = SuperGlueMatch(classes, D.COLOR_NAMES, words, fa)
+        fine.load_state_dict(sd)
         fine = fine.to(dev).eval()
-    out = evaluate(coarse, fine, scenes, default_transform(256, a.seed), a.top_k, a.threshs, a.pad_size)
+    out = evaluate(coarse, fine, scenes, default_transform(n_pts, a.seed), a.top_k, a.threshs, a.pad_size)
     print("Retrieval accuracies (hit@k):", out["hit"], " close-by@k:", out["close"])
     print("Coarse (cell centre):")
     E.print_accuracies(out["localisation"])

@@ -92,14 +92,25 @@ class SuperGlueMatch(nn.Module):
         self._opack = None
         self._mpack = None
         self._side = None
+        self._overflow = None   # fp16-range guard word of the object encoder's f16x3 calls (include/t2p.h)
 
     # ---- cached weight images -------------------------------------------------------------------------------------
     def _object_pack(self):
         ver = (packing.params_version(self.object_encoder), str(self.device))
         if self._opack is None or self._opack[0] != ver:
-            tensors = packing.pack_cell_weights(self, self.device)
+            tensors = packing.pack_cell_weights(self, self.device, x3=self.precision == "f16x3")
             self._opack = (ver, tensors, ops.make_cell_weights(tensors))
         return self._opack[2]
+
+    def overflow_detected(self) -> int:
+        """Reads (synchronises) and clears the fp16-range guard word of the object encoder (f16x3 only); non-zero = the
+        outputs since the last check must not be used: construct the model with precision="fp32"."""
+        if self._overflow is None:
+            return 0
+        code = int(self._overflow.item())
+        if code:
+            self._overflow.zero_()
+        return code
 
     def _match_pack(self):
         ver = (packing.params_version(self.superglue), packing.params_version(self.mlp_offsets), str(self.device))
@@ -115,7 +126,8 @@ class SuperGlueMatch(nn.Module):
             raise NotImplementedError("the HIP path is forward-only; call it under torch.no_grad()")
 
     # ---- forward ----------------------------------------------------------------------------------------------------
-    def forward_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, hints, class_idx=None, color_idx=None):
+    def forward_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, hints, class_idx=None, color_idx=None,
+                       check_overflow=True):
         """Device-resident packed objects (see CellRetrievalNetwork.encode_objects_packed); every sample must hold the
         same number of objects (the dataset pads to args.pad_size, dataloading/kitti360pose/eval.py:147-149) and the
         same number of hints.  hints: List[List[str]], or pre-tokenised (tokens int32 [B * num_hints, T],
@@ -144,6 +156,10 @@ class SuperGlueMatch(nn.Module):
                                    radius=self.object_encoder.pointnet.radii, precision=self.precision,
                                    class_idx=class_idx, color_idx=color_idx, objects_only=True)
         dev = self.device
+        if self.precision == "f16x3":
+            if self._overflow is None or self._overflow.device != dev:
+                self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+            cfg.overflow_flag = self._overflow.data_ptr()
         # the hint sentences do not depend on the objects: their (latency-bound) biLSTM runs on a second HIP stream
         # underneath the object encoder
         main = torch.cuda.current_stream(dev)
@@ -161,6 +177,9 @@ class SuperGlueMatch(nn.Module):
         main.wait_stream(self._side)
         hint.record_stream(main)
         out = ops.match(obj.contiguous(), hint.contiguous(), self._match_pack(), self.sinkhorn_iters, MATCH_THRESHOLD)
+        if check_overflow and self.overflow_detected():
+            raise FloatingPointError("f16x3 path: an object-encoder activation left fp16's range; construct the model "
+                                     "with precision=\"fp32\"")
         return MatchOutputs(P=out["P"], matches0=out["matches0"], matches1=out["matches1"], offsets=out["offsets"],
                             matching_scores0=out["matching_scores0"], matching_scores1=out["matching_scores1"],
                             object_encodings=obj, hint_encodings=hint)

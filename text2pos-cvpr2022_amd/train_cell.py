@@ -31,10 +31,11 @@ def _ptr_from_counts(counts):
     return _i32(torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]))
 
 
-def _mlp_train(x, mlp, seg_ptr):
-    """get_mlp block list (Linear, BatchNorm1d, ReLU) in training mode; statistics per row segment."""
+def _mlp_train(x, mlp, seg_ptr, rows_min):
+    """get_mlp block list (Linear, BatchNorm1d, ReLU) in training mode; statistics per row segment.  rows_min: the
+    smallest segment's row count (known on the host); a single-row segment raises as nn.BatchNorm1d does."""
     for blk in mlp:
-        x = TO.bn_relu_train(TO.linear(x, blk[0]), seg_ptr, blk[1], relu=True)
+        x = TO.bn_relu_train(TO.linear(x, blk[0]), seg_ptr, blk[1], relu=True, rows_min=rows_min)
     return x
 
 
@@ -80,9 +81,9 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
     one = lambda n: torch.tensor([0, n], dtype=torch.int32, device=dev)
 
     parts = []
-    if "class" in a.use_features and class_embed:               # models/object_encoder.py:103-109: no PointNet++ at all
-        parts.append(TO.normalize(oe.class_embedding(class_idx.long())))
-    elif "class" in a.use_features:
+
+    def pointnet_branch():
+        """models/object_encoder.py:86-98: the PointNet++ (one call per cell) + mlp_pointnet."""
         gt = ops.sample_group(xyz.contiguous(), pn.radii)
         pos = xyz.reshape(n_obj * n_pts, 3)
         x = rgb.reshape(n_obj * n_pts, 3)
@@ -97,21 +98,31 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
             cent_ptr = _ptr_from_counts(torch.bincount(dst, minlength=n_obj * nc))
             cell_edge_ptr = _ptr_from_counts(torch.bincount(cell_of_obj[dst // nc], minlength=n_cells))
             msg = TO.edge_features(x, pos, pos_c, _i32(src), _i32(dst))
-            h = _mlp_train(msg, sa.point_conv.local_nn, cell_edge_ptr)
+            h = _mlp_train(msg, sa.point_conv.local_nn, cell_edge_ptr, nc)    # >= one self loop / hit per centroid
             x, pos, nd = TO.segment_max(h, cent_ptr), pos_c, nc
-        h = _mlp_train(torch.cat([x, pos], dim=1), pn.ga.mlp, _i32(cell_ptr_dev.long() * nd))
+        h = _mlp_train(torch.cat([x, pos], dim=1), pn.ga.mlp, _i32(cell_ptr_dev.long() * nd), nd)
         f0 = TO.segment_max(h, _i32(torch.arange(n_obj + 1, device=dev) * nd))
         f1 = torch.relu(TO.linear(f0, pn.lin1))
         f2 = torch.relu(TO.linear(f1, pn.lin2))
         feats = (f0, f1, f2)[a.pointnet_features]
-        parts.append(TO.normalize(_mlp_train(feats, oe.mlp_pointnet, one(n_obj))))
+        return _mlp_train(feats, oe.mlp_pointnet, one(n_obj), n_obj)
+
+    if "class" in a.use_features and class_embed:               # models/object_encoder.py:103-109: no PointNet++ at all
+        parts.append(TO.normalize(oe.class_embedding(class_idx.long())))
+    elif "class" in a.use_features:
+        parts.append(TO.normalize(pointnet_branch()))
+    elif not class_embed:
+        # the reference runs the PointNet++ whenever class_embed is off (models/object_encoder.py:86-98) and only then
+        # decides whether the result is a feature: in train() mode its BatchNorm running statistics still move
+        with torch.no_grad():
+            pointnet_branch()
     if "color" in a.use_features and color_embed:               # models/object_encoder.py:112-120
         parts.append(TO.normalize(oe.color_embedding(color_idx.long())))
     elif "color" in a.use_features:
-        parts.append(TO.normalize(_mlp_train(mean_rgb.float(), oe.color_encoder, one(n_obj))))
+        parts.append(TO.normalize(_mlp_train(mean_rgb.float(), oe.color_encoder, one(n_obj), n_obj)))
     if "position" in a.use_features:
-        parts.append(TO.normalize(_mlp_train(center.float(), oe.pos_encoder, one(n_obj))))
-    emb = _mlp_train(torch.cat(parts, dim=-1), oe.mlp_merge, one(n_obj)) if len(parts) > 1 else parts[0]
+        parts.append(TO.normalize(_mlp_train(center.float(), oe.pos_encoder, one(n_obj), n_obj)))
+    emb = _mlp_train(torch.cat(parts, dim=-1), oe.mlp_merge, one(n_obj), n_obj) if len(parts) > 1 else parts[0]
     emb = TO.normalize(emb)
 
     # DynamicEdgeConv(k = 8, max) inside each cell (models/cell_retrieval.py:46-48, :97), pool, lin, normalize (:98-106)
@@ -121,8 +132,8 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
     tgt = torch.arange(n_obj, device=dev)[:, None].expand(-1, k)[valid]
     srcn = knn[valid].long()
     msg = TO.pair_features(emb, _i32(tgt), _i32(srcn))
-    h = _mlp_train(msg, model.graph1.nn, one(msg.shape[0]))
+    h = _mlp_train(msg, model.graph1.nn, one(msg.shape[0]), int(msg.shape[0]))
     pool = TO.segment_max if model.variation == 0 else TO.segment_mean    # models/cell_retrieval.py:46-54, :98-103
     xg = pool(h, _ptr_from_counts(valid.sum(1)))
     xc = pool(xg, cell_ptr_dev)
-    return TO.normalize(_mlp_train(xc, model.lin, one(n_cells)))
+    return TO.normalize(_mlp_train(xc, model.lin, one(n_cells), n_cells))

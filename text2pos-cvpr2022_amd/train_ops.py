@@ -51,20 +51,33 @@ class _BnReluTrainFn(torch.autograd.Function):
         return dx, None, dg.sum(0), db.sum(0), None, None
 
 
-def bn_relu_train(x, seg_ptr, bn: torch.nn.BatchNorm1d, relu: bool = True):
+def bn_relu_train(x, seg_ptr, bn: torch.nn.BatchNorm1d, relu: bool = True, rows_min: int = None):
     """BatchNorm1d in training mode (+ ReLU) over the row segments seg_ptr [S+1] int32 (device), statistics per segment.
     Updates bn.running_mean / running_var / num_batches_tracked once per segment, in order, exactly as S consecutive
-    calls of the module would (momentum bn.momentum, unbiased variance)."""
+    calls of the module would (momentum bn.momentum - None = cumulative average, as in torch -, unbiased variance).
+    rows_min: the smallest segment's row count when the caller knows it on the host (otherwise it is read back from
+    seg_ptr); like nn.BatchNorm1d, a segment with a single row is refused in training mode."""
+    if rows_min is None:
+        rows_min = int((seg_ptr[1:] - seg_ptr[:-1]).min().item()) if seg_ptr.numel() > 1 else 2
+    if rows_min <= 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got a segment of {rows_min} row(s) "
+                         f"x {x.shape[1]} channels")     # torch.nn.functional._verify_batch_size
     y, mean, var_u = _BnReluTrainFn.apply(x.contiguous(), seg_ptr, bn.weight, bn.bias, bn.eps, relu)
     if bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
-            mom = bn.momentum if bn.momentum is not None else 0.1
             s = mean.shape[0]
-            # r <- (1 - m) r + m stat, S times: closed form with weights m (1 - m)^(S-1-k)
-            w = mom * (1.0 - mom) ** torch.arange(s - 1, -1, -1, device=mean.device, dtype=torch.float32)
-            keep = (1.0 - mom) ** s
-            bn.running_mean.mul_(keep).add_((w[:, None] * mean).sum(0))
-            bn.running_var.mul_(keep).add_((w[:, None] * var_u).sum(0))
+            if bn.momentum is None:
+                # cumulative moving average: the k-th call uses factor 1 / (n0 + k); S calls in closed form
+                n0 = float(bn.num_batches_tracked.item())
+                bn.running_mean.mul_(n0 / (n0 + s)).add_(mean.sum(0) / (n0 + s))
+                bn.running_var.mul_(n0 / (n0 + s)).add_(var_u.sum(0) / (n0 + s))
+            else:
+                mom = float(bn.momentum)
+                # r <- (1 - m) r + m stat, S times: closed form with weights m (1 - m)^(S-1-k)
+                w = mom * (1.0 - mom) ** torch.arange(s - 1, -1, -1, device=mean.device, dtype=torch.float32)
+                keep = (1.0 - mom) ** s
+                bn.running_mean.mul_(keep).add_((w[:, None] * mean).sum(0))
+                bn.running_var.mul_(keep).add_((w[:, None] * var_u).sum(0))
             bn.num_batches_tracked += s
     return y
 
@@ -208,14 +221,19 @@ class _LinearFn(torch.autograd.Function):
         wp = torch.nn.functional.pad(weight.detach(), (0, pad)).contiguous() if pad else weight.detach().contiguous()
         ctx.save_for_backward(xp, wp)
         ctx.k = k
+        ctx.has_bias = bias is not None
         return ops.gemm(xp, wp.t().contiguous(), bias.detach().contiguous() if bias is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
         xp, wp = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = ops.gemm(dy, wp)                              # [M, N] x [N, K]: the weight is its own k-major operand
-        return dx[:, : ctx.k], (dy.t() @ xp)[:, : ctx.k], dy.sum(0)
+        need_x, need_w, need_b = ctx.needs_input_grad
+        # [M, N] x [N, K]: the weight is its own k-major operand
+        dx = ops.gemm(dy, wp)[:, : ctx.k] if need_x else None
+        dw = (dy.t() @ xp)[:, : ctx.k] if need_w else None       # frozen layers (--pointnet_freeze) skip the reductions
+        db = dy.sum(0) if (need_b and ctx.has_bias) else None
+        return dx, dw, db
 
 
 def linear(x, lin: torch.nn.Linear):
