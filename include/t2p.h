@@ -121,6 +121,13 @@ typedef struct t2p_cell_weights {
      * and ga_b1_absmax = max |ga_b1| (that kernel's epilogue is too tight for a running maximum of its own). */
     float ga_w1_l1;
     float ga_b1_absmax;
+    /* the same kind of bound for the layer-1 tables that depend on the inputs only: sa_wp_l1[l] = max over columns of
+     * |W1p_l[0][c]| + |W1p_l[1][c]| + |W1p_l[2][c]| (position rows of SA level l's first layer: |B_l| <= sa_wp_l1[l] max|xyz|),
+     * sa_a1_l1 = max over columns of sum_k |sa_w1[0][k][c]| and sa_b1_absmax = max |sa_b1[0]| (|A_1| <= sa_a1_l1 max|input|
+     * + sa_b1_absmax). */
+    float sa_wp_l1[3];
+    float sa_a1_l1;
+    float sa_b1_absmax;
 } t2p_cell_weights;
 
 typedef struct t2p_cell_config {

@@ -28,7 +28,8 @@ class CellWeights(C.Structure):
                  ("pn_scale", C.c_float), ("g_wp_scale", C.c_float), ("g_wq_scale", C.c_float),
                  ("sa_w1_x3", c_void * 3), ("ga_w1_x3", c_void),
                  ("class_embedding", c_void), ("color_embedding", c_void),
-                 ("ga_w1_l1", C.c_float), ("ga_b1_absmax", C.c_float)])
+                 ("ga_w1_l1", C.c_float), ("ga_b1_absmax", C.c_float), ("sa_wp_l1", C.c_float * 3),
+                 ("sa_a1_l1", C.c_float), ("sa_b1_absmax", C.c_float)])
 
 
 class CellConfig(C.Structure):

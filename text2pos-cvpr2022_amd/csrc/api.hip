@@ -1,5 +1,6 @@
 // extern "C" entry points of libt2p_hip.so (see include/t2p.h) and the launch orchestration of the cell branch.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -228,6 +229,16 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     // fp16-range guard (f16x3 only): the chunk's words are cleared by the first kernel and judged by the last
     uint32_t* guard = (cfg.precision == 1 && cfg.overflow_flag != nullptr) ? ws.guard : nullptr;
     auto gslot = [&](int i) -> uint32_t* { return guard ? guard + i : nullptr; };
+    GuardBounds gbounds{};
+    for (int l = 0; l < 3; l++) gbounds.wp_l1[l] = W.sa_wp_l1[l];
+    gbounds.a1_l1 = W.sa_a1_l1;
+    gbounds.a1_bmax = W.sa_b1_absmax;
+    gbounds.ga1_l1 = W.ga_w1_l1;
+    gbounds.ga1_bmax = W.ga_b1_absmax;
+    // f16x3: the SA kernels of levels 1 and 2 build their centroid tables in LDS (ws_sa2.hip, BL); the HBM tables B_2 / B_3
+    // are then neither written nor read.  The fp32 kernels (ws_sa.hip) gather all three from HBM.
+    static const bool lds_btab_env = []() { const char* e = getenv("T2P_SA_LDS_BTAB"); return e == nullptr || e[0] != '0'; }();
+    const bool lds_btab = cfg.precision == 1 && lds_btab_env;   // T2P_SA_LDS_BTAB=0: A/B switch back to the HBM tables
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st, guard));
     // models/object_encoder.py:86: the PointNet++ only runs when the "class" feature does not come from class_embedding
     const bool run_pointnet = cfg.use_class && !cfg.class_embed;
@@ -242,7 +253,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         // [xyz | 0] tail of the F_l rows) for every level, and the K = 6 point table A_1 of level 0
         for (int l = 0; l < 3; l++) {
             const int cf = l == 0 ? 3 : Geo::C[l - 1];
-            gt.B[l] = ws.B[l];
+            gt.B[l] = (lds_btab && l > 0) ? nullptr : ws.B[l];
             gt.wp[l] = W.sa_w1[l] + (size_t)cf * Geo::H[l];
             gt.H[l] = Geo::H[l];
             gt.tail[l] = ws.F[l];
@@ -272,7 +283,6 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     for (int l = 0; l < 3; l++) {
         const int H = Geo::H[l], C = Geo::C[l];
         const int cf = l == 0 ? 3 : Geo::C[l - 1];  // feature columns in front of the xyz columns
-        (void)cf;
         const float* pos_src = l == 0 ? xyz : ws.F[l - 1];
         const int ld_pos = l == 0 ? 3 : Geo::LD[l - 1];
         const int pos_col0 = l == 0 ? 0 : Geo::C[l - 1];
@@ -296,6 +306,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         SaParams p{};
         p.A = ws.A[l];
         p.Bc = ws.B[l];
+        p.wp = (lds_btab && l > 0) ? W.sa_w1[l] + (size_t)cf * Geo::H[l] : nullptr;
         p.W = W.sa_w2[l];
         p.W_x3 = cfg.precision == 1 ? W.sa_w2_x3[l] : nullptr;
         p.bias = cfg.precision == 1 ? W.sa_b2_x3[l] : W.sa_b2[l];
@@ -404,7 +415,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     }
     if (cfg.objects_only) {  // the fine stage consumes ObjectEncoder.forward's output as is
         T2P_TRY(copy_trace(tr->obj_emb + trace_obj0 * D, emb, (size_t)n * D, st));
-        T2P_TRY(launch_guard_check(guard, cfg.overflow_flag, W.ga_w1_l1, W.ga_b1_absmax, st));
+        T2P_TRY(launch_guard_check(guard, cfg.overflow_flag, gbounds, st));
         return 0;
     }
     // ---- cell head: normalize, DynamicEdgeConv(k, max), global max pool, lin, normalize -------------------------
@@ -439,7 +450,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     T2P_TRY(launch_gemm(ws.pool, D, W.lin_w1, W.lin_b1, ws.l1, D, 0, nb, D, D, 1, st));
     T2P_TRY(launch_gemm(ws.l1, D, W.lin_w2, W.lin_b2, ws.l2, D, 0, nb, D, D, 1, st));
     T2P_TRY(launch_rownorm(ws.l2, D, nb, D, out, D, 0, st));
-    T2P_TRY(launch_guard_check(guard, cfg.overflow_flag, W.ga_w1_l1, W.ga_b1_absmax, st));
+    T2P_TRY(launch_guard_check(guard, cfg.overflow_flag, gbounds, st));
 
     if (tr && run_pointnet) {
         for (int l = 0; l < 3; l++) {
@@ -548,8 +559,8 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
                           w->ga_w1_x3 && w->ga_w2_x3,
                       "encode_cells: precision = f16x3 needs the packed *_x3 weight images");
     if (cfg->precision == 1 && cfg->overflow_flag != nullptr)
-        T2P_CHECK_ARG(w->ga_w1_l1 > 0.f && w->ga_b1_absmax >= 0.f,
-                      "encode_cells: the fp16-range guard needs ga_w1_l1 / ga_b1_absmax (packing.py)");
+        T2P_CHECK_ARG(w->ga_w1_l1 > 0.f && w->ga_b1_absmax >= 0.f && w->sa_a1_l1 > 0.f && w->sa_wp_l1[0] >= 0.f,
+                      "encode_cells: the fp16-range guard needs the weight norms of t2p_cell_weights (packing.py)");
     T2P_CHECK_ARG(cell_ptr_host[0] == 0 && cell_ptr_host[n_cells] == n_obj,
                   "encode_cells: cell_ptr must start at 0 and end at n_obj=%lld (got %d..%d)", (long long)n_obj,
                   cell_ptr_host[0], cell_ptr_host[n_cells]);

@@ -229,15 +229,23 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
     __syncthreads();
 }
 
-// Centroid table of one level + the [xyz | 0 x 29] tail of the SA output rows (was k_pos_table): H/4 lanes per centroid row,
-// the lane's 4 output columns of W1p in registers, 16-byte stores.  Same arithmetic order as the stand-alone kernel.
+// Centroid table of one level (out; may be nullptr: the f16x3 SA kernels of levels 1 and 2 build theirs in LDS) + the
+// [xyz | 0 x 29] tail of the SA output rows (was k_pos_table): H/4 lanes per centroid row, the lane's 4 output columns of
+// W1p in registers, 16-byte stores.  Same arithmetic order as the stand-alone kernel.
 __device__ __attribute__((noinline)) void emit_centroid_table(const float* qx, const float* qy, const float* qz, int n_c,
                                                     const float* __restrict__ wp, int H, float* __restrict__ out,
-                                                    float* __restrict__ tail, int ld_tail, int tail_col0, uint32_t* amax) {
+                                                    float* __restrict__ tail, int ld_tail, int tail_col0) {
     const int lane = threadIdx.x;
+    if (out == nullptr) {   // tails only: 8 lanes per row
+        if (tail == nullptr) return;
+        const int hq = lane & 7;
+        for (int c = lane >> 3; c < n_c; c += 8)
+            *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0 + hq * 4) =
+                hq == 0 ? f32x4{qx[c], qy[c], qz[c], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int tpr = H >> 2, rpp = 64 / tpr, hq = lane % tpr;
     const f32x4 w0 = *(const f32x4*)(wp + hq * 4), w1 = *(const f32x4*)(wp + H + hq * 4), w2 = *(const f32x4*)(wp + 2 * H + hq * 4);
-    float m = 0.f;  // fp16-range guard: largest |B_i| entry of this object's table
     for (int c = lane / tpr; c < n_c; c += rpp) {
         const float px = qx[c], py = qy[c], pz = qz[c];
         f32x4 v;
@@ -248,25 +256,22 @@ __device__ __attribute__((noinline)) void emit_centroid_table(const float* qx, c
             a = fmaf(pz, w2[e], a);
             v[e] = a;
         }
-        if (amax) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         *(f32x4*)(out + (size_t)c * H + hq * 4) = v;
         if (tail != nullptr && hq < 8)
             *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0 + hq * 4) = hq == 0 ? f32x4{px, py, pz, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    guard_publish(amax, m);
 }
 
 // SA1 layer-1 point table of one object (was k_sa1_point_table): A_1[j] = W1 [rgb_j | xyz_j] + b1
 __device__ __attribute__((noinline)) void emit_point_table(const float* px, const float* py, const float* pz,
                                                  const float* __restrict__ rgb, int n_pts, const float* __restrict__ w,
-                                                 const float* __restrict__ bias, int H, float* __restrict__ out, uint32_t* amax) {
+                                                 const float* __restrict__ bias, int H, float* __restrict__ out) {
     const int lane = threadIdx.x;
     const int tpr = H >> 2, rpp = 64 / tpr, hq = lane % tpr;
     f32x4 wk[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) wk[k] = *(const f32x4*)(w + k * H + hq * 4);
     const f32x4 bv = *(const f32x4*)(bias + hq * 4);
-    float m = 0.f;  // fp16-range guard: largest |A_j| entry
     for (int j = lane / tpr; j < n_pts; j += rpp) {
         const float in[6] = {rgb[j * 3], rgb[j * 3 + 1], rgb[j * 3 + 2], px[j], py[j], pz[j]};
         f32x4 v = bv;
@@ -274,10 +279,8 @@ __device__ __attribute__((noinline)) void emit_point_table(const float* px, cons
         for (int k = 0; k < 6; k++)
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = fmaf(in[k], wk[k][e], v[e]);
-        if (amax) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         *(f32x4*)(out + (size_t)j * H + hq * 4) = v;
     }
-    guard_publish(amax, m);
 }
 
 // 6 waves per SIMD (80 registers, some spills) measured fastest: 4 -> 3.26, 5 -> 3.08, 6 -> 2.85, 7 -> 3.5, 8 -> 3.16 ms / 3k cells
@@ -300,9 +303,18 @@ __global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict_
     const int lane = threadIdx.x;
     for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
         const float* src = xyz + o * (int64_t)n_pts * 3;
+        float in_max = 0.f;  // fp16-range guard: the layer-1 tables are bounded from the input magnitudes (k_guard_check)
         for (int i = lane; i < n_pts * 3; i += 64) {
             float v = src[i];
+            in_max = fmaxf(in_max, fabsf(v));
             p0[(i % 3) * kMaxPts + i / 3] = v;
+        }
+        if (gt.guard != nullptr) {
+            if (gt.rgb != nullptr) {
+                const float* col = gt.rgb + o * (int64_t)n_pts * 3;
+                for (int i = lane; i < n_pts * 3; i += 64) in_max = fmaxf(in_max, fabsf(col[i]));
+            }
+            guard_publish_above(gt.guard + G_INPUT, in_max, 1.0f);   // normalised inputs stay below 1: nothing is published
         }
         __syncthreads();
         if (gt.A1 != nullptr) {
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict_
             const float *w1 = gt.w1, *b1 = gt.b1;
             asm volatile("" : "+s"(w1), "+s"(b1));
             emit_point_table(p0, p0 + kMaxPts, p0 + 2 * kMaxPts, gt.rgb + o * (int64_t)n_pts * 3, n_pts, w1, b1, gt.H1,
-                             gt.A1 + o * (int64_t)n_pts * gt.H1, gt.guard ? gt.guard + G_A1 : nullptr);
+                             gt.A1 + o * (int64_t)n_pts * gt.H1);
         }
         float* pin[4][3] = {{p0, p0 + kMaxPts, p0 + 2 * kMaxPts},
                             {p1, p1 + kMaxPts / 2, p1 + kMaxPts},
@@ -349,13 +361,13 @@ __global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict_
                 level<1>(pin[l][0], pin[l][1], pin[l][2], n_d, n_c, rr[l], sel_lds, pin[l + 1][0], pin[l + 1][1],
                          pin[l + 1][2], nbr_lds, cnt_lds, g_rows16, gt.self_loops, &n_rows);
             if (g_rows16 != nullptr && lane == 0) gt.n_rows[l][o] = (uint16_t)n_rows;
-            if (gt.B[l] != nullptr) {
+            if (gt.B[l] != nullptr || gt.tail[l] != nullptr) {
                 const float* wpl = gt.wp[l];
                 asm volatile("" : "+s"(wpl));
                 emit_centroid_table(pin[l + 1][0], pin[l + 1][1], pin[l + 1][2], n_c, wpl, gt.H[l],
-                                    gt.B[l] + o * (int64_t)n_c * gt.H[l],
+                                    gt.B[l] ? gt.B[l] + o * (int64_t)n_c * gt.H[l] : nullptr,
                                     gt.tail[l] ? gt.tail[l] + o * (int64_t)n_c * gt.ld_tail[l] : nullptr, gt.ld_tail[l],
-                                    gt.tail_col0[l], gt.guard ? gt.guard + G_B1 + 2 * l : nullptr);
+                                    gt.tail_col0[l]);
             }
             uint8_t* g_sel = gt.fps_idx[l] + o * (int64_t)n_c;
             for (int i = lane; i < n_c; i += 64) g_sel[i] = sel_lds[i];
@@ -379,6 +391,9 @@ int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float 
     int64_t grid = n_obj < (int64_t)num_cus() * 64 ? n_obj : (int64_t)num_cus() * 64;
     ProfScope ps_("sample_group", st);
     const bool want_nbr = gt.nbr[0] != nullptr;
+    for (int l = 0; l < 3; l++)
+        if (gt.B[l] != nullptr)
+            T2P_CHECK_ARG(gt.tail[l] == nullptr || gt.H[l] >= 32, "sample_group: tails need H >= 32");
     for (int l = 0; l < 3; l++)
         if (gt.B[l] != nullptr)
             T2P_CHECK_ARG(gt.H[l] % 4 == 0 && gt.H[l] >= 32 && gt.H[l] <= 256 && 64 % (gt.H[l] / 4) == 0 && gt.wp[l],

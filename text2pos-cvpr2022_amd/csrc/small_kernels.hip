@@ -378,27 +378,29 @@ __global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, 
 // fp16-range verdict of one chunk (t2p_common.h GuardSlot): bit 0..2 = SA level l may have staged relu(A_j - B_i) past
 // fp16's largest finite value, bit 3 = an SA output row (split by the next dense kernel) did, bit 4 = the GA hidden planes
 // may have (bound ||W1||_1 max(F_3, 1) + max|b1|), bit 5 = a row of the LDS-tiled GEMMs did
-__global__ void k_guard_check(const uint32_t* __restrict__ guard, int32_t* flag, float ga1_l1, float ga1_bmax) {
+__global__ void k_guard_check(const uint32_t* __restrict__ guard, int32_t* flag, GuardBounds gb) {
     if (threadIdx.x != 0) return;
     const float lim = 65504.f;
     int code = 0;
+    const float in_max = fmaxf(__uint_as_float(guard[G_INPUT]), 1.f);       // unpublished: the inputs stayed within [-1, 1]
     for (int l = 0; l < 3; l++) {
-        // a word below kGuardFloor was never published: count it as the floor
-        const float a = fmaxf(__uint_as_float(guard[G_A1 + 2 * l]), kGuardFloor);
-        const float b = fmaxf(__uint_as_float(guard[G_B1 + 2 * l]), kGuardFloor);
+        // point table: level 0 bounded from the inputs, levels 1 and 2 reported by their dense kernels (unpublished = below
+        // the floor); centroid table: ||W1p||_1 max|xyz|
+        const float a = l == 0 ? gb.a1_l1 * in_max + gb.a1_bmax : fmaxf(__uint_as_float(guard[l == 1 ? G_A2 : G_A3]), kGuardFloor);
+        const float b = gb.wp_l1[l] * in_max;
         if (!(a + b < lim)) code |= 1 << l;   // also catches inf patterns
         if (!(__uint_as_float(guard[G_F1 + l]) < lim)) code |= 8;
     }
-    if (!(fmaxf(__uint_as_float(guard[G_F3]), 1.f) * ga1_l1 + ga1_bmax < lim)) code |= 16;
+    if (!(fmaxf(__uint_as_float(guard[G_F3]), 1.f) * gb.ga1_l1 + gb.ga1_bmax < lim)) code |= 16;
     if (!(__uint_as_float(guard[G_GEMM_IN]) < lim)) code |= 32;
     if (code != 0) atomicOr(flag, code);
 }
 
 }  // namespace
 
-int launch_guard_check(const uint32_t* guard, int32_t* overflow_flag, float ga1_l1, float ga1_bmax, hipStream_t st) {
+int launch_guard_check(const uint32_t* guard, int32_t* overflow_flag, const GuardBounds& b, hipStream_t st) {
     if (guard == nullptr || overflow_flag == nullptr) return 0;
-    hipLaunchKernelGGL(k_guard_check, dim3(1), dim3(64), 0, st, guard, overflow_flag, ga1_l1, ga1_bmax);
+    hipLaunchKernelGGL(k_guard_check, dim3(1), dim3(64), 0, st, guard, overflow_flag, b);
     T2P_CHECK_LAUNCH("guard_check");
     return 0;
 }

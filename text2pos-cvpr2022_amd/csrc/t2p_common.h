@@ -53,12 +53,22 @@ int reserve_lds(const void* kernel, size_t bytes, const char* what);
 // caller's sticky overflow flag.  The SA edge kernels convert relu(A_j - B_i) and are covered by the bound
 // max|A_l| + max|B_l| taken where the tables are produced, so their inner loop carries no check.
 enum GuardSlot {
-    G_A1 = 0, G_B1 = 1, G_A2 = 2, G_B2 = 3, G_A3 = 4, G_B3 = 5,  // layer-1 point / centroid tables of the SA levels
+    G_INPUT = 0,               // max(|xyz|, |rgb|) of the call's inputs when above 1 (normalised inputs: never published).
+                               // Bounds the geometry-only layer-1 tables: |B_l| <= ||W1p_l||_1 max|xyz|,
+                               // |A_1| <= ||W1_1||_1 max(|rgb|, |xyz|) + max|b1|
+    G_A2 = 2, G_A3 = 4,        // layer-1 point tables of SA levels 2 and 3, reported by the dense kernels that write them
     G_F1 = 6, G_F2 = 7, G_F3 = 8,  // SA outputs F_l = the rows the dense weight-stationary kernels split on the fly; exact
                                    // maxima, reported by the SA kernels (their xyz tail is bounded by 1).  GA layer 1's
                                    // output (handed on as fp16 planes) is bounded by ||W||_1 max(F_3, 1) + max|b|
     G_GEMM_IN = 9,    // rows split on the fly by the LDS-tiled f16x3 GEMM (f0, f1, cat, emb)
     G_SLOTS = 16
+};
+struct GuardBounds {   // host-side norms of the folded weights (packing.py), passed by value to k_guard_check
+    float wp_l1[3];     // per SA level: max over columns of |W1p[0][c]| + |W1p[1][c]| + |W1p[2][c]|
+    float a1_l1;        // SA1 layer 1 over all 6 inputs: max over columns of sum_k |W1[k][c]|
+    float a1_bmax;      // max |b1| of SA1
+    float ga1_l1;       // GA layer 1: max over columns of sum_k |W[k][c]|
+    float ga1_bmax;
 };
 // Magnitudes below kGuardFloor are never published (no atomic traffic in the normal case: activations of a trained,
 // batch-normalised network are O(1..100)); k_guard_check counts an unpublished word as kGuardFloor.
@@ -69,6 +79,13 @@ constexpr float kGuardFloor = 16384.f;
 __device__ __forceinline__ void guard_publish(uint32_t* slot, float m) {
     if (slot == nullptr) return;
     if (!__any(m >= kGuardFloor)) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+__device__ __forceinline__ void guard_publish_above(uint32_t* slot, float m, float floor_) {
+    if (slot == nullptr) return;
+    if (!__any(m > floor_)) return;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
@@ -85,8 +102,7 @@ __device__ __forceinline__ void guard_track_bits(uint32_t& acc, int lane_bits /*
     acc = b > acc ? b : acc;
 }
 #endif
-// ga1_l1 = max over GA layer 1's output columns of sum_k |W[k][col]|, ga1_bmax = max |b| (host, packing.py)
-int launch_guard_check(const uint32_t* guard, int32_t* overflow_flag, float ga1_l1, float ga1_bmax, hipStream_t st);  // small_kernels.hip
+int launch_guard_check(const uint32_t* guard, int32_t* overflow_flag, const GuardBounds& b, hipStream_t st);  // small_kernels.hip
 
 // Opt-in per-kernel timing (t2p_profile_enable): brackets a launch with hipEvents on the launch stream.
 struct ProfScope {
@@ -194,7 +210,9 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st);
 // ---- ws_sa.hip: the set-abstraction edge kernel (flattened, fully pipelined batch stream) ----------------------------
 struct SaParams {
     const float* A;   // layer-1 point table [n_obj*n_dense][H]
-    const float* Bc;  // centroid table [n_obj*n_cent][H]
+    const float* Bc;  // centroid table [n_obj*n_cent][H] (unused when wp is given)
+    const float* wp;  // nullptr, or the [3][H] position rows of the layer-1 weights: the f16x3 kernel then builds each object's
+                      // centroid table B_i = W1p pos_i in LDS itself (pos_i from the [xyz | 0] tail of the `out` rows)
     const float* W;   // [H][C] k-major (fp32 MFMA path)
     const void* W_x3; // nullptr, or the host-packed f16x3 register image of W (selects the split-precision path)
     const float* bias;  // [C]; the f16x3 path takes it pre-multiplied by the weight image's scale

@@ -38,10 +38,15 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 // workgroups per CU (one wave per SIMD each): the two waves of a SIMD then belong to different workgroups, drift apart
 // and cover each other's non-MFMA phases; needs <= 80 KB of LDS, which the single-buffered accumulator allows for K <= 128.
 // WGS = workgroups per CU (1 or 2; 2 needs <= 80 KB of LDS each, hence a single accumulator buffer).
-template <int K, int N, int WN, int RT, int NW, int WGS>
+// BL = 1: the object's centroid table B_i = W1p pos_i is BUILT IN LDS by the kernel (3 fmas per entry, once per object)
+// instead of being written to HBM by k_sample_group and gathered row by row through the vector-memory path: that path
+// delivers ~30 B/clk/CU and B_i rows were half of its bytes (profiles/microbench/README.md).  The 33 KB table takes
+// the place of the second accumulator buffer, so a finished object drains behind a barrier instead of under the next
+// object's MFMAs (~1 % of an object's time).
+template <int K, int N, int WN, int RT, int NW, int WGS, int BL = 0>
 struct Cfg2 {
     static constexpr int NT = 64 * NW;
-    static constexpr int ACC_BUFS = WGS == 1 ? 2 : 1;
+    static constexpr int ACC_BUFS = (WGS == 1 && !BL) ? 2 : 1;
     static constexpr int WM = NW / WN;
     static constexpr int NTW = N / (32 * WN);
     static constexpr int TR = WM * RT * 32;
@@ -55,8 +60,11 @@ struct Cfg2 {
     static constexpr int ACC_INTS = 8192 + N;
     static constexpr int NG = S16 * RT;      // MFMA groups per batch and wave
     static constexpr int NCH = 3 * ITERS;    // staging chunks per batch and thread
+    static constexpr int BT_FLOATS = BL ? 8192 + K + 3 * K + 256 : 0;  // [n_cent + 1][K] centroid table + W1p [3][K] + [n_cent][3]
+    static_assert(!BL || K == N, "the staged rows address the centroid table with the accumulator's byte offsets");
     static constexpr size_t lds_bytes() {
-        return (size_t)2 * 2 * PLANE * 2 + (size_t)ACC_BUFS * ACC_INTS * 4 + 4 * TR * 2 + kSub * 2 + kSub * 4;
+        return (size_t)2 * 2 * PLANE * 2 + (size_t)ACC_BUFS * ACC_INTS * 4 + 4 * TR * 2 + kSub * 2 + kSub * 4 +
+               (size_t)BT_FLOATS * 4;
     }
 };
 
@@ -84,6 +92,12 @@ __device__ __forceinline__ void abl_keep(const f32x16& v, uint32_t a, const void
     asm volatile("" ::"v"(v), "v"(a), "v"(q));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which on gfx950 waits
+// for every outstanding global STORE (vmcnt(0), and with it for the gathers queued behind them): right after an object's
+// drain to HBM that exposes a full store round trip.  Where only LDS contents are handed between waves, waiting for the
+// wave's own LDS operations and meeting at s_barrier is enough.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct BatchIt {
     int gi, r0, n;
     int sb;  // source row of centroid 0's self loop for the current object (kept from the last object past the end)
@@ -94,12 +108,15 @@ struct BatchIt {
         const int k = c / 3, part = c % 3;                                                     \
         if (part == 0) stage_a(sbuf, k);                                                       \
         else if (part == 1) stage_b(sbuf, k);                                                  \
-        else issue(it_g, meta_g, k, dbuf);                                                     \
+        else {                                                                                 \
+            issue(it_g, meta_g, k, dbuf);                                                      \
+            if constexpr (BL) { if (k + 1 < C::ITERS) load_b(k + 1); }                         \
+        }                                                                                      \
     }
 
-template <int K, int N, int WN, int RT, int NW, int WGS>
+template <int K, int N, int WN, int RT, int NW, int WGS, int BL>
 __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
-    using C = Cfg2<K, N, WN, RT, NW, WGS>;
+    using C = Cfg2<K, N, WN, RT, NW, WGS, BL>;
     constexpr int IT = C::ITERS;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -110,6 +127,9 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
     uint16_t* dstl = (uint16_t*)(acc_lds + C::ACC_BUFS * C::ACC_INTS);
     uint16_t* nr = dstl + 4 * C::TR;                            // [kSub]
     int* sbase = (int*)(nr + kSub);                             // [kSub]
+    float* btab = (float*)(sbase + kSub);                       // BL: [n_cent + 1][K] centroid table of the current object
+    float* wpl = btab + 8192 + K;                               // BL: [3][K] position rows of the layer-1 weights
+    float* cposl = wpl + 3 * K;                                 // BL: [n_cent][3] centroid positions of the object being built
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN, h = lane >> 5, l31 = lane & 31;
@@ -147,6 +167,50 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
     const uint32_t c4b = (uint32_t)c4 * 16u;
     typedef uint16_t metav __attribute__((ext_vector_type(C::ITERS)));
 
+    // ---- BL: centroid table in LDS ---------------------------------------------------------------------------------
+    // The positions of an object's centroids sit in the [xyz | 0] tail of this level's output rows (written by
+    // k_sample_group).  Thread t < 3 n_cent keeps ONE coordinate of the NEXT object in a register, fetched one object ahead,
+    // so a build waits for no memory: it drops the coordinates into LDS, and thread (row group cg, column quad c4) then
+    // forms the entries [c][4 c4 .. 4 c4 + 3] of the centroids c = cg + CGS i.
+    constexpr int CGS = NT / C::F4_PER_ROW;              // row groups of the workgroup
+    constexpr int CPT = BL ? (8192 / K) / CGS : 1;       // centroids per thread (n_cent / CGS)
+    const int cg = tid / C::F4_PER_ROW;
+    float npos = 0.f;
+    auto fetch_pos = [&](int64_t g) {
+        if constexpr (BL) {
+            if (tid < 3 * nc && g < g_end) npos = p.out[(g * nc + tid / 3) * (int64_t)p.ldo + N + tid % 3];
+        }
+    };
+    auto build_b = [&](int64_t g) {  // from the prefetched positions of object g; then prefetch g + 1.  Ends with a barrier.
+        if constexpr (BL) {
+            if (tid < 3 * nc) cposl[tid] = npos;
+            fetch_pos(g + 1);
+            lds_barrier();
+            const f32x4 w0 = *(const f32x4*)(wpl + c4 * 4), w1 = *(const f32x4*)(wpl + K + c4 * 4),
+                        w2 = *(const f32x4*)(wpl + 2 * K + c4 * 4);
+#pragma unroll
+            for (int i = 0; i < CPT; i++) {
+                const int c = cg + CGS * i;
+                const float px = cposl[3 * c], py = cposl[3 * c + 1], pz = cposl[3 * c + 2];
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {   // same order as k_sample_group's table: ((x w0) + y w1) + z w2
+                    float a = px * w0[e];
+                    a = fmaf(py, w1[e], a);
+                    a = fmaf(pz, w2[e], a);
+                    v[e] = a;
+                }
+                *(f32x4*)(btab + c * K + c4 * 4) = v;
+            }
+            lds_barrier();
+        }
+    };
+    if constexpr (BL) {
+        for (int i = tid; i < 3 * K; i += NT) wpl[i] = p.wp[i];
+        for (int i = tid; i < K; i += NT) btab[8192 + i] = 0.f;   // row n_cent: what padding rows subtract
+        fetch_pos(g_begin);
+    }
+
     for (int ga = g_begin; ga < g_end; ga += kSub) {
         const int cnt = (g_end - ga) < kSub ? (g_end - ga) : kSub;
         __syncthreads();
@@ -171,7 +235,12 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         auto valid = [&](const BatchIt& it) { return it.gi < cnt; };
 
         metav meta_g, meta_m;
-        f32x4 sa[IT], sb[IT];
+        f32x4 sa[IT], sb[BL ? 1 : IT];
+        uint32_t boff[BL ? IT : 1];   // BL: byte offset of the staged row's centroid inside the LDS table
+        f32x4 bq;                     // BL: that centroid's table entries, fetched one staging chunk ahead of their use
+        auto load_b = [&](int k) {
+            if constexpr (BL) bq = *(const f32x4*)((const char*)btab + boff[k]);
+        };
         f32x4 vv;            // staged values between the two halves of a staging step
         fp16x2 vh01, vh23;
 
@@ -207,7 +276,9 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
                     sa[k] = f32x4{f, f, f, f};
                 } else
                     sa[k] = *(const f32x4*)((const char*)p.A + (srow * (uint32_t)(K * 4) + c4b));
-                if constexpr (T2P_ABL & 2) {
+                if constexpr (BL) {
+                    boff[k] = (pad ? (uint32_t)nc : dl) * (uint32_t)(K * 4) + c4b;
+                } else if constexpr (T2P_ABL & 2) {
                     const float f = __uint_as_float(((g * (uint32_t)nc + dl) * (uint32_t)(K * 4) + c4b) | 0x3e000000u);
                     sb[k] = f32x4{f, f, f, f};
                 } else
@@ -218,7 +289,9 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         // staging of row k, first half: v = relu(A_j - B_i), hi = fp16(v) toward zero -> hi plane
         auto stage_a = [&](int buf, int k) {
             _Float16* dsth = hidh + buf * 2 * C::PLANE;
-            const f32x4 t = sa[k] - sb[k];
+            f32x4 t;
+            if constexpr (BL) t = sa[k] - bq;
+            else t = sa[k] - sb[k];
 #pragma unroll
             for (int e = 0; e < 4; e++) vv[e] = fmaxf(t[e], 0.f);
             vh01 = __builtin_amdgcn_cvt_pkrtz(vv[0], vv[1]);
@@ -263,8 +336,10 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         fix_meta(it_c, meta_g);
 #pragma unroll
         for (int k = 0; k < IT; k++) issue(it_c, meta_g, k, 0);
+        if constexpr (BL) build_b(ga);   // (the sub-range's first barrier pair above ordered any earlier reader of the table)
 #pragma unroll
         for (int k = 0; k < IT; k++) {
+            load_b(k);
             stage_a(0, k);
             stage_b(0, k);
         }
@@ -314,12 +389,25 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         for (int t = 0; valid(it_c); t++) {
             t_end = t + 1;
             STAMP(0);
-            if (flush_g >= 0) {  // the object finished in the previous batch drains to HBM
-                flush(flush_g, flush_buf);
-                flush_g = -1;
-                // one accumulator buffer: the next object's atomics (issued inside this batch) must not overtake the drain
-                if constexpr (C::ACC_BUFS == 1) __syncthreads();
+            {
+                bool fence = false;
+                if (flush_g >= 0) {  // the object finished in the previous batch drains to HBM
+                    flush(flush_g, flush_buf);
+                    flush_g = -1;
+                    // one accumulator buffer: the next object's atomics (issued inside this batch) must not overtake the drain
+                    fence = C::ACC_BUFS == 1;
+                }
+                if constexpr (BL) {
+                    // batch t+1 (staged during this batch) opens a new object: its centroid table replaces the current one;
+                    // nobody reads the table right now (batch t was staged in the previous iteration)
+                    if (valid(it_s) && it_s.r0 == 0) {
+                        build_b(ga + it_s.gi);   // (its barriers also order the drain above)
+                        fence = false;
+                    }
+                }
+                if (fence) lds_barrier();   // (LDS only: the drain's global stores need not have landed)
             }
+            load_b(0);   // BL: first row of batch t+1; the others follow one staging chunk ahead of their use
 
             const int buf = t & 1, sbuf = buf ^ 1, dbuf = (t + 2) & 3;
             BatchIt it_n = it_m;
@@ -432,7 +520,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         }
         if (flush_g >= 0) {
             flush(flush_g, flush_buf);
-            if constexpr (C::ACC_BUFS == 1) __syncthreads();
+            if constexpr (C::ACC_BUFS == 1) lds_barrier();
         }
         if constexpr (DEFER) {  // drain: atomics of the last batch, then its object
             uint2 four[RT][4];
@@ -450,12 +538,14 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         atomicMax(p.amax_out, __float_as_uint(__uint_as_float(gbits) * p.out_scale));
 }
 
-template <int K, int N, int WN, int RT, int NW, int WGS>
+template <int K, int N, int WN, int RT, int NW, int WGS, int BL = 0>
 int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
-    using C = Cfg2<K, N, WN, RT, NW, WGS>;
+    using C = Cfg2<K, N, WN, RT, NW, WGS, BL>;
     static_assert(WGS == 1 || K <= 128, "two workgroups per CU rely on the deferred atomics (K <= 128)");
     static_assert(C::lds_bytes() * WGS <= 160 * 1024, "LDS budget");
-    auto kern = k_ws_sa2<K, N, WN, RT, NW, WGS>;
+    auto kern = k_ws_sa2<K, N, WN, RT, NW, WGS, BL>;
+    if (BL) T2P_CHECK_ARG(p.wp != nullptr && p.n_cent == 8192 / K && ((uintptr_t)p.out & 3) == 0,
+                          "ws_sa2: the LDS centroid table needs wp and n_cent = %d (got %d)", 8192 / K, p.n_cent);
     T2P_TRY(reserve_lds((const void*)kern, C::lds_bytes(), "ws_sa2"));
     if (p.n_obj <= 0) return 0;
     T2P_CHECK_ARG(p.n_obj < (1 << 30) && p.n_obj * p.n_dense * (int64_t)K * 4 < 0xffffffffLL &&
@@ -522,6 +612,9 @@ int launch_ws_sa2(int H, int Cout, const SaParams& p, hipStream_t st) {
     // SA1: the weights take 16 registers, so 16 waves per CU fit (two 8-wave workgroups of <= 128 registers, 2 rows per
     // thread): 4 waves per SIMD measured 10 % faster than 2 (two 4-wave workgroups) and 14 % faster than one 8-wave one
     if (H == 32 && Cout == 64) return launch_cfg2<32, 64, 2, 1, 8, 2>(p, st, "ws_edge_sa_k32_n64");
+    // wp given: the centroid table is built in LDS per object (BL); otherwise gathered from the Bc table in HBM
+    if (H == 128 && Cout == 128 && p.wp) return launch_cfg2<128, 128, 4, 1, 8, 1, 1>(p, st, "ws_edge_sa_k128_n128");
+    if (H == 256 && Cout == 256 && p.wp) return launch_cfg2<256, 256, 8, 1, 8, 1, 1>(p, st, "ws_edge_sa_k256_n256");
     if (H == 128 && Cout == 128) return launch_cfg2<128, 128, 4, 1, 8, 1>(p, st, "ws_edge_sa_k128_n128");
     if (H == 256 && Cout == 256) return launch_cfg2<256, 256, 8, 1, 8, 1>(p, st, "ws_edge_sa_k256_n256");
     set_error("ws_sa2: no instantiation for H=%d C=%d", H, Cout);

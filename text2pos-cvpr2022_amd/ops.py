@@ -197,6 +197,8 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
             setattr(w, name, g.data_ptr())
     if packed.get("ga_w1_l1") is not None:
         w.ga_w1_l1, w.ga_b1_absmax = float(packed["ga_w1_l1"]), float(packed["ga_b1_absmax"])
+        w.sa_wp_l1 = (C.c_float * 3)(*[float(v) for v in packed["sa_wp_l1"]])
+        w.sa_a1_l1, w.sa_b1_absmax = float(packed["sa_a1_l1"]), float(packed["sa_b1_absmax"])
     for name in ("class_embedding", "color_embedding"):
         t = packed.get(name)
         if t is not None:

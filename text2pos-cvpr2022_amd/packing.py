@@ -124,6 +124,11 @@ def _add_x3_images(p: Dict[str, object], device, cell_head: bool):
     # fp16-range guard: GA layer 1's output is bounded by ||W||_1 (largest column sum of |w|) * max|input| + max|b|
     p["ga_w1_l1"] = float(p["ga_w1"].double().abs().sum(0).max())
     p["ga_b1_absmax"] = float(p["ga_b1"].double().abs().max())
+    # ... and the layer-1 tables that depend on the inputs only (position rows = the last three real rows of each sa_w1)
+    feat = (3, 64, 128)
+    p["sa_wp_l1"] = [float(w[c: c + 3].double().abs().sum(0).max()) for w, c in zip(p["sa_w1"], feat)]
+    p["sa_a1_l1"] = float(p["sa_w1"][0].double().abs().sum(0).max())
+    p["sa_b1_absmax"] = float(p["sa_b1"][0].double().abs().max())
     for name, src in (("lin1", "lin1_w"), ("lin2", "lin2_w"), ("pn", "pn_w"), ("merge", "merge_w")) + \
             ((("g_wp", "g_wp"), ("g_wq", "g_wq")) if cell_head else ()):
         sc = f16x3_scale(p[src])
