@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--bn", choices=["calibrated", "random"], default="calibrated",
                     help="BatchNorm running statistics of the random-init model: calibrated on 64 cells of the workload "
                          "(default) or drawn at random (SURVEY 8(d); embeddings then collapse onto one direction)")
+    ap.add_argument("--tuning", type=int, default=0, help="t2p_cell_config.tuning (A/B between equivalent execution plans)")
     ap.add_argument("--no-fp32-pass", action="store_true", help="skip the extra exact-fp32 pass behind the timed region")
     ap.add_argument("--fp32-steps", type=int, default=2)
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
@@ -221,6 +222,7 @@ def main():
             m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
             m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
     model = model.to(dev).eval()
+    model.tuning = args.tuning
 
     # ---- inputs -> HBM (outside the timed region) ---------------------------------------------------------------------
     d_xyz, d_rgb, d_center, d_mean = (torch.from_numpy(a).to(dev) for a in (xyz, rgb, center, mean_rgb))

@@ -165,6 +165,10 @@ typedef struct t2p_cell_config {
      * fire for a checkpoint that would just have fitted, never the other way round.  The caller clears it, reads it after the stream has drained, and must
      * not trust the call's output when it is set (the Python host raises or re-runs with precision = 0).  NULL: no check. */
     int32_t* overflow_flag;
+    /* A/B switches between equivalent execution plans (0 = the default plan; results are bit-identical either way):
+     *   bit 0: keep the edge rows of repeated points in SA level 1's row lists (default: t2p_dedup_rows drops them)
+     *   bit 1: f16x3 only: gather the centroid tables of SA levels 2 and 3 from HBM (default: built in LDS per object) */
+    int32_t tuning;
 } t2p_cell_config;
 
 /* Optional stage outputs for parity tests (any member may be NULL).  Layouts:
@@ -365,6 +369,14 @@ int t2p_hardest_ranking(const float* scores, int32_t batch, float margin, float*
 int t2p_sample_group(const float* xyz, int64_t n_obj, int32_t n_pts, const float* radius_host /*[3]*/,
                      uint8_t* const* fps_idx /*[3]*/, uint8_t* const* nbr /*[3]*/, uint8_t* const* cnt /*[3]*/,
                      t2p_stream_t stream);
+/* Level-1 (SA1) row lists without the edges of repeated points.  rows uint16 [n_obj][(n_pts/2) * 33]: per object the compact
+ * edge-row list of k_sample_group, sorted by centroid: (centroid | 0x80 for the self-loop row) << 8 | source point, terminated
+ * by four 0xFFFF; n_rows uint16 [n_obj].  A row whose source point repeats an EARLIER point of the object bit for bit (xyz and
+ * rgb; T.FixedPoints draws with replacement, dataloading/kitti360pose/utils.py:99-109) carries the same message as that
+ * point's row for the same centroid, so under PointConv's max-aggregation (pointnet2.py:31-35) it can be dropped.  In place;
+ * detection is conservative (a repeat may survive, a non-repeat is never dropped).  n_pts must be 256. */
+int t2p_dedup_rows(const float* xyz, const float* rgb, int64_t n_obj, int32_t n_pts, uint16_t* rows, uint16_t* n_rows,
+                   t2p_stream_t stream);
 /* knn of DynamicEdgeConv (cell_retrieval.py:46-48): x [n][dim], seg_ptr [n_seg+1] int32, out [n][k] int32 */
 int t2p_knn(const float* x, int32_t dim, const int32_t* seg_ptr, int32_t n_seg, int32_t max_seg_rows, int32_t k,
             int32_t* out_idx, t2p_stream_t stream);

@@ -38,7 +38,7 @@ class CellConfig(C.Structure):
                 ("self_loops", C.c_int32), ("knn_k", C.c_int32), ("variation", C.c_int32),
                 ("radius", C.c_float * 3), ("chunk_objects", C.c_int32), ("precision", C.c_int32),
                 ("class_embed", C.c_int32), ("color_embed", C.c_int32), ("class_idx", c_void), ("color_idx", c_void),
-                ("objects_only", C.c_int32), ("overflow_flag", c_void)]
+                ("objects_only", C.c_int32), ("overflow_flag", c_void), ("tuning", C.c_int32)]
 
 
 class CellTrace(C.Structure):
@@ -103,6 +103,7 @@ SYMBOLS = {
     "t2p_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),
     "t2p_sample_group": (C.c_int, [c_void, C.c_int64, C.c_int32, c_float_p, C.POINTER(c_void), C.POINTER(c_void),
                                    C.POINTER(c_void), c_void]),
+    "t2p_dedup_rows": (C.c_int, [c_void, c_void, C.c_int64, C.c_int32, c_void, c_void, c_void]),
     "t2p_knn": (C.c_int, [c_void, C.c_int32, c_void, C.c_int32, C.c_int32, C.c_int32, c_void, c_void]),
     "t2p_gemm": (C.c_int, [c_void, C.c_int32, c_void, c_void, c_void, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                            C.c_int32, C.c_int32, c_void]),

@@ -50,6 +50,7 @@ class CellRetrievalNetwork(nn.Module):
             raise ValueError("on_overflow must be 'raise' or 'fp32'")
         self.on_overflow = on_overflow
         self._overflow = None
+        self.tuning = 0          # t2p_cell_config.tuning: A/B switches between equivalent execution plans (include/t2p.h)
         d = self.embed_dim
         assert args.variation in (0, 1)
         self.graph1 = DynamicEdgeConv(get_mlp([2 * d, d, d], add_batchnorm=True), k=8,
@@ -102,7 +103,7 @@ class CellRetrievalNetwork(nn.Module):
                                     use_features=tuple(a.use_features), self_loops=self.add_self_loops,
                                     knn_k=self.graph1.k, variation=self.variation, radius=radii,
                                     chunk_objects=chunk_objects, precision=precision or self.precision,
-                                    class_idx=class_idx, color_idx=color_idx,
+                                    class_idx=class_idx, color_idx=color_idx, tuning=self.tuning,
                                     overflow_flag=self._overflow_word() if (precision or self.precision) == "f16x3" else None)
 
     def _check_forward_only(self):

@@ -237,8 +237,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     gbounds.ga1_bmax = W.ga_b1_absmax;
     // f16x3: the SA kernels of levels 1 and 2 build their centroid tables in LDS (ws_sa2.hip, BL); the HBM tables B_2 / B_3
     // are then neither written nor read.  The fp32 kernels (ws_sa.hip) gather all three from HBM.
-    static const bool lds_btab_env = []() { const char* e = getenv("T2P_SA_LDS_BTAB"); return e == nullptr || e[0] != '0'; }();
-    const bool lds_btab = cfg.precision == 1 && lds_btab_env;   // T2P_SA_LDS_BTAB=0: A/B switch back to the HBM tables
+    const bool lds_btab = cfg.precision == 1 && !(cfg.tuning & 2);
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st, guard));
     // models/object_encoder.py:86: the PointNet++ only runs when the "class" feature does not come from class_embedding
     const bool run_pointnet = cfg.use_class && !cfg.class_embed;
@@ -266,7 +265,11 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         gt.rgb = rgb;
         gt.H1 = Geo::H[0];
         gt.guard = guard;
+
         T2P_TRY(launch_sample_group(xyz, n, cfg.n_pts, cfg.radius, gt, st));
+        // level 0: edges of repeated points leave the row list (same max-aggregate, -36 % SA1 rows on the synthetic cells)
+        if (!(cfg.tuning & 1) && cfg.n_pts == 256)
+            T2P_TRY(launch_dedup_rows(xyz, rgb, n, cfg.n_pts, gt.rows[0], gt.n_rows[0], g.nc[0], st));
         // the per-centroid row counts of all three levels exist now: cut every level's balanced object ranges at once
         SaParams bp[3] = {};
         for (int l = 0; l < 3; l++) {
@@ -791,6 +794,13 @@ int t2p_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* 
     T2P_CHECK_ARG(n_obj >= 0 && n_pts >= 1, "pack_objects: bad sizes");
     return launch_pack_objects(raw_xyz, raw_rgb, obj_ptr, sample_idx, rot_cos_sin, n_obj, n_pts, xyz, rgb, center, mean_rgb,
                                (hipStream_t)stream);
+}
+
+int t2p_dedup_rows(const float* xyz, const float* rgb, int64_t n_obj, int32_t n_pts, uint16_t* rows, uint16_t* n_rows,
+                   t2p_stream_t stream) {
+    T2P_CHECK_ARG(n_obj >= 0, "dedup_rows: negative size");
+    T2P_CHECK_ARG((((uintptr_t)xyz | (uintptr_t)rgb | (uintptr_t)rows) & 15) == 0, "dedup_rows: xyz, rgb and rows must be 16-byte aligned");
+    return launch_dedup_rows(xyz, rgb, n_obj, n_pts, rows, n_rows, (n_pts + 1) / 2, (hipStream_t)stream);
 }
 
 int t2p_knn(const float* x, int32_t dim, const int32_t* seg_ptr, int32_t n_seg, int32_t max_seg_rows, int32_t k,

@@ -382,7 +382,108 @@ __global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict_
     }
 }
 
+// ---- level-0 row lists without the edges of repeated points ----------------------------------------------------------
+// T.FixedPoints draws an object's 256 points WITH replacement (dataloading/kitti360pose/utils.py:99-109), so 35-40 % of a
+// typical object's points repeat an earlier point bit for bit (coordinates and colour).  A repeat's message
+// W2 relu(W1 [x_j | pos_j - pos_i]) equals its original's for every centroid, and the original - lower index, same
+// position - lies in the same ball and inside the 32-neighbour cap whenever the repeat does.  Under max-aggregation the
+// repeat's edge row can therefore be dropped from the compact list without changing a bit of the result; the cap itself
+// was applied to all hits in index order by k_sample_group (the reference's neighbourhood).  -36 % SA1 rows on the
+// synthetic cells.  One wavefront per object: a 1024-slot LDS table keeps the lowest index per coordinate hash; a point whose
+// slot holds a lower index with identical coordinates and colour is a repeat (a slot taken by a different point of the
+// same hash only leaves a repeat undetected: its rows stay, which is always valid).  The list is compacted in place
+// (writes never pass the read position), re-terminated and its length updated.
+__global__ __launch_bounds__(64) void k_dedup_rows(const float* __restrict__ xyz, const float* __restrict__ rgb, int64_t n_obj,
+                                                   uint16_t* rows, uint16_t* n_rows, int max_rows) {
+    __shared__ uint32_t slot[1024];
+    __shared__ __attribute__((aligned(16))) float pxyz[kMaxPts * 3];
+    __shared__ __attribute__((aligned(16))) float prgb[kMaxPts * 3];
+    __shared__ uint8_t rep[kMaxPts];
+    const int lane = threadIdx.x;
+    for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
+        const f32x4* sx = (const f32x4*)(xyz + o * kMaxPts * 3);
+        const f32x4* sc = (const f32x4*)(rgb + o * kMaxPts * 3);
+        for (int i = lane; i < kMaxPts * 3 / 4; i += 64) {   // straight 16-byte copies: point j at [3 j .. 3 j + 2]
+            ((f32x4*)pxyz)[i] = sx[i];
+            ((f32x4*)prgb)[i] = sc[i];
+        }
+        for (int i = lane; i < 1024; i += 64) slot[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = lane * 4 + j;
+            uint32_t k = __float_as_uint(pxyz[i * 3]) * 0x9E3779B1u;
+            k = (k ^ (k >> 15)) + __float_as_uint(pxyz[i * 3 + 1]) * 0x85EBCA77u;
+            k = (k ^ (k >> 13)) + __float_as_uint(pxyz[i * 3 + 2]) * 0xC2B2AE3Du;
+            h[j] = (k ^ (k >> 16)) & 1023u;
+            atomicMin(&slot[h[j]], (uint32_t)i);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = lane * 4 + j;
+            const int f = (int)slot[h[j]];   // f <= i: the slot keeps the lowest index of its hash
+            bool r = f != i;
+#pragma unroll
+            for (int e = 0; e < 3; e++)
+                r = r && __float_as_uint(pxyz[f * 3 + e]) == __float_as_uint(pxyz[i * 3 + e]) &&
+                    __float_as_uint(prgb[f * 3 + e]) == __float_as_uint(prgb[i * 3 + e]);
+            rep[i] = r ? 1 : 0;
+        }
+        __syncthreads();
+        // 512 rows per step: lane l owns the 8 consecutive rows [512 s + 8 l, +8) (one 16-byte load; the lists are 16-byte
+        // aligned and 0xFFFF-terminated inside their allocation), the next step's load is in flight while this one is written
+        uint16_t* list = rows + o * (int64_t)max_rows;
+        const int n = n_rows[o];
+        const uint4* list4 = (const uint4*)list;
+        int out = 0;
+        uint4 cur = n > 0 ? list4[lane] : uint4{0, 0, 0, 0};
+        for (int b = 0; b < n; b += 512) {
+            uint4 nxt = uint4{0, 0, 0, 0};
+            if (b + 512 < n) nxt = list4[(b + 512) / 8 + lane];
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+            uint32_t v[8];
+            bool keep[8];
+            int below = 0, mine = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                v[k] = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
+                const int r = b + lane * 8 + k;
+                // a self-loop row (flag 0x80 in the centroid byte) names a centroid, not a point: always kept
+                keep[k] = r < n && ((v[k] & 0x8000u) || !rep[v[k] & 0xFFu]);
+                const unsigned long long m = __ballot(keep[k]);
+                below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, below));
+                total += __popcll(m);
+            }
+            int pos = out + below;   // kept rows of lower lanes come first (row order = lane-major)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (keep[k]) list[pos + mine] = (uint16_t)v[k];
+                mine += keep[k] ? 1 : 0;
+            }
+            out += total;
+            cur = nxt;
+        }
+        if (lane < 4 && out + lane < max_rows) list[out + lane] = 0xFFFF;   // the 4-row terminator consumers rely on
+        if (lane == 0) n_rows[o] = (uint16_t)out;
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+int launch_dedup_rows(const float* xyz, const float* rgb, int64_t n_obj, int n_pts, uint16_t* rows, uint16_t* n_rows,
+                      int n_cent, hipStream_t st) {
+    T2P_CHECK_ARG(n_pts == kMaxPts && xyz && rgb && rows && n_rows, "dedup_rows: built for %d points per object", kMaxPts);
+    if (n_obj == 0) return 0;
+    const int64_t grid = n_obj < (int64_t)num_cus() * 32 ? n_obj : (int64_t)num_cus() * 32;
+    ProfScope ps_("dedup_rows", st);
+    hipLaunchKernelGGL(k_dedup_rows, dim3((unsigned)grid), dim3(64), 0, st, xyz, rgb, n_obj, rows, n_rows,
+                       n_cent * (kMaxNbr + 1));
+    T2P_CHECK_LAUNCH("dedup_rows");
+    return 0;
+}
 
 int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float radius[3], GroupTables gt,
                         hipStream_t st) {

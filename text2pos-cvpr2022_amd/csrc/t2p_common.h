@@ -139,10 +139,14 @@ struct GroupTables {
     const float* b1;
     const float* rgb;       // [n_obj][n_pts][3]
     int H1;
-    uint32_t* guard;        // nullptr, or the chunk's GuardSlot words: max|A_1|, max|B_l| are reported here
+    uint32_t* guard;        // nullptr, or the chunk's GuardSlot words (the input magnitude is reported here)
 };
 int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float radius[3], GroupTables gt,
                         hipStream_t st);
+// Drops from level 0's compact row lists the edges of points that repeat an earlier point of their object bit for bit
+// (identical message, so the max-aggregate is unchanged); updates n_rows.  rows [n_obj][n_cent * 33], n_pts = 256.
+int launch_dedup_rows(const float* xyz, const float* rgb, int64_t n_obj, int n_pts, uint16_t* rows, uint16_t* n_rows,
+                      int n_cent, hipStream_t st);
 
 // ---- tables.hip / small kernels ------------------------------------------------------------------------------
 // gather level-l centroid positions: out[(o*n_cent + c), 0..2]

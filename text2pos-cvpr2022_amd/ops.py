@@ -75,6 +75,19 @@ def sample_group(xyz: torch.Tensor, radius=(0.2, 0.3, 0.4)):
     return out
 
 
+def dedup_rows(xyz: torch.Tensor, rgb: torch.Tensor, rows: torch.Tensor, n_rows: torch.Tensor):
+    """In-place t2p_dedup_rows: rows uint16 [n_obj, (n_pts / 2) * 33] (as int16 storage), n_rows uint16 [n_obj] (int16)."""
+    _need(xyz, "xyz", torch.float32, 3)
+    _need(rgb, "rgb", torch.float32, 3, xyz.device)
+    _need(rows, "rows", torch.int16, 2, xyz.device)
+    _need(n_rows, "n_rows", torch.int16, 1, xyz.device)
+    n_obj, n_pts = xyz.shape[0], xyz.shape[1]
+    if rows.shape[0] != n_obj or rows.shape[1] != ((n_pts + 1) // 2) * 33 or n_rows.numel() != n_obj:
+        raise RuntimeError("dedup_rows: inconsistent shapes")
+    L.check(L.lib().t2p_dedup_rows(_ptr(xyz), _ptr(rgb), n_obj, n_pts, _ptr(rows), _ptr(n_rows), _stream(xyz.device)),
+            "t2p_dedup_rows")
+
+
 def knn(x: torch.Tensor, seg_ptr: torch.Tensor, k: int, max_seg_rows: Optional[int] = None) -> torch.Tensor:
     _need(x, "x", torch.float32, 2)
     _need(seg_ptr, "seg_ptr", torch.int32, 1, x.device)
@@ -132,7 +145,7 @@ def sim_topk(queries: torch.Tensor, cells: torch.Tensor, k: int, index_offset: i
 def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features=("class", "color", "position"),
                      self_loops=True, knn_k=8, variation=0, radius=(0.2, 0.3, 0.4), chunk_objects=0,
                      precision="f16x3", class_idx=None, color_idx=None, objects_only=False,
-                     overflow_flag=None) -> L.CellConfig:
+                     overflow_flag=None, tuning=0) -> L.CellConfig:
     """class_idx / color_idx: int32 device tensors [n_obj] enabling the --class_embed / --color_embed ablations.
     overflow_flag: int32 device tensor [1], the sticky fp16-range guard word of the f16x3 path (include/t2p.h)."""
     cfg = L.CellConfig()
@@ -152,6 +165,7 @@ def make_cell_config(n_pts=256, embed_dim=256, pointnet_features=2, use_features
             _need(t, name + "_idx", torch.int32, 1)
             setattr(cfg, name + "_embed", 1)
             setattr(cfg, name + "_idx", t.data_ptr())
+    cfg.tuning = int(tuning)
     if overflow_flag is not None:
         _need(overflow_flag, "overflow_flag", torch.int32, 1)
         cfg.overflow_flag = overflow_flag.data_ptr()
