@@ -176,6 +176,12 @@ def main():
     ap.add_argument("--bn", choices=["calibrated", "random"], default="calibrated",
                     help="BatchNorm running statistics of the random-init model: calibrated on 64 cells of the workload "
                          "(default) or drawn at random (SURVEY 8(d); embeddings then collapse onto one direction)")
+    ap.add_argument("--cell-streams", type=int, choices=[1, 2], default=1,
+                    help="HIP streams of the cell encoder in the timed region: 2 = the two halves of the batch run "
+                         "concurrently (own workspaces).  Default 1: an event pair around a launch then times that kernel "
+                         "alone, which is what `roofline` and the rocprofv3 summary need; the two-stream rate is measured "
+                         "right after the timed region and reported as `two_stream`")
+    ap.add_argument("--no-two-stream", action="store_true", help="skip the extra two-stream measurement")
     ap.add_argument("--tuning", type=int, default=0, help="t2p_cell_config.tuning (A/B between equivalent execution plans)")
     ap.add_argument("--no-fp32-pass", action="store_true", help="skip the extra exact-fp32 pass behind the timed region")
     ap.add_argument("--fp32-steps", type=int, default=2)
@@ -265,7 +271,8 @@ def main():
                 queries = model.language_encoder.encode_tokens(d_tok, d_len, normalize=True)
             # the fp16-range guard accumulates in a device word during the step; it is read once after the timed region
             cells = model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
-                                                chunk_objects=args.chunk_objects, check_overflow=False)
+                                                chunk_objects=args.chunk_objects, check_overflow=False,
+                                                streams=args.cell_streams)
             if world > 1:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(main)
@@ -316,6 +323,34 @@ def main():
                     "all_gather_ms_per_rank": [round(float(v), 4) for v in per_rank.tolist()],
                     "note": "mean over the timed steps of the event-bracketed collective on each rank (includes waiting "
                             "for the slowest rank's encoder)"}
+
+    # ---- the same step with the cell encoder's two halves on two HIP streams (each kernel launch fills the CUs, so what
+    # overlaps is one half's work under the tails of the other's kernels and under the small launch-bound kernels)
+    two_stream = None
+    if args.cell_streams == 1 and not args.no_two_stream:
+        saved_streams, args.cell_streams = args.cell_streams, 2
+        try:
+            step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                idx2, _ = step()
+            barrier()
+            e2 = time.perf_counter() - t1
+        finally:
+            args.cell_streams = saved_streams
+        if world > 1:
+            t = torch.tensor([e2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t.item())
+        assert torch.equal(idx2, idx), "two-stream run retrieved different cells"
+        two_stream = {"ms_per_step": e2 / args.steps * 1e3, "value": (n_cells_total + n_q_total) / (e2 / args.steps),
+                      "unit": "cells+queries/s", "steps": args.steps,
+                      "note": "same step, cell batch cut into two halves on two HIP streams (encode_objects_packed(streams=2)); "
+                              "identical top-k; not the headline because per-kernel event timings overlap in this mode"}
+        if guard_code == 0 and args.precision == "f16x3" and model.overflow_detected():
+            raise SystemExit("fp16-range guard fired in the two-stream run")
+        log(f"two streams: {two_stream['ms_per_step']:.2f} ms per step")
 
     # ---- one pass of the same step on the exact fp32 MFMA path (outside the headline timing), and the precision evidence
     fp32_info = None
@@ -473,6 +508,8 @@ def main():
             "host_generation_s": round(gen_s, 2),
             "fp16_range_guard": "clear" if args.precision == "f16x3" else "n/a (fp32)",
         }
+        if two_stream:
+            out["two_stream"] = two_stream
         if fp32_info:
             out.update(fp32_info)
         if exchange:

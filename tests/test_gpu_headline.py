@@ -608,3 +608,8 @@ def test_execution_plans_are_bit_identical(hip_model):
         assert torch.equal(out, outs[0][0]) and torch.equal(tr["obj_emb"], outs[0][1]["obj_emb"])
         for l in range(3):
             assert torch.equal(tr["sa_out"][l], outs[0][1]["sa_out"][l]), f"SA{l + 1} output"
+    # the two halves of the batch on two HIP streams (own workspaces) give the same rows
+    with torch.no_grad():
+        two = hip_model.encode_objects_packed(*args, cell_ptr, streams=2)
+        again = hip_model.encode_objects_packed(*args, cell_ptr, streams=2)
+    assert torch.equal(two, outs[0][0]) and torch.equal(again, two)

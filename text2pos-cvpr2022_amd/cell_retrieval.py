@@ -115,14 +115,17 @@ class CellRetrievalNetwork(nn.Module):
                                       "torch.no_grad(), or put the model in train() for the training-mode path")
 
     def encode_objects_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, cell_ptr_dev=None, want_trace=False,
-                              chunk_objects=0, class_idx=None, color_idx=None, check_overflow=True):
+                              chunk_objects=0, class_idx=None, color_idx=None, check_overflow=True, streams=1):
         """Device-resident packed inputs: xyz/rgb [Nobj, P, 3], center/mean_rgb [Nobj, 3] (fp32, on self.device),
         cell_ptr int32 [B+1] on the host.  Returns [B, D] L2-normalised.  In train() mode (training/coarse.py:32) the
         batch-statistics path of train_cell.py runs instead of the folded inference kernels and the result carries a
         grad_fn.
         check_overflow (f16x3 only): read the fp16-range guard word after the launch (one host synchronisation; the
         reference's callers move the result to the host right away, training/coarse.py:115) and act as `on_overflow` says.
-        Pipelined callers pass False and call overflow_detected() once their stream has drained."""
+        Pipelined callers pass False and call overflow_detected() once their stream has drained.
+        streams=2: the batch is cut into two halves (whole cells) that run on the current stream and on a second HIP
+        stream with its own workspace; the kernels of a call fill every CU, so the gain is the other half's work under each
+        kernel's tail (measured 1.8 %, profiles/microbench/two_stream_overlap.py).  Cells are independent: same result."""
         if self.training and not want_trace:
             from .train_cell import encode_objects_train
             return encode_objects_train(self, xyz, rgb, center, mean_rgb, cell_ptr, class_idx, color_idx)
@@ -132,6 +135,9 @@ class CellRetrievalNetwork(nn.Module):
             cell_ptr_dev = torch.from_numpy(cp).to(self.device)
         if "color" not in self.args.use_features and not getattr(self.args, "class_embed", False):
             rgb = torch.zeros_like(rgb)   # models/object_encoder.py:86-90: the PointNet++ then sees x = 0
+        if streams == 2 and not want_trace and cp.shape[0] > 2 and self.precision in ("f16x3", "fp32"):
+            return self._encode_two_streams(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx, color_idx,
+                                            check_overflow)
         cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx)
         out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
         if check_overflow and self.precision == "f16x3" and cp.shape[0] > 1:
@@ -144,6 +150,46 @@ class CellRetrievalNetwork(nn.Module):
                 warnings.warn(msg + "; recomputing this call on the exact fp32 path", RuntimeWarning)
                 cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx, precision="fp32")
                 out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
+        return out
+
+    def _encode_two_streams(self, xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx, color_idx,
+                            check_overflow):
+        dev = self.device
+        n_cells = cp.shape[0] - 1
+        half = int(np.searchsorted(cp, cp[-1] // 2))          # first cell whose start lies past half of the objects
+        half = min(max(half, 1), n_cells - 1)
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_aux_stream", None) is None:
+            self._aux_stream = torch.cuda.Stream(device=dev)
+        aux = self._aux_stream
+        out = torch.empty((n_cells, self.embed_dim), dtype=torch.float32, device=dev)
+        out.record_stream(aux)
+        pack = self._cell_pack()
+        aux.wait_stream(main)
+        for (c0, c1), st, tag in (((half, n_cells), aux, "encode_cells#2"), ((0, half), main, "encode_cells")):
+            o0, o1 = int(cp[c0]), int(cp[c1])
+            with torch.cuda.stream(st):
+                sub = [t[o0:o1] for t in (xyz, rgb, center, mean_rgb)]
+                ci = None if class_idx is None else class_idx[o0:o1].contiguous()
+                co = None if color_idx is None else color_idx[o0:o1].contiguous()
+                cfg = self._cell_config(xyz.shape[1], chunk_objects, ci, co)
+                cpd = cell_ptr_dev[c0: c1 + 1] - o0 if o0 else cell_ptr_dev[c0: c1 + 1]
+                out[c0:c1] = ops.encode_cells(*sub, cp[c0: c1 + 1] - o0, cpd.contiguous(), pack, cfg, False, ws_tag=tag)
+                if st is aux:
+                    for t in (xyz, rgb, center, mean_rgb, cell_ptr_dev):
+                        t.record_stream(aux)
+        main.wait_stream(aux)
+        if check_overflow and self.precision == "f16x3" and self.overflow_detected():
+            if self.on_overflow != "fp32":
+                raise FloatingPointError("f16x3 path: an activation left fp16's range; construct the model with "
+                                         "precision=\"fp32\" or on_overflow=\"fp32\"")
+            warnings.warn("f16x3 path: an activation left fp16's range; recomputing on the exact fp32 path", RuntimeWarning)
+            saved, self.precision = self.precision, "fp32"
+            try:
+                return self._encode_two_streams(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx,
+                                                color_idx, False)
+            finally:
+                self.precision = saved
         return out
 
     def encode_objects_packed_host(self, xyz, rgb, center, mean_rgb, cell_ptr, cells_per_chunk=2048):

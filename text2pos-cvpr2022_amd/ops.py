@@ -222,7 +222,7 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
 
 
 def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr_dev, weights: L.CellWeights,
-                 cfg: L.CellConfig, want_trace=False):
+                 cfg: L.CellConfig, want_trace=False, ws_tag: str = "encode_cells"):
     """Cell branch on packed, device-resident inputs.  Returns out [n_cells, D] (and a dict of stage outputs when
     want_trace is True or names some of them; knn_idx rows are local to the internal chunk of <= chunk_objects objects)."""
     _need(xyz, "xyz", torch.float32, 3)
@@ -290,7 +290,7 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
         big_cfg = L.CellConfig.from_buffer_copy(cfg)
         big_cfg.chunk_objects = biggest
         nbytes = max(nbytes, L.lib().t2p_encode_cells_workspace_bytes(n_obj, n_cells, C.byref(big_cfg)))
-    ws = workspace(dev, nbytes, "encode_cells")
+    ws = workspace(dev, nbytes, ws_tag)   # (one scratch buffer per tag: concurrent calls on two streams need two tags)
     rc = L.lib().t2p_encode_cells(_ptr(xyz), _ptr(rgb), _ptr(center), _ptr(mean_rgb),
                                   cp.ctypes.data_as(C.c_void_p), _ptr(cell_ptr_dev), n_obj, n_cells, C.byref(weights),
                                   C.byref(cfg), _ptr(out) if out is not None else None,
