@@ -128,6 +128,8 @@ typedef struct t2p_cell_weights {
     float sa_wp_l1[3];
     float sa_a1_l1;
     float sa_b1_absmax;
+    /* optional f16x3 image (packing.py::pack_f16x3 layout, as ga_w2_x3) of g_w2, DynamicEdgeConv's second layer */
+    const void* g_w2_x3;
 } t2p_cell_weights;
 
 typedef struct t2p_cell_config {

@@ -29,7 +29,7 @@ class CellWeights(C.Structure):
                  ("sa_w1_x3", c_void * 3), ("ga_w1_x3", c_void),
                  ("class_embedding", c_void), ("color_embedding", c_void),
                  ("ga_w1_l1", C.c_float), ("ga_b1_absmax", C.c_float), ("sa_wp_l1", C.c_float * 3),
-                 ("sa_a1_l1", C.c_float), ("sa_b1_absmax", C.c_float)])
+                 ("sa_a1_l1", C.c_float), ("sa_b1_absmax", C.c_float), ("g_w2_x3", c_void)])
 
 
 class CellConfig(C.Structure):

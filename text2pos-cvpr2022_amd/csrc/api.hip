@@ -437,6 +437,8 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.lda = D;
         p.Bc = ws.P;
         p.W = W.g_w2;
+        p.W_x3 = (cfg.precision == 1 && D == 256) ? W.g_w2_x3 : nullptr;   // f16x3 image of layer 2 (falls back to fp32 MFMA)
+        p.amax_out = gslot(G_GEMM_IN);                                      // (here: the rows this kernel splits itself)
         p.ldw = D;
         p.bias = W.g_b2;
         p.out = ws.x1;

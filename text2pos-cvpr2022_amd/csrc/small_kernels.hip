@@ -63,24 +63,59 @@ __global__ void k_segpool(const float* __restrict__ in, int dim, const int32_t* 
 }
 
 // kNN graph inside one segment (cell): all-pairs squared distances in LDS, then a k-pass ordered selection.
-// Distance pinned to the sequential fp32 form acc = acc + (a-b)*(a-b), no FMA (oracle/primitives.c).
+// Distance pinned to the sequential fp32 form acc = acc + (a-b)*(a-b), no FMA (oracle/primitives.c); it is symmetric bit
+// for bit ((a-b)^2 == (b-a)^2), so only the n (n + 1) / 2 pairs j >= i are formed - enumerated densely over the threads -
+// and, for cells of up to kKnnStage rows, from a copy of the rows in LDS (16-byte reads, row stride padded by 16 B) instead
+// of two dependent 4-byte global loads per term.
+constexpr int kKnnStage = 64;
 __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int dim, const int32_t* __restrict__ seg_ptr,
-                                             int k, int32_t* __restrict__ out_idx) {
+                                             int k, int32_t* __restrict__ out_idx, int stage_rows) {
 #pragma clang fp contract(off)
-    extern __shared__ float dmat[];
+    extern __shared__ __attribute__((aligned(16))) float dmat[];   // [n][n] distances | [n][dim + 4] staged rows
     int s = blockIdx.x;
     int lo = seg_ptr[s], hi = seg_ptr[s + 1];
     int n = hi - lo;
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
-        int i = e / n, j = e - i * n;
-        if (j < i) continue;  // symmetric: (a-b)^2 == (b-a)^2 exactly
-        const float* a = x + (int64_t)(lo + j) * dim;
-        const float* b = x + (int64_t)(lo + i) * dim;
+    const bool staged = n <= stage_rows && (dim & 3) == 0;
+    const int ld = dim + 4;
+    float* xs = dmat + ((n * n + 3) & ~3);
+    if (staged) {
+        const int q4 = dim >> 2;
+        for (int e = threadIdx.x; e < n * q4; e += blockDim.x) {
+            const int r = e / q4, c = e - r * q4;
+            *(f32x4*)(xs + r * ld + c * 4) = *(const f32x4*)(x + (int64_t)(lo + r) * dim + c * 4);
+        }
+        __syncthreads();
+    }
+    const int n_pairs = n * (n + 1) / 2;
+    for (int e = threadIdx.x; e < n_pairs; e += blockDim.x) {
+        // pair e of the upper triangle, row-major: row i starts at i n - i (i - 1) / 2
+        int a_lo = 0, a_hi = n - 1;
+        while (a_lo < a_hi) {
+            const int m = (a_lo + a_hi + 1) >> 1;
+            if (m * n - m * (m - 1) / 2 <= e) a_lo = m; else a_hi = m - 1;
+        }
+        const int i = a_lo, j = i + (e - (i * n - i * (i - 1) / 2));
         float acc = 0.f;
-        for (int t = 0; t < dim; t++) {
-            float df = a[t] - b[t];
-            float sq = df * df;
-            acc = acc + sq;
+        if (staged) {
+            const float* a = xs + j * ld;
+            const float* b = xs + i * ld;
+            for (int t = 0; t < dim; t += 4) {
+                const f32x4 av = *(const f32x4*)(a + t), bv = *(const f32x4*)(b + t);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    float df = av[u] - bv[u];
+                    float sq = df * df;
+                    acc = acc + sq;
+                }
+            }
+        } else {
+            const float* a = x + (int64_t)(lo + j) * dim;
+            const float* b = x + (int64_t)(lo + i) * dim;
+            for (int t = 0; t < dim; t++) {
+                float df = a[t] - b[t];
+                float sq = df * df;
+                acc = acc + sq;
+            }
         }
         dmat[i * n + j] = acc;
         dmat[j * n + i] = acc;
@@ -496,10 +531,20 @@ int launch_knn(const float* x, int dim, const int32_t* seg_ptr, int n_seg, int m
     const int kMaxRows = 192;
     T2P_CHECK_ARG(max_seg_rows >= 0 && max_seg_rows <= kMaxRows, "knn: a cell with %d objects exceeds the %d-row limit",
                   max_seg_rows, kMaxRows);
-    size_t lds = (size_t)(max_seg_rows > 0 ? max_seg_rows : 1) * max_seg_rows * sizeof(float);
-    T2P_TRY(reserve_lds((const void*)k_knn, (size_t)kMaxRows * kMaxRows * sizeof(float), "knn"));
+    size_t lds = (size_t)(((max_seg_rows > 0 ? max_seg_rows : 1) * max_seg_rows + 3) & ~3) * sizeof(float);
+    // cells of up to kKnnStage rows keep a copy of their rows in LDS behind the distance matrix, when both fit
+    int stage_arg = 0;
+    if (dim <= 512 && (dim & 3) == 0) {
+        const int stage_rows = max_seg_rows < kKnnStage ? max_seg_rows : kKnnStage;
+        const size_t extra = (size_t)stage_rows * (dim + 4) * sizeof(float);
+        if (lds + extra <= 160 * 1024) {
+            lds += extra;
+            stage_arg = stage_rows;
+        }
+    }
+    T2P_TRY(reserve_lds((const void*)k_knn, 160 * 1024, "knn"));
     ProfScope ps_("knn", st);
-    hipLaunchKernelGGL(k_knn, dim3(n_seg), dim3(256), lds, st, x, dim, seg_ptr, k, out_idx);
+    hipLaunchKernelGGL(k_knn, dim3(n_seg), dim3(256), lds, st, x, dim, seg_ptr, k, out_idx, stage_arg);
     T2P_CHECK_LAUNCH("knn");
     return 0;
 }

@@ -61,7 +61,6 @@ struct WsCfg {
     }
     static_assert(K % 8 == 0, "K must be a multiple of 8");
     static_assert(!X3 || K % 32 == 0, "f16x3 needs K % 32 == 0");
-    static_assert(!X3 || !EDGE, "the kNN edge mode is fp32 only");
     static_assert(NW % (32 * WN) == 0, "NW must split into 32-column tiles per wave");
 };
 
@@ -159,6 +158,7 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
         }
     };
     // VALU part + LDS write of the staged batch.
+    float gmax_edge = 0.f;
     auto stage_write = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < C::ITERS; it++) {
@@ -178,6 +178,8 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                 *(f32x4*)(hidh + buf * 2 * C::PLANE + pl * C::PLANE + prow * C::LDHH + c8 * 8) = sa[it];
             } else if constexpr (X3) {
                 _Float16* dsth = hidh + buf * 2 * C::PLANE;
+                if constexpr (C::EDGE)   // fp16-range guard: the kNN edge rows relu(P_i + Q_j) are split here and nowhere reported
+                    gmax_edge = fmaxf(fmaxf(gmax_edge, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                 const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                 const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.f, (v[1] - (float)h01[1]) * 2048.f);
                 const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * 2048.f, (v[3] - (float)h23[1]) * 2048.f);
@@ -442,6 +444,7 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
             }
             __syncthreads();
         }
+        if constexpr (X3) guard_publish(p.amax_out, gmax_edge);
     }
 }
 
@@ -488,8 +491,9 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
 #define WS_CASE(MODE_, K_, N_, NW_, WN_, RT_, X3_, SIO_)                                      \
     if (mode == MODE_ && K == K_ && N == N_ && x3 == X3_ && split_io == SIO_)                  \
         return launch_cfg<K_, NW_, WN_, RT_, MODE_, X3_, SIO_>(p, N_ / NW_, st);
-    // DynamicEdgeConv layer 2 (fp32)
+    // DynamicEdgeConv layer 2 (fp32 / f16x3)
     WS_CASE(WS_EDGE_KNN, 256, 256, 256, 8, 1, 0, 0)  // 8 waves, one 32-column block each (128 weight registers)
+    WS_CASE(WS_EDGE_KNN, 256, 256, 256, 8, 1, 1, 0)
     // SA2 / SA3 layer-1 point tables ([feat | pos | zero pad] -> H) and GA layer 1
     WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 0, 0)
     WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 0, 0)

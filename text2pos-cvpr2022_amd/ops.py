@@ -204,7 +204,7 @@ def make_cell_weights(packed: Dict[str, object]) -> L.CellWeights:
             _need(img, name + "_x3", torch.int16)
             setattr(w, name + "_x3", img.data_ptr())
             setattr(w, name + "_scale", float(packed[name + "_scale"]))
-    for name in ("ga_w1_x3", "ga_w2_x3"):
+    for name in ("ga_w1_x3", "ga_w2_x3", "g_w2_x3"):
         g = packed.get(name)
         if g is not None:
             _need(g, name, torch.int16)

@@ -133,6 +133,8 @@ def _add_x3_images(p: Dict[str, object], device, cell_head: bool):
             ((("g_wp", "g_wp"), ("g_wq", "g_wq")) if cell_head else ()):
         sc = f16x3_scale(p[src])
         p[name + "_scale"], p[name + "_x3"] = sc, pack_gemm_x3(p[src], sc).to(device)
+    if cell_head and p["g_w2"].shape[0] % 32 == 0 and p["g_w2"].shape[1] % 32 == 0:
+        p["g_w2_x3"] = pack_f16x3(p["g_w2"]).to(device)
 
 
 def _pack_cell_weights_fp32(model, device) -> Dict[str, object]:
