@@ -4,14 +4,14 @@
 tag=${1:-r01_j}
 cd /root/repo; export TMPDIR=/tmp
 mkdir -p gpurun_out/$tag
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/$tag/pytest.txt
-timeout 600 python bench.py 2> gpurun_out/$tag/bench.err | tail -1 > gpurun_out/$tag/bench.json
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/$tag/pytest.txt
+timeout 600 python bench.py --steps 20 --warmup 5 2> gpurun_out/$tag/bench.err | tail -1 > gpurun_out/$tag/bench.json
 timeout 600 python bench_fine.py 2> gpurun_out/$tag/bench_fine.err | tail -1 > gpurun_out/$tag/bench_fine.json
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats -o s -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats -o s -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream > gpurun_out/$tag/stats.log 2>&1
 db=$(find gpurun_out/$tag/stats -name "*.db" | head -1)
-python profiles/summarize.py $db gpurun_out/$tag/kernel_stats.md "$tag: python bench.py --steps 3 --warmup 1 --no-cpu-baseline (12k cells + 1k queries, 1 x MI355X)" > /dev/null
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/$tag/fetch -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/$tag/write -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/write.log 2>&1
+python profiles/summarize.py $db gpurun_out/$tag/kernel_stats.md "$tag: python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream (12k cells + 1k queries, 1 x MI355X)" > /dev/null
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/$tag/fetch -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream > gpurun_out/$tag/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/$tag/write -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream > gpurun_out/$tag/write.log 2>&1
 python profiles/pmc_traffic.py gpurun_out/$tag/fetch gpurun_out/$tag/write gpurun_out/$tag/pmc_traffic.json > /dev/null
 # keep the merge small: drop the raw traces
 find gpurun_out/$tag -name "*.db" -delete; find gpurun_out/$tag -name "*.csv" -delete

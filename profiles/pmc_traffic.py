@@ -45,7 +45,7 @@ def main():
         kernels[k] = {"launches": n, "fetch_bytes_per_launch_raw": fetch, "fetch_bytes_per_launch_corrected_x2": 2 * fetch,
                       "write_bytes_per_launch": write, "hbm_bytes_per_launch": 2 * fetch + write}
     json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py "
-                          "--steps 1 --warmup 1 --no-cpu-baseline",
+                          "--steps 1 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream",
                "units": "bytes; FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE doubled per the gfx950 note in "
                         "MI355X_MICROARCH.md (HBM section); WRITE_SIZE uncalibrated",
                "kernels": kernels}, open(out, "w"), indent=1)

@@ -1,6 +1,7 @@
 """Parameter container mirroring models/object_encoder.py::ObjectEncoder (same constructor, same state_dict keys).
-Its forward runs inside CellRetrievalNetwork.encode_objects on the HIP path; the ground-truth class/colour embedding
-ablations (`--class_embed`, `--color_embed`, models/object_encoder.py:74-84,103-120) are not built.
+Its forward runs inside CellRetrievalNetwork.encode_objects / SuperGlueMatch.forward on the HIP path (t2p_encode_cells in
+eval mode, train_cell.py in train mode), including the ground-truth class / colour embedding ablations (`--class_embed`,
+`--color_embed`, models/object_encoder.py:74-84,103-120); calling this module directly raises.
 """
 from typing import List
 
