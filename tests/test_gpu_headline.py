@@ -614,3 +614,36 @@ def test_execution_plans_are_bit_identical(hip_model):
         two = hip_model.encode_objects_packed(*args, cell_ptr, streams=2)
         again = hip_model.encode_objects_packed(*args, cell_ptr, streams=2)
     assert torch.equal(two, outs[0][0]) and torch.equal(again, two)
+
+
+@pytest.mark.parametrize("variation", [0, 1])
+def test_coarse_model_at_embed_dim_128(vocab, variation):
+    """--embed_dim 128 (training/args.py:19 makes it a free parameter): cell branch, text branch and retrieval against the
+    oracle; both aggregation variants of the cell graph."""
+    import weights as W
+    import text2pos_amd as t2p
+    from oracle import model as OM
+    from oracle.model import retrieve_topk_f64
+    from text2pos_amd import synthetic as S
+    kw = dict(embed_dim=128, variation=variation)
+    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(**kw)).eval()
+    W.fill_state_dict(om, 31)
+    for precision in ("f16x3", "fp32"):
+        hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(**kw), precision=precision)
+        hm.load_state_dict(om.state_dict(), strict=True)
+        hm = hm.to(_dev()).eval()
+        xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(401, 7)
+        assert int(cell_ptr[-1]) == 123
+        # cells of 3 and 2 objects (fewer than k = 8 neighbours) and one of 70 (beyond the kNN kernel's LDS-staged size)
+        cell_ptr = np.concatenate([[0], np.cumsum([9, 3, 12, 20, 2, 7, 70])]).astype(np.int32)
+        texts = S.make_texts(401, 0, 9)
+        want_c = om.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)
+        want_q = om.encode_text(texts)
+        with torch.no_grad():
+            got_c = hm.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr)
+            got_q = hm.encode_text(texts)
+        assert got_c.shape == (7, 128) and (got_c.cpu() - want_c).abs().max().item() < TOL, precision
+        assert (got_q.cpu() - want_q).abs().max().item() < TOL
+        idx, score = t2p.retrieve_topk(got_c, got_q, 5)
+        widx, wscore = retrieve_topk_f64(got_c.cpu().numpy(), got_q.cpu().numpy(), 5)
+        assert np.array_equal(idx.cpu().numpy(), widx) and np.abs(score.cpu().numpy() - wscore).max() < 1e-12

@@ -188,8 +188,8 @@ int check_cfg(const t2p_cell_config* cfg) {
             set_error("encode_cells: objects_only supports embed_dim in {64, 128, ..., 512}, got %d", cfg->embed_dim);
             return T2P_E_UNSUPPORTED;
         }
-    } else if (cfg->embed_dim != 256) {
-        set_error("encode_cells: embed_dim=%d not built for the cell head (256)", cfg->embed_dim);
+    } else if (cfg->embed_dim != 256 && cfg->embed_dim != 128) {
+        set_error("encode_cells: embed_dim=%d not built for the cell head (128, 256)", cfg->embed_dim);
         return T2P_E_UNSUPPORTED;
     }
     T2P_CHECK_ARG(cfg->variation == 0 || cfg->variation == 1, "encode_cells: variation=%d (0 = max, 1 = mean)",
@@ -437,7 +437,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.lda = D;
         p.Bc = ws.P;
         p.W = W.g_w2;
-        p.W_x3 = (cfg.precision == 1 && D == 256) ? W.g_w2_x3 : nullptr;   // f16x3 image of layer 2 (falls back to fp32 MFMA)
+        p.W_x3 = cfg.precision == 1 ? W.g_w2_x3 : nullptr;   // f16x3 image of layer 2 (absent: fp32 MFMA)
         p.amax_out = gslot(G_GEMM_IN);                                      // (here: the rows this kernel splits itself)
         p.ldw = D;
         p.bias = W.g_b2;

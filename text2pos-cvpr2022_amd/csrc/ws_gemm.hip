@@ -494,6 +494,8 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
     // DynamicEdgeConv layer 2 (fp32 / f16x3)
     WS_CASE(WS_EDGE_KNN, 256, 256, 256, 8, 1, 0, 0)  // 8 waves, one 32-column block each (128 weight registers)
     WS_CASE(WS_EDGE_KNN, 256, 256, 256, 8, 1, 1, 0)
+    WS_CASE(WS_EDGE_KNN, 128, 128, 128, 4, 1, 0, 0)  // embed_dim 128: 4 waves, one 32-column block each
+    WS_CASE(WS_EDGE_KNN, 128, 128, 128, 4, 1, 1, 0)
     // SA2 / SA3 layer-1 point tables ([feat | pos | zero pad] -> H) and GA layer 1
     WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 0, 0)
     WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 0, 0)
