@@ -385,6 +385,13 @@ int t2p_knn(const float* x, int32_t dim, const int32_t* seg_ptr, int32_t n_seg, 
 /* C[M][ldc] (+c0) = act(A[M][lda] W[K][N] + bias[N]);  K % 4 == 0, N % 8 == 0, lda % 4 == 0 */
 int t2p_gemm(const float* a, int32_t lda, const float* w, const float* bias, float* c, int32_t ldc, int32_t c0,
              int64_t m, int32_t k, int32_t n, int32_t relu, t2p_stream_t stream);
+/* C[k1][n] (ldc) = A[m][k1]^T B[m][n]: a product whose reduction runs over the ROWS - the weight gradient dW = dY^T X of
+ * every nn.Linear, the recurrent / input weight gradients of the LSTM and its gate-table gradient in the training-mode path
+ * (training/coarse.py:31-62 through autograd).  The rows are split over the grid and the partial products added in a fixed
+ * order (deterministic); fp32 MFMA.  workspace: t2p_gemm_tn_workspace_bytes. */
+size_t t2p_gemm_tn_workspace_bytes(int64_t m, int32_t k1, int32_t n);
+int t2p_gemm_tn(const float* a, int32_t lda, const float* b, int32_t ldb, float* c, int32_t ldc, int64_t m, int32_t k1, int32_t n,
+                void* workspace, size_t workspace_bytes, t2p_stream_t stream);
 /* F.normalize(x, dim=-1), eps 1e-12 */
 int t2p_rownorm(const float* x, int64_t n_rows, int32_t dim, float* out, t2p_stream_t stream);
 

@@ -96,6 +96,21 @@ def test_gemm_matches_fp64(m, k, n):
     assert (got.double() - want).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("m,k1,n", [(1, 4, 8), (37, 67, 128), (5000, 256, 1024), (100003, 32, 6), (3, 1024, 512), (0, 8, 8)])
+def test_gemm_tn_matches_fp64(m, k1, n):
+    """t2p_gemm_tn: A^T B with the reduction over the rows split across the grid (weight gradients of the training path);
+    against float64, bit-deterministic from run to run."""
+    from text2pos_amd import ops
+    g = torch.Generator().manual_seed(m * 3 + k1)
+    a = torch.randn(m, k1, generator=g)
+    b = torch.randn(m, n, generator=g)
+    got = ops.gemm_tn(a.to(_dev()), b.to(_dev()))
+    again = ops.gemm_tn(a.to(_dev()), b.to(_dev()))
+    want = a.double().t() @ b.double()
+    assert got.shape == (k1, n) and torch.equal(got, again)
+    assert (got.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, m ** 0.5)
+
+
 def test_rownorm():
     from text2pos_amd import ops
     x = torch.randn(77, 256)

@@ -108,6 +108,9 @@ SYMBOLS = {
     "t2p_gemm": (C.c_int, [c_void, C.c_int32, c_void, c_void, c_void, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                            C.c_int32, C.c_int32, c_void]),
     "t2p_rownorm": (C.c_int, [c_void, C.c_int64, C.c_int32, c_void, c_void]),
+    "t2p_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "t2p_gemm_tn": (C.c_int, [c_void, C.c_int32, c_void, C.c_int32, c_void, C.c_int32, C.c_int64, C.c_int32, C.c_int32, c_void,
+                              C.c_size_t, c_void]),
 }
 
 _lib = None

@@ -181,6 +181,11 @@ int launch_gemm_x3(const float* A, int lda, const void* Wx, float scale, const f
                    int64_t M, int K, int N, int relu, hipStream_t st, const float* resid = nullptr, int ldr = 0,
                    uint32_t* amax_in = nullptr /* f16x3 guard word for the rows of A */);
 
+// tg_gemm_tn.hip: C[K1, N] = A[M, K1]^T B[M, N], rows split over the grid + fixed-order reduction (training-mode gradients)
+size_t gemm_tn_workspace_bytes(int64_t M, int K1, int N);
+int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int64_t M, int K1, int N, void* ws,
+                   size_t ws_bytes, hipStream_t st);
+
 // ---- ws_gemm.hip: weight-stationary streaming fp32-MFMA kernels ---------------------------------------------
 enum WsMode { WS_DENSE_STORE = 0, WS_DENSE_GROUPMAX = 1, WS_EDGE_KNN = 3 };
 struct WsParams {

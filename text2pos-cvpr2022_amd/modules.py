@@ -91,16 +91,16 @@ class _LstmTrainFn(torch.autograd.Function):
                 dh_gemm = ops.gemm(d_pre[s], whh_t) if s > 0 else None
                 dc, dh_carry = dc_new, carry_new
             flat = d_pre.reshape(t * b, 4 * d)
-            d_whh_k = hs[dr, :t].reshape(t * b, d).t() @ flat                             # [D, 4D]
+            d_whh_k = ops.gemm_tn(hs[dr, :t].reshape(t * b, d), flat)                     # [D, 4D] = H^T dPre
             # gate-table gradient: rows of d_pre summed per token (one-hot product: deterministic, V is ~40)
             pos = steps if dr == 0 else (ln - 1 - steps).clamp(min=0)                     # token position of (step, sequence)
             tok = torch.gather(tokens.to(torch.int64).t(), 0, pos.expand(t, b))           # [T, B]
-            onehot = torch.zeros((v, t * b), dtype=torch.float32, device=dev)
-            onehot.scatter_(0, tok.reshape(1, t * b), active.reshape(1, t * b).to(torch.float32))
-            d_table = onehot @ flat                                                       # [V, 4D]
+            onehot_t = torch.zeros((t * b, v), dtype=torch.float32, device=dev)
+            onehot_t.scatter_(1, tok.reshape(t * b, 1), active.reshape(t * b, 1).to(torch.float32))
+            d_table = ops.gemm_tn(onehot_t, flat)                                         # [V, 4D]: one-hot^T dPre
             d_bias = d_table.sum(0)
-            d_wih_k = emb_c.t() @ d_table                                                 # [D, 4D]
-            d_emb += d_table @ wih_k.t()
+            d_wih_k = ops.gemm_tn(emb_c, d_table)                                         # [D, 4D] = E^T dTable
+            d_emb += ops.matmul(d_table, wih_k.t().contiguous())
             grads += [d_wih_k.t().contiguous(), d_whh_k.t().contiguous(), d_bias, d_bias.clone()]
         d_emb[0].zero_()                                                                  # nn.Embedding(padding_idx=0)
         return (None, None, d_emb) + tuple(grads)

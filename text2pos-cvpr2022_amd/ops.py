@@ -116,6 +116,46 @@ def gemm(a: torch.Tensor, w_kmajor: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a [M, K] @ b [K, N] on the tiled fp32-MFMA GEMM (t2p_gemm) for any sizes: K is zero-padded to a multiple of 4 and N
+    to a multiple of 8 (the kernel's granules).  The training path's weight-gradient / score products go through here:
+    a transposed operand is a torch copy (`x.t().contiguous()`), the arithmetic is this library's."""
+    _need(a.contiguous(), "a", torch.float32, 2)
+    m, k = a.shape
+    if b.shape[0] != k:
+        raise RuntimeError(f"matmul: a is [{m},{k}] but b is {tuple(b.shape)}")
+    n = b.shape[1]
+    kp, np_ = (k + 3) // 4 * 4, (n + 7) // 8 * 8
+    a = a.contiguous()
+    b = b.contiguous()
+    if kp != k:
+        a = torch.nn.functional.pad(a, (0, kp - k))
+    if kp != k or np_ != n:
+        b = torch.nn.functional.pad(b, (0, np_ - n, 0, kp - k))
+    if m == 0 or n == 0:
+        return torch.zeros((m, n), dtype=torch.float32, device=a.device)
+    out = gemm(a.contiguous(), b.contiguous())
+    return out if np_ == n else out[:, :n].contiguous()
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a[M, K1]^T @ b[M, N] -> [K1, N] (t2p_gemm_tn): rows split over the grid, partials added in a fixed order.  The
+    weight-gradient products of the training-mode path (dW = dY^T X, ...): no transposed copy, no library GEMM."""
+    _need(a, "a", torch.float32, 2)
+    _need(b, "b", torch.float32, 2, a.device)
+    m, k1 = a.shape
+    if b.shape[0] != m:
+        raise RuntimeError(f"gemm_tn: a is [{m},{k1}] but b is {tuple(b.shape)}")
+    n = b.shape[1]
+    out = torch.empty((k1, n), dtype=torch.float32, device=a.device)
+    if m == 0:
+        return out.zero_()
+    ws = torch.empty((L.lib().t2p_gemm_tn_workspace_bytes(m, k1, n),), dtype=torch.uint8, device=a.device)
+    L.check(L.lib().t2p_gemm_tn(_ptr(a), k1, _ptr(b), n, _ptr(out), n, m, k1, n, _ptr(ws), ws.numel(), _stream(a.device)),
+            "t2p_gemm_tn")
+    return out
+
+
 def rownorm(x: torch.Tensor) -> torch.Tensor:
     _need(x, "x", torch.float32, 2)
     out = torch.empty_like(x)

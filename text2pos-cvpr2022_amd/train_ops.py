@@ -211,7 +211,7 @@ def normalize(x):
 
 class _LinearFn(torch.autograd.Function):
     """x [M, K] @ weight[N, K]^T + bias on the tiled fp32-MFMA GEMM (t2p_gemm); dX on the same GEMM (weight is its k-major
-    operand), dW / db are reductions over the rows (library GEMM)."""
+    operand), dW = dY^T X on t2p_gemm_tn (rows split over the grid, fixed-order reduction), db a row sum."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -231,7 +231,7 @@ class _LinearFn(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad
         # [M, N] x [N, K]: the weight is its own k-major operand
         dx = ops.gemm(dy, wp)[:, : ctx.k] if need_x else None
-        dw = (dy.t() @ xp)[:, : ctx.k] if need_w else None       # frozen layers (--pointnet_freeze) skip the reductions
+        dw = ops.gemm_tn(dy, xp)[:, : ctx.k] if need_w else None   # dY^T X; frozen layers (--pointnet_freeze) skip it
         db = dy.sum(0) if (need_b and ctx.has_bias) else None
         return dx, dw, db
 
