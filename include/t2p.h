@@ -176,7 +176,7 @@ typedef struct t2p_cell_config {
 /* Optional stage outputs for parity tests (any member may be NULL).  Layouts:
  *   fps_idx[l] uint8 [n_obj][n_cent_l]      local FPS indices into level l's dense ordering
  *   nbr[l]     uint8 [n_obj][n_cent_l][32]  ball-query neighbours (first cnt valid), cnt[l] uint8 [n_obj][n_cent_l]
- *   sa_out[l]  fp32  [n_obj*n_cent_l][C_l+32] rows = [features C_l | centroid xyz | 0 x 29]
+ *   sa_out[l]  fp32  [n_obj*n_cent_l][C_l+32] rows = [features C_l | centroid xyz | 0 | 28 columns the call leaves untouched]
  *   features0  fp32  [n_obj][1024]; features1 [n_obj][512]; features2 [n_obj][256]; obj_emb [n_obj][D] (ObjectEncoder output)
  *   knn_idx    int32 [n_obj][knn_k] global object rows (-1 = none) */
 typedef struct t2p_cell_trace {

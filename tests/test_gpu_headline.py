@@ -616,6 +616,30 @@ def test_execution_plans_are_bit_identical(hip_model):
     assert torch.equal(two, outs[0][0]) and torch.equal(again, two)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_result_does_not_depend_on_workspace_contents(hip_model, precision):
+    """The scratch buffer is the caller's and arrives with arbitrary bytes.  Some columns of it are never written (the pad
+    behind [features | xyz 0] of the SA output rows; their readers mask them, WsParams::k_live): fill every cached
+    workspace with NaN bit patterns and with zeros, the cell embeddings must be the same bits."""
+    from text2pos_amd import ops, synthetic as S
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(78, 24)
+    args = _to_dev(xyz, rgb, center, mean_rgb)
+    outs, saved = [], hip_model.precision
+    try:
+        hip_model.precision = precision
+        with torch.no_grad():
+            hip_model.encode_objects_packed(*args, cell_ptr)   # (allocates the workspace)
+            for fill in (0xFF, 0x00, 0x7F):
+                for ws in ops._workspaces.values():
+                    if ws is not None:
+                        ws.fill_(fill)
+                outs.append(hip_model.encode_objects_packed(*args, cell_ptr))
+    finally:
+        hip_model.precision = saved
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("variation", [0, 1])
 def test_coarse_model_at_embed_dim_128(vocab, variation):
     """--embed_dim 128 (training/args.py:19 makes it a free parameter): cell branch, text branch and retrieval against the

@@ -294,6 +294,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
             WsParams p{};
             p.A = ws.F[l - 1];
             p.lda = Geo::LD[l - 1];
+            p.k_live = Geo::C[l - 1] + 4;   // [features | xyz 0]; the pad columns behind are never written
             p.W = W.sa_w1[l];
             p.W_x3 = cfg.precision == 1 ? W.sa_w1_x3[l] : nullptr;
             p.ldw = H;
@@ -337,6 +338,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         WsParams p{};
         p.A = ws.F[2];
         p.lda = Geo::LD[2];
+        p.k_live = Geo::C[2] + 4;
         p.W = W.ga_w1;
         p.W_x3 = cfg.precision == 1 ? W.ga_w1_x3 : nullptr;
         p.ldw = 512;
@@ -465,8 +467,15 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
                                (size_t)n * g.nc[l] * 32, st));
             T2P_TRY(copy_trace(tr->cnt[l] ? tr->cnt[l] + trace_obj0 * g.nc[l] : nullptr, ws.gt.cnt[l],
                                (size_t)n * g.nc[l], st));
-            T2P_TRY(copy_trace(tr->sa_out[l] ? tr->sa_out[l] + trace_obj0 * g.nc[l] * Geo::LD[l] : nullptr, ws.F[l],
-                               (size_t)n * g.nc[l] * Geo::LD[l], st));
+            if (tr->sa_out[l] && n > 0) {   // [features | xyz 0] of every row; the pad columns behind are left as the caller set them
+                hipError_t e = hipMemcpy2DAsync(tr->sa_out[l] + trace_obj0 * g.nc[l] * Geo::LD[l], Geo::LD[l] * sizeof(float), ws.F[l],
+                                                Geo::LD[l] * sizeof(float), (Geo::C[l] + 4) * sizeof(float), (size_t)n * g.nc[l],
+                                                hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) {
+                    set_error("encode_cells: trace copy failed: %s", hipGetErrorString(e));
+                    return (int)e;
+                }
+            }
         }
         T2P_TRY(copy_trace(tr->features0 ? tr->features0 + trace_obj0 * 1024 : nullptr, ws.f0, (size_t)n * 1024, st));
         T2P_TRY(copy_trace(tr->features1 ? tr->features1 + trace_obj0 * 512 : nullptr, ws.f1, (size_t)n * 512, st));

@@ -230,18 +230,16 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
 }
 
 // Centroid table of one level (out; may be nullptr: the f16x3 SA kernels of levels 1 and 2 build theirs in LDS) + the
-// [xyz | 0 x 29] tail of the SA output rows (was k_pos_table): H/4 lanes per centroid row, the lane's 4 output columns of
+// [xyz | 0] quad behind the features of the SA output rows (was k_pos_table; the other pad columns stay unwritten): H/4 lanes per centroid row, the lane's 4 output columns of
 // W1p in registers, 16-byte stores.  Same arithmetic order as the stand-alone kernel.
 __device__ __attribute__((noinline)) void emit_centroid_table(const float* qx, const float* qy, const float* qz, int n_c,
                                                     const float* __restrict__ wp, int H, float* __restrict__ out,
                                                     float* __restrict__ tail, int ld_tail, int tail_col0) {
     const int lane = threadIdx.x;
-    if (out == nullptr) {   // tails only: 8 lanes per row
+    if (out == nullptr) {   // tails only: one lane per row
         if (tail == nullptr) return;
-        const int hq = lane & 7;
-        for (int c = lane >> 3; c < n_c; c += 8)
-            *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0 + hq * 4) =
-                hq == 0 ? f32x4{qx[c], qy[c], qz[c], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < n_c; c += 64)
+            *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0) = f32x4{qx[c], qy[c], qz[c], 0.f};
         return;
     }
     const int tpr = H >> 2, rpp = 64 / tpr, hq = lane % tpr;
@@ -257,8 +255,7 @@ __device__ __attribute__((noinline)) void emit_centroid_table(const float* qx, c
             v[e] = a;
         }
         *(f32x4*)(out + (size_t)c * H + hq * 4) = v;
-        if (tail != nullptr && hq < 8)
-            *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0 + hq * 4) = hq == 0 ? f32x4{px, py, pz, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tail != nullptr && hq == 0) *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0) = f32x4{px, py, pz, 0.f};
     }
 }
 

@@ -132,7 +132,7 @@ struct GroupTables {
     float* B[3];            // centroid tables  B_l[o*n_cent + c][H_l] = W1p_l pos_c
     const float* wp[3];     // [3][H_l] position rows of the level's layer-1 weights
     int H[3];
-    float* tail[3];         // SA output rows F_l: the [xyz | 0 x 29] tail at column tail_col0[l] (row stride ld_tail[l])
+    float* tail[3];         // SA output rows F_l: the [xyz | 0] quad at column tail_col0[l]; the 28 pad columns behind it are never written, their readers mask them (WsParams::k_live) (row stride ld_tail[l])
     int ld_tail[3], tail_col0[3];
     float* A1;              // SA1 point table A_1[o*n_pts + j][H1] = W1 [rgb_j | xyz_j] + b1
     const float* w1;        // [6][H1]
@@ -192,6 +192,7 @@ struct WsParams {
     // operand tables
     const float* A;    // source rows [n_src, lda]   (dense: the GEMM's A; edge: layer-1 point table)
     int lda;
+    int k_live;        // dense fp32 rows: columns >= k_live (a multiple of 4; 0 = all K) are taken as zero and never read
     const float* Bc;   // edge modes: per-destination term [n_dst, H]
     const float* W;    // [K][ldw] k-major weights (BN folded)
     int ldw;

@@ -123,6 +123,7 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
     // fp16-range guard (f16x3 only, t2p_common.h): the rows these kernels split while staging are SA outputs, whose
     // magnitude the SA kernels report; here only the magnitude of the layer-1 point tables (A_2, A_3) is published, per
     // batch, by the epilogue (guard_publish: one ballot, no atomic below the floor)
+    const int k_live = p.k_live > 0 ? p.k_live : K;   // pad columns of SA output rows are never written: do not read them
     f32x4 sa[C::ITERS];                  // staged source rows (in flight behind the MFMA block)
     f32x4 sb[C::EDGE ? C::ITERS : 1];    // staged destination terms (kNN edge mode)
 
@@ -152,7 +153,7 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                     sa[it] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (prow < n_rows) sa[it] = *(const f32x4*)(base + (g * C::TR + prow) * (int64_t)p.lda + c8 * 8);
                 } else {
-                    sa[it] = *(const f32x4*)(p.A + (g * C::TR + r) * (int64_t)p.lda + c4 * 4);
+                    if (c4 * 4 < k_live) sa[it] = *(const f32x4*)(p.A + (g * C::TR + r) * (int64_t)p.lda + c4 * 4);
                 }
             }
         }

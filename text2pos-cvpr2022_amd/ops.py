@@ -313,7 +313,7 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
                      "sa_out": lambda nc, c: ((n_obj * nc, c + 32), torch.float32)}
         for name, fn in per_level.items():
             if name in names:
-                trace[name] = [torch.empty(fn(nc, c)[0], dtype=fn(nc, c)[1], device=dev) for nc, c in shapes]
+                trace[name] = [torch.zeros(fn(nc, c)[0], dtype=fn(nc, c)[1], device=dev) for nc, c in shapes]
                 setattr(tr, name, (C.c_void_p * 3)(*[t.data_ptr() for t in trace[name]]))
         flat = {"features0": ((n_obj, 1024), torch.float32), "features1": ((n_obj, 512), torch.float32),
                 "features2": ((n_obj, 256), torch.float32), "obj_emb": ((n_obj, D), torch.float32),
