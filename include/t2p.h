@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 15
+#define T2P_ABI_VERSION 16
+#define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -110,7 +111,10 @@ typedef struct t2p_cell_weights {
     const void* g_wp_x3; /* DynamicEdgeConv layer-1 tables P, Q */
     const void* g_wq_x3;
     float lin1_scale, lin2_scale, merge_scale, pn_scale, g_wp_scale, g_wq_scale;
-    const void* sa_w1_x3[3]; /* levels 1 and 2 only (level 0 has K = 6 and runs on the VALU); [0] is ignored */
+    /* pack_f16x3 images of the layer-1 matrices that read SA output rows: of their first C + 16 rows only
+     * (K = 80 / 144 for sa_w1[1], sa_w1[2]; 272 for ga_w1: [features C | xyz | zero rows]; the fp32 matrices keep C + 32
+     * rows).  Levels 1 and 2 only (level 0 has K = 6 and runs on the VALU); [0] is ignored */
+    const void* sa_w1_x3[3];
     const void* ga_w1_x3;
     /* ObjectEncoder.class_embedding / color_embedding (object_encoder.py:31-38), used by the --class_embed /
      * --color_embed ablations only: [n_classes + 1][D], [8][D] */
@@ -143,7 +147,7 @@ typedef struct t2p_cell_config {
     int32_t knn_k;             /* DynamicEdgeConv k (cell_retrieval.py:47); 8 */
     int32_t variation;         /* args.variation (cell_retrieval.py:45-54): 0 = max, 1 = mean aggregation + mean pool */
     float radius[3];           /* SA ball radii (pointnet2.py:57-59); 0.2, 0.3, 0.4 */
-    int32_t chunk_objects;     /* objects processed per internal chunk (whole cells); 0 = default */
+    int32_t chunk_objects;     /* objects processed per internal chunk (whole cells); 0 = T2P_DEFAULT_CHUNK_OBJECTS */
     int32_t precision;         /* 0 = fp32 MFMA (exact fp32 fma chains); 1 = f16x3 split-precision MFMA with fp32
                                   accumulation (hi.hi + hi.lo + lo.hi), same 1e-4 parity bar, 5.3x the MFMA rate */
     /* ground-truth embedding ablations (training/args.py:60-61, object_encoder.py:74-84,103-120): when class_embed

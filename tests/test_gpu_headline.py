@@ -133,8 +133,9 @@ def test_headline_config_full_size_parity(oracle_model, vocab, checkpoint):
     # (knn_idx rows are local to the internal chunk; both runs chunk alike, and the distances only need the members)
     chunk0 = np.zeros(xyz.shape[0], dtype=np.int64)
     lo = 0
-    for c in range(n_cells):                                            # chunk starts: whole cells, <= 32768 objects
-        if cell_ptr[c + 1] - lo > 32768:
+    from text2pos_amd.ops import DEFAULT_CHUNK_OBJECTS
+    for c in range(n_cells):                                            # chunk starts: whole cells, <= the default chunk
+        if cell_ptr[c + 1] - lo > DEFAULT_CHUNK_OBJECTS:
             lo = cell_ptr[c]
         chunk0[cell_ptr[c]: cell_ptr[c + 1]] = lo
     ka, kb = tr3["knn_idx"].cpu().numpy().astype(np.int64), tr32["knn_idx"].cpu().numpy().astype(np.int64)

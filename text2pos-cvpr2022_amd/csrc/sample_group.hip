@@ -230,16 +230,20 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
 }
 
 // Centroid table of one level (out; may be nullptr: the f16x3 SA kernels of levels 1 and 2 build theirs in LDS) + the
-// [xyz | 0] quad behind the features of the SA output rows (was k_pos_table; the other pad columns stay unwritten): H/4 lanes per centroid row, the lane's 4 output columns of
-// W1p in registers, 16-byte stores.  Same arithmetic order as the stand-alone kernel.
+// tail behind the features of the SA output rows (was k_pos_table): the [xyz 0] quad alone (tail_quads = 1: levels 1 and 2,
+// whose readers mask the 28 pad columns, WsParams::k_live) or [xyz | 0 x 29] (tail_quads = 8: level 3; GA layer 1 sits at
+// its register limit and reads whole rows).  H/4 lanes per centroid row, the lane's 4 output columns of W1p in registers,
+// 16-byte stores.  Same arithmetic order as the stand-alone kernel.
 __device__ __attribute__((noinline)) void emit_centroid_table(const float* qx, const float* qy, const float* qz, int n_c,
                                                     const float* __restrict__ wp, int H, float* __restrict__ out,
-                                                    float* __restrict__ tail, int ld_tail, int tail_col0) {
+                                                    float* __restrict__ tail, int ld_tail, int tail_col0, int tail_quads) {
     const int lane = threadIdx.x;
-    if (out == nullptr) {   // tails only: one lane per row
+    if (out == nullptr) {   // tails only: tail_quads (1 or 8) lanes per row
         if (tail == nullptr) return;
-        for (int c = lane; c < n_c; c += 64)
-            *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0) = f32x4{qx[c], qy[c], qz[c], 0.f};
+        const int hq = lane % tail_quads;
+        for (int c = lane / tail_quads; c < n_c; c += 64 / tail_quads)
+            *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0 + hq * 4) =
+                hq == 0 ? f32x4{qx[c], qy[c], qz[c], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
     const int tpr = H >> 2, rpp = 64 / tpr, hq = lane % tpr;
@@ -255,7 +259,8 @@ __device__ __attribute__((noinline)) void emit_centroid_table(const float* qx, c
             v[e] = a;
         }
         *(f32x4*)(out + (size_t)c * H + hq * 4) = v;
-        if (tail != nullptr && hq == 0) *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0) = f32x4{px, py, pz, 0.f};
+        if (tail != nullptr && hq < tail_quads)
+            *(f32x4*)(tail + (size_t)c * ld_tail + tail_col0 + hq * 4) = hq == 0 ? f32x4{px, py, pz, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict_
                 emit_centroid_table(pin[l + 1][0], pin[l + 1][1], pin[l + 1][2], n_c, wpl, gt.H[l],
                                     gt.B[l] ? gt.B[l] + o * (int64_t)n_c * gt.H[l] : nullptr,
                                     gt.tail[l] ? gt.tail[l] + o * (int64_t)n_c * gt.ld_tail[l] : nullptr, gt.ld_tail[l],
-                                    gt.tail_col0[l]);
+                                    gt.tail_col0[l], l == 2 ? 8 : 1);
             }
             uint8_t* g_sel = gt.fps_idx[l] + o * (int64_t)n_c;
             for (int i = lane; i < n_c; i += 64) g_sel[i] = sel_lds[i];

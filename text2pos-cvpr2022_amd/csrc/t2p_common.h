@@ -227,7 +227,7 @@ struct SaParams {
     const void* W_x3; // nullptr, or the host-packed f16x3 register image of W (selects the split-precision path)
     const float* bias;  // [C]; the f16x3 path takes it pre-multiplied by the weight image's scale
     float out_scale;    // f16x3: 1 / scale of the weight image (results are drained as acc * out_scale); fp32: 1
-    float* out;       // [n_obj*n_cent][ldo] rows = [features C | centroid xyz | 0 x 5]
+    float* out;       // [n_obj*n_cent][ldo] rows = [features C | centroid xyz 0 | pad] (this kernel writes the features)
     int ldo;
     const uint16_t* rows;    // GroupTables::rows[l]
     const uint16_t* n_rows;  // GroupTables::n_rows[l]

@@ -60,7 +60,7 @@ struct WsCfg {
         return b;
     }
     static_assert(K % 8 == 0, "K must be a multiple of 8");
-    static_assert(!X3 || K % 32 == 0, "f16x3 needs K % 32 == 0");
+    static_assert(!X3 || K % 16 == 0, "f16x3 needs K % 16 == 0 (one MFMA step = 8 k per lane half)");
     static_assert(NW % (32 * WN) == 0, "NW must split into 32-column tiles per wave");
 };
 
@@ -153,7 +153,8 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                     sa[it] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (prow < n_rows) sa[it] = *(const f32x4*)(base + (g * C::TR + prow) * (int64_t)p.lda + c8 * 8);
                 } else {
-                    if (c4 * 4 < k_live) sa[it] = *(const f32x4*)(p.A + (g * C::TR + r) * (int64_t)p.lda + c4 * 4);
+                    if (SPLIT_IO == 2 || c4 * 4 < k_live)   // (GA layer 1, split output: at its register limit, reads whole rows)
+                        sa[it] = *(const f32x4*)(p.A + (g * C::TR + r) * (int64_t)p.lda + c4 * 4);
                 }
             }
         }
@@ -487,6 +488,8 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
     // split_io: 0 = fp32 in / fp32 out, 1 = fp16 hi/lo planes in, 2 = fp16 hi/lo planes out (f16x3 only)
     const int split_io = p.A_hi != nullptr ? 1 : (p.out_hi != nullptr ? 2 : 0);
     T2P_CHECK_ARG(split_io == 0 || x3 == 1, "ws_gemm: split fp16 activations need the f16x3 path");
+    T2P_CHECK_ARG(p.k_live == 0 || (split_io == 0 && mode == WS_DENSE_STORE && p.k_live % 4 == 0),
+                  "ws_gemm: k_live is honoured by the fp32-in / fp32-out dense mode only (multiple of 4)");
     if (split_io == 1) T2P_CHECK_ARG(p.A_lo != nullptr && p.lda % 8 == 0, "ws_gemm: split input needs both planes, lda %% 8 == 0");
     if (split_io == 2) T2P_CHECK_ARG(p.out_lo != nullptr, "ws_gemm: split output needs both planes");
 #define WS_CASE(MODE_, K_, N_, NW_, WN_, RT_, X3_, SIO_)                                      \
@@ -501,10 +504,11 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
     WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 0, 0)
     WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 0, 0)
     WS_CASE(WS_DENSE_STORE, 288, 512, 128, 4, 1, 0, 0)
-    if (mode == WS_DENSE_STORE && K == 96 && N == 128 && x3 == 1 && split_io == 0)  // 8 waves: 4 column blocks x 2 row tiles
-        return launch_cfg<96, 128, 4, 1, WS_DENSE_STORE, 1, 0, 1>(p, 1, st);
-    WS_CASE(WS_DENSE_STORE, 160, 256, 256, 8, 1, 1, 0)  // 8 waves (two per SIMD), one 32-column block per wave
-    WS_CASE(WS_DENSE_STORE, 288, 512, 256, 8, 1, 1, 2)  // 8 waves: two per SIMD, two column slices instead of four
+    // f16x3: K = C + 16 (the rows' last 16 pad columns have zero weights: not staged, not multiplied)
+    if (mode == WS_DENSE_STORE && K == 80 && N == 128 && x3 == 1 && split_io == 0)  // 8 waves: 4 column blocks x 2 row tiles
+        return launch_cfg<80, 128, 4, 1, WS_DENSE_STORE, 1, 0, 1>(p, 1, st);
+    WS_CASE(WS_DENSE_STORE, 144, 256, 256, 8, 1, 1, 0)  // 8 waves (two per SIMD), one 32-column block per wave
+    WS_CASE(WS_DENSE_STORE, 272, 512, 256, 8, 1, 1, 2)  // 8 waves: two per SIMD, two column slices instead of four
     // GA layer 2 + max over the 32 points of an object
     WS_CASE(WS_DENSE_GROUPMAX, 512, 1024, 128, 4, 1, 0, 0)
 #if !T2P_GA2_V1

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NT, 2) void k_ws_sa(SaParams p) {
                 if (c4 == 0) dstl[buf * C::TR + lr] = m[k] == 0xFFFF ? (uint8_t)nc : (uint8_t)((m[k] >> 8) & 127);
             }
         };
-        // flush one finished object's accumulator (feature columns; the [xyz | 0 x 5] tail of the rows is written
+        // flush one finished object's accumulator (feature columns; the [xyz 0] quad of the rows is written
         // by the centroid-table kernel), re-zero
         auto flush = [&](int64_t g, int abuf) {
             int* a = acc_lds + abuf * C::ACC_INTS;

@@ -38,6 +38,9 @@ def _need(t: torch.Tensor, name: str, dtype, ndim=None, device=None):
     return t
 
 
+DEFAULT_CHUNK_OBJECTS = 65000   # include/t2p.h: T2P_DEFAULT_CHUNK_OBJECTS
+
+
 def workspace(device, nbytes: int, tag: str) -> torch.Tensor:
     """Grow-only scratch buffer per (device, tag), obtained from torch's caching allocator."""
     key = (str(device), tag)
@@ -325,7 +328,7 @@ def encode_cells(xyz, rgb, center, mean_rgb, cell_ptr_host: np.ndarray, cell_ptr
     nbytes = L.lib().t2p_encode_cells_workspace_bytes(n_obj, n_cells, C.byref(cfg))
     # a single cell larger than the chunk forms its own (bigger) chunk: size for it
     biggest = int((cp[1:] - cp[:-1]).max()) if n_cells > 0 else 0
-    chunk = cfg.chunk_objects if cfg.chunk_objects > 0 else 32768
+    chunk = cfg.chunk_objects if cfg.chunk_objects > 0 else DEFAULT_CHUNK_OBJECTS
     if biggest > chunk:
         big_cfg = L.CellConfig.from_buffer_copy(cfg)
         big_cfg.chunk_objects = biggest

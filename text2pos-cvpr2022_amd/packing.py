@@ -54,7 +54,7 @@ def pack_f16x3(w_kmajor: torch.Tensor) -> torch.Tensor:
     round-to-nearest) laid out exactly as the MFMA B-operand registers of csrc/ws_sa.hip / ws_gemm.hip read it:
     element (plane, tile, step, half, lane, e) = split(w[k = half*K/2 + 8*step + e][n = 32*tile + lane])."""
     k, n = w_kmajor.shape
-    assert k % 32 == 0 and n % 32 == 0, (k, n)
+    assert k % 16 == 0 and n % 32 == 0, (k, n)
     w = w_kmajor.detach().float().cpu()
     _check_fp16_range(w, "pack_f16x3")
     hi = w.to(torch.float16)
@@ -119,8 +119,11 @@ def _add_x3_images(p: Dict[str, object], device, cell_head: bool):
     p["sa_w2_scale"] = scales
     p["sa_w2_x3"] = [pack_f16x3_scaled(t, sc).to(device) for t, sc in zip(p["sa_w2"], scales)]
     p["sa_b2_x3"] = [f32(b.double() * sc).to(device) for b, sc in zip(p["sa_b2"], scales)]
-    p["sa_w1_x3"] = [None] + [pack_f16x3(t).to(device) for t in p["sa_w1"][1:]]
-    p.update(ga_w1_x3=pack_f16x3(p["ga_w1"]).to(device), ga_w2_x3=pack_f16x3(p["ga_w2"]).to(device))
+    # rows of the layer-1 matrices: [features C | xyz | zero rows up to C + 32].  The f16x3 kernels step 16 k per MFMA, so
+    # their images (and their K) stop at C + 16: one MFMA step of zeros less per row batch
+    assert all(float(t[-16:].abs().max()) == 0.0 for t in p["sa_w1"][1:] + [p["ga_w1"]])
+    p["sa_w1_x3"] = [None] + [pack_f16x3(t[:-16]).to(device) for t in p["sa_w1"][1:]]
+    p.update(ga_w1_x3=pack_f16x3(p["ga_w1"][:-16]).to(device), ga_w2_x3=pack_f16x3(p["ga_w2"]).to(device))
     # fp16-range guard: GA layer 1's output is bounded by ||W||_1 (largest column sum of |w|) * max|input| + max|b|
     p["ga_w1_l1"] = float(p["ga_w1"].double().abs().sum(0).max())
     p["ga_b1_absmax"] = float(p["ga_b1"].double().abs().max())
