@@ -17,7 +17,8 @@
 #ifndef T2P_TRACE
 #define T2P_TRACE 0
 #endif
-// T2P_ABL (development only, results are wrong): 1 = no A_j gathers, 2 = no B_i gathers, 4 = no atomics, 8 = no third MFMA
+// T2P_ABL (development only, results are wrong): 1 = no A_j gathers, 2 = no B_i gathers, 4 = no atomics, 8 = no third MFMA,
+// 16 = no special-casing of padding rows (metadata taken as it comes, no clean-up past the object's end)
 #ifndef T2P_ABL
 #define T2P_ABL 0
 #endif
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             }
         };
         auto fix_meta = [&](const BatchIt& it, metav& m) {
+            if constexpr (T2P_ABL & 16) return;
 #pragma unroll
             for (int k = 0; k < IT; k++)
                 if (it.r0 + rgrp + k >= it.n) m[k] = 0xFFFF;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             const int gi = it.gi < cnt ? it.gi : cnt - 1;
             const uint32_t g = (uint32_t)(ga + gi);
             const uint32_t sb0 = (uint32_t)it.sb;
-            const bool pad = m[k] == 0xFFFF;
+            const bool pad = (T2P_ABL & 16) ? false : m[k] == 0xFFFF;
             const uint32_t mm = pad ? 0u : (uint32_t)m[k];
             const uint32_t src = mm & 0xFF, d = mm >> 8, dl = d & 127;
             const uint32_t srow = (d & 0x80) ? (sb0 + src) : (g * (uint32_t)p.n_dense + src);
