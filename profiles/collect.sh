@@ -5,14 +5,19 @@ tag=${1:-r01_j}
 cd /root/repo; export TMPDIR=/tmp
 mkdir -p gpurun_out/$tag
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/$tag/pytest.txt
-timeout 600 python bench.py --steps 20 --warmup 5 2> gpurun_out/$tag/bench.err | tail -1 > gpurun_out/$tag/bench.json
-timeout 600 python bench_fine.py 2> gpurun_out/$tag/bench_fine.err | tail -1 > gpurun_out/$tag/bench_fine.json
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats -o s -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream > gpurun_out/$tag/stats.log 2>&1
 db=$(find gpurun_out/$tag/stats -name "*.db" | head -1)
 python profiles/summarize.py $db gpurun_out/$tag/kernel_stats.md "$tag: python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream (12k cells + 1k queries, 1 x MI355X)" > /dev/null
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/$tag/fetch -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream > gpurun_out/$tag/fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/$tag/write -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream > gpurun_out/$tag/write.log 2>&1
 python profiles/pmc_traffic.py gpurun_out/$tag/fetch gpurun_out/$tag/write gpurun_out/$tag/pmc_traffic.json > /dev/null
+# matrix-pipe utilisation of the kernels (own pass: counters are never combined with the trace domains gpurun refuses)
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d gpurun_out/$tag/sq -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-pass --no-two-stream > gpurun_out/$tag/sq.log 2>&1
+python profiles/pmc_summary.py $(dirname $(find gpurun_out/$tag/sq -name "p_counter_collection.csv" | head -1)) p 10 > gpurun_out/$tag/pmc_sq.txt 2>&1
+# the bench line quotes the HBM traffic of the dominant kernel from the newest profiles/*_pmc_traffic.json: this run's
+cp gpurun_out/$tag/pmc_traffic.json profiles/${tag}_pmc_traffic.json
+timeout 600 python bench.py --steps 20 --warmup 5 2> gpurun_out/$tag/bench.err | tail -1 > gpurun_out/$tag/bench.json
+timeout 600 python bench_fine.py 2> gpurun_out/$tag/bench_fine.err | tail -1 > gpurun_out/$tag/bench_fine.json
 # keep the merge small: drop the raw traces
 find gpurun_out/$tag -name "*.db" -delete; find gpurun_out/$tag -name "*.csv" -delete
 cat gpurun_out/$tag/pytest.txt; cut -c1-400 gpurun_out/$tag/bench.json; head -12 gpurun_out/$tag/kernel_stats.md
