@@ -435,8 +435,12 @@ def main():
     text_flops = 2.0 * 2 * 256 * 1024 * n_tok
     sim_flops = 2.0 * (q_hi - q_lo) * cells_.shape[0] * 256
     phase_rates["roofline"] = {
-        "text": {"bound": "mfma (fp32) / latency", "achieved_tflops": text_flops / t_text / 1e12, "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-                 "frac": text_flops / t_text / 1e12 / FP32_MFMA_PEAK_TFLOPS, "tokens": n_tok},
+        # (a call's latency is max_len sequential time steps whatever the batch: 1,000 queries occupy 64 of the 256 CUs)
+        "text": {"bound": ("mfma (f16x3: 3 f16 MFMA FLOPs per algorithmic FLOP)" if args.precision == "f16x3" else "mfma (fp32)")
+                 + " / latency of the recurrence", "achieved_tflops": text_flops / t_text / 1e12,
+                 "peak_tflops": F16_MFMA_PEAK_TFLOPS if args.precision == "f16x3" else FP32_MFMA_PEAK_TFLOPS,
+                 "frac": text_flops / t_text / 1e12 / (F16_MFMA_PEAK_TFLOPS if args.precision == "f16x3" else FP32_MFMA_PEAK_TFLOPS),
+                 "tokens": n_tok},
         "retrieval": {"bound": "mfma (fp64)", "achieved_tflops": sim_flops / t_topk / 1e12, "peak_tflops": 78.6,
                       "frac": sim_flops / t_topk / 1e12 / 78.6}}
     if rank == 0:  # PCIe-inclusive cell rate: pinned host arrays -> HBM -> embeddings (never `value`)

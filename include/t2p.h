@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 16
+#define T2P_ABI_VERSION 17
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
@@ -264,6 +264,12 @@ typedef struct t2p_text_weights {
     const float* w_ih;      /* [2][D][4D] k-major: lstm.weight_ih_l0^T, lstm.weight_ih_l0_reverse^T */
     const float* w_hh;      /* [2][D][4D] k-major: lstm.weight_hh_l0^T, ..._reverse^T */
     const float* bias;      /* [2][4D] = bias_ih + bias_hh (gate order i, f, g, o) */
+    /* NULL (exact fp32 MFMA recurrence), or the f16x3 images of w_hh: per direction one packing.py::pack_f16x3_scaled image
+     * (as t2p_cell_weights.sa_w2_x3: uint16 [2 planes hi,lo][4D/32 tiles][D/16 steps][2 halves][32 lanes][8] of
+     * w' = w_hh_scale * w, w_hh_scale a power of two) - the recurrent product then runs as 3 f16 MFMAs per 16 k with fp32
+     * accumulation: fp32-class error, a time step 5x shorter (a call's latency is max_len time steps whatever the batch) */
+    const void* w_hh_x3;
+    float w_hh_scale;
 } t2p_text_weights;
 
 size_t t2p_encode_text_workspace_bytes(int64_t batch, int32_t vocab, int32_t embed_dim);

@@ -144,6 +144,36 @@ def test_encode_text_vs_oracle_large_batch(hip_model, oracle_model):
     assert (got - want).abs().max().item() < TOL
 
 
+def test_encode_text_both_recurrences(hip_model, oracle_model, golden_dir):
+    """The biLSTM recurrence has two arithmetic paths (csrc/lstm.hip): f16x3 (default; W_hh and h split into fp16 hi + lo,
+    fp32 accumulation) and the exact fp32 MFMA one (precision="fp32").  Both against the reference's own outputs
+    (tests/golden/text_encoder.npz, produced by models/modules.py:59-92 itself) and against each other, ragged lengths
+    from 1 to 3 x 54 tokens."""
+    from text2pos_amd import synthetic as S
+    enc = hip_model.language_encoder
+    z = np.load(os.path.join(golden_dir, "text_encoder.npz"))
+    texts = S.make_texts(11, 0, 200)
+    texts[3] = "road"
+    texts[4] = " ".join([texts[4]] * 3)
+    outs = {}
+    saved = enc.precision
+    try:
+        for precision in ("f16x3", "fp32"):
+            enc.precision = precision
+            with torch.no_grad():
+                for case in ("b1", "b7_ragged_unk", "b64"):
+                    raw = enc([str(t) for t in z[f"{case}.texts"]]).cpu().numpy()
+                    assert np.abs(raw - z[f"{case}.raw"]).max() < TOL, (precision, case)
+                outs[precision] = enc(texts).cpu()
+    finally:
+        enc.precision = saved
+    assert enc._weights().w_hh_x3, "the default recurrence must be the f16x3 one"
+    d = (outs["f16x3"] - outs["fp32"]).abs().max().item()
+    assert d < 2e-5, f"f16x3 vs fp32 recurrence: {d:.3e}"
+    want = oracle_model.language_encoder(texts)
+    assert (outs["f16x3"] - want).abs().max().item() < TOL
+
+
 def test_encode_text_rejects_empty(hip_model):
     with pytest.raises(RuntimeError):
         with torch.no_grad():

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -56,7 +56,8 @@ class MatchWeights(C.Structure):
 
 
 class TextWeights(C.Structure):
-    _fields_ = [("embedding", c_void), ("w_ih", c_void), ("w_hh", c_void), ("bias", c_void)]
+    _fields_ = [("embedding", c_void), ("w_ih", c_void), ("w_hh", c_void), ("bias", c_void), ("w_hh_x3", c_void),
+                ("w_hh_scale", C.c_float)]
 
 
 # every symbol include/t2p.h declares: (restype, argtypes)

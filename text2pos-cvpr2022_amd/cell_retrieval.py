@@ -58,6 +58,7 @@ class CellRetrievalNetwork(nn.Module):
         self.lin = get_mlp([d, d, d])
         self.object_encoder = ObjectEncoder(d, known_classes, known_colors, args)
         self.language_encoder = LanguageEncoder(known_words, d, bi_dir=True)
+        self.language_encoder.precision = precision
         self._pack = None
 
     # ---- text branch -----------------------------------------------------------------------------------------

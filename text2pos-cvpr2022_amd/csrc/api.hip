@@ -639,7 +639,7 @@ int t2p_encode_text(const int32_t* tokens, const int32_t* lengths, int64_t batch
     for (int dir = 0; dir < 2; dir++)
         T2P_TRY(launch_gemm(w->embedding, D, w->w_ih + (size_t)dir * D * 4 * D, w->bias + (size_t)dir * 4 * D,
                             table + (size_t)dir * vocab * 4 * D, 4 * D, 0, vocab, D, 4 * D, 0, st));
-    T2P_TRY(launch_bilstm_impl(table, w->w_hh, tokens, lengths, (int)batch, max_len, vocab, D, hdir, raw, st));
+    T2P_TRY(launch_bilstm_impl(table, w->w_hh, w->w_hh_x3, w->w_hh_scale, tokens, lengths, (int)batch, max_len, vocab, D, hdir, raw, st));
     T2P_TRY(launch_rownorm(raw, D, batch, D, out, D, 0, st));
     return 0;
 }

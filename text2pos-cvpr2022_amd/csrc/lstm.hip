@@ -138,6 +138,169 @@ __global__ __launch_bounds__(256, 1) void k_bilstm(const float* __restrict__ gat
         }
 }
 
+// ---- the same recurrence on the f16x3 path -------------------------------------------------------------------------------
+// The fp32 kernel above spends a time step in 1,024 v_mfma_f32_32x32x2_f32 per wave (64 cycles each: 27 us) - and a call's
+// latency is max_len steps whatever the batch, because a sequence's steps cannot overlap.  Here the recurrent product runs as
+// three v_mfma_f32_32x32x16_f16 per 16 k (W_hh and h split hi + lo in fp16, fp32 accumulation: fp32-class error, as in the
+// cell branch): 384 MFMAs of 32 cycles per wave and step.  W_hh arrives as the host-packed register image of
+// packing.py::pack_f16x3_scaled (w' = s w, s a power of two; hi = fp16(w'), lo = fp16(w' - hi); one accumulator for
+// hi.hi + hi.lo + lo.hi that starts at s x the gate-table row and is drained as acc / s), streamed from L2 one k-step
+// ahead with 16-byte loads (1 MB per step and workgroup, as the fp32 kernel).  h_{t-1} lives in LDS as two fp16 planes.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// Gate functions on the hardware exponential / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each; absolute error of the gate
+// values <= 2e-7).  The library expf / tanhf of the fp32 kernel cost ~35 instructions per value: 160 values per lane and time
+// step made the cell update as long as the recurrent product.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float t = __expf(-2.f * fabsf(x));            // in (0, 1]: no overflow; 1 - t is exact-ish near t = 1 (small |x|)
+    return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ gate_table, const uint4* __restrict__ whh_x3,
+                                                       float scale, const int32_t* __restrict__ tokens,
+                                                       const int32_t* __restrict__ lengths, int B, int T, int V,
+                                                       float* __restrict__ hout /*[2][B][D]*/) {
+    constexpr int G4 = 4 * D;
+    constexpr int UT = D / 128;      // 32-unit tiles per wave and gate
+    constexpr int S16 = D / 16;      // k-steps of 16
+    constexpr int LDHH = D + 8;      // halves; 16-byte pad keeps ds_read_b128 conflict-free
+    constexpr int PLANE_U4 = (G4 / 32) * S16 * 64;   // uint4 per plane of one direction's image
+    __shared__ __attribute__((aligned(16))) _Float16 h_hi[32 * LDHH];
+    __shared__ __attribute__((aligned(16))) _Float16 h_lo[32 * LDHH];
+    __shared__ int len_lds[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int dir = blockIdx.y;
+    const int row0 = blockIdx.x * 32;
+    const float* gt = gate_table + (int64_t)dir * V * G4;
+    const uint4* wd = whh_x3 + (int64_t)dir * 2 * PLANE_U4;
+    const float inv_scale = 1.f / scale;
+    // D = 256: one direction's image is 1 MB, four times the registers of a workgroup: it is streamed again every time step,
+    // and the compiler must not hoist the (loop-invariant) loads of all 16 k-steps out of the time loop - the pointer is made
+    // opaque once per step.  D = 128: the 256 KB image fits (64 fragments of 4 registers per lane), the loads ARE hoisted
+    // and the recurrence runs from registers.
+    constexpr bool STREAM = D > 128;
+
+    for (int i = tid; i < 32 * LDHH; i += 256) { h_hi[i] = (_Float16)0.f; h_lo[i] = (_Float16)0.f; }
+    if (tid < 32) len_lds[tid] = (row0 + tid < B) ? lengths[row0 + tid] : 0;
+    __syncthreads();
+    int max_len = 0;
+    for (int i = 0; i < 32; i++) max_len = len_lds[i] > max_len ? len_lds[i] : max_len;
+    int my_len[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) my_len[e] = len_lds[(e & 3) + 8 * (e >> 2) + 4 * h];
+
+    float c[UT][16], hreg[UT][16];
+#pragma unroll
+    for (int u = 0; u < UT; u++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) { c[u][e] = 0.f; hreg[u][e] = 0.f; }
+
+    const int unit0 = wave * (D / 4);
+    // image tile of (gate q, unit tile u) of this wave: columns q D + unit0 + 32 u ...; uint4 index of (tile, step s, half h, lane)
+    auto widx = [&](int q, int u, int s) { return (((q * (D / 32) + wave * UT + u) * S16 + s) * 2 + h) * 32 + l31; };
+    uint4 wc_hi[4][UT], wc_lo[4][UT], wn_hi[4][UT], wn_lo[4][UT];
+    auto load_w = [&](int s, uint4 (&whi)[4][UT], uint4 (&wlo)[4][UT]) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int u = 0; u < UT; u++) {
+                const int i = widx(q, u, s);
+                whi[q][u] = wd[i];
+                wlo[q][u] = wd[PLANE_U4 + i];
+            }
+    };
+    load_w(0, wc_hi, wc_lo);
+    // the token of every row of this lane, fetched one time step ahead (token -> table row -> accumulator is a chain of two
+    // dependent loads in front of every step's MFMAs otherwise)
+    int tok_next[16];
+    auto fetch_tokens = [&](int step) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int len = my_len[e];
+            tok_next[e] = 0;
+            if (step < len) tok_next[e] = tokens[(int64_t)(row0 + r) * T + (dir == 0 ? step : (len - 1 - step))];
+        }
+    };
+    fetch_tokens(0);
+
+    for (int step = 0; step < max_len; step++) {
+        f32x16 acc[4][UT];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const bool active = step < my_len[e];
+            const float* trow = gt + (int64_t)tok_next[e] * G4;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int u = 0; u < UT; u++) acc[q][u][e] = active ? trow[q * D + unit0 + u * 32 + l31] * scale : 0.f;
+        }
+        fetch_tokens(step + 1);
+        if constexpr (STREAM) asm volatile("" : "+s"(wd));
+        const _Float16* hr_hi = h_hi + l31 * LDHH + h * (D / 2);
+        const _Float16* hr_lo = h_lo + l31 * LDHH + h * (D / 2);
+        // one k-step: fragments `cur` feed the MFMAs while those of the following k-step land in `nxt` (the first of the next
+        // time step behind the last one: the image does not change)
+        auto kstep = [&](int s, uint4 (&chi)[4][UT], uint4 (&clo)[4][UT], uint4 (&nhi)[4][UT], uint4 (&nlo)[4][UT]) {
+            const half8 a_hi = *(const half8*)(hr_hi + 8 * s), a_lo = *(const half8*)(hr_lo + 8 * s);
+            load_w(s + 1 < S16 ? s + 1 : 0, nhi, nlo);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int u = 0; u < UT; u++) {
+                    const half8 bh = __builtin_bit_cast(half8, chi[q][u]), bl = __builtin_bit_cast(half8, clo[q][u]);
+                    acc[q][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh, acc[q][u], 0, 0, 0);
+                    acc[q][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl, acc[q][u], 0, 0, 0);
+                    acc[q][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh, acc[q][u], 0, 0, 0);
+                }
+        };
+        if constexpr (STREAM) {
+#pragma unroll 1
+            for (int s = 0; s < S16; s += 2) {   // (kept rolled: unrolled, all 16 k-steps' loads are scheduled up front and spill)
+                kstep(s, wc_hi, wc_lo, wn_hi, wn_lo);
+                kstep(s + 1, wn_hi, wn_lo, wc_hi, wc_lo);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < S16; s += 2) {
+                kstep(s, wc_hi, wc_lo, wn_hi, wn_lo);
+                kstep(s + 1, wn_hi, wn_lo, wc_hi, wc_lo);
+            }
+        }
+        __syncthreads();  // every wave has finished reading h_{t-1}
+#pragma unroll
+        for (int u = 0; u < UT; u++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (step < my_len[e]) {
+                    const float ig = fast_sigmoid(acc[0][u][e] * inv_scale);
+                    const float fg = fast_sigmoid(acc[1][u][e] * inv_scale);
+                    const float gg = fast_tanh(acc[2][u][e] * inv_scale);
+                    const float og = fast_sigmoid(acc[3][u][e] * inv_scale);
+                    const float cn = fg * c[u][e] + ig * gg;
+                    c[u][e] = cn;
+                    const float hn = og * fast_tanh(cn);
+                    hreg[u][e] = hn;
+                    const _Float16 hh = (_Float16)hn;
+                    h_hi[r * LDHH + unit0 + u * 32 + l31] = hh;
+                    h_lo[r * LDHH + unit0 + u * 32 + l31] = (_Float16)(hn - (float)hh);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < UT; u++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int r = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (r < B) hout[((int64_t)dir * B + r) * D + unit0 + u * 32 + l31] = hreg[u][e];
+        }
+}
+
 __global__ void k_mean2(const float* __restrict__ hdir, int64_t n, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (hdir[i] + hdir[n + i]) / 2.f;
@@ -146,13 +309,25 @@ __global__ void k_mean2(const float* __restrict__ hdir, int64_t n, float* __rest
 }  // namespace
 
 // hdir_ws: [2][B][D] scratch.
-int launch_bilstm_impl(const float* gate_table, const float* whh, const int32_t* tokens, const int32_t* lengths, int B,
-                       int T, int V, int D, float* hdir_ws, float* out, hipStream_t st) {
+int launch_bilstm_impl(const float* gate_table, const float* whh, const void* whh_x3, float whh_scale, const int32_t* tokens,
+                       const int32_t* lengths, int B, int T, int V, int D, float* hdir_ws, float* out, hipStream_t st) {
     if (B == 0) return 0;
     dim3 grid((unsigned)((B + 31) / 32), 2);
     {
-    ProfScope ps_("bilstm", st);
-    if (D == 256) {
+    ProfScope ps_(whh_x3 ? "bilstm_x3" : "bilstm", st);
+    if (whh_x3 != nullptr) {
+        T2P_CHECK_ARG(((uintptr_t)whh_x3 & 15) == 0 && whh_scale > 0.f, "bilstm: the f16x3 image must be 16-byte aligned, its scale > 0");
+        if (D == 256) {
+            hipLaunchKernelGGL(k_bilstm_x3<256>, grid, dim3(256), 0, st, gate_table, (const uint4*)whh_x3, whh_scale, tokens, lengths,
+                               B, T, V, hdir_ws);
+        } else if (D == 128) {
+            hipLaunchKernelGGL(k_bilstm_x3<128>, grid, dim3(256), 0, st, gate_table, (const uint4*)whh_x3, whh_scale, tokens, lengths,
+                               B, T, V, hdir_ws);
+        } else {
+            set_error("bilstm: embed_dim=%d not instantiated (128, 256)", D);
+            return T2P_E_UNSUPPORTED;
+        }
+    } else if (D == 256) {
         hipLaunchKernelGGL(k_bilstm<256>, grid, dim3(256), 0, st, gate_table, whh, tokens, lengths, B, T, V, hdir_ws);
     } else if (D == 128) {
         hipLaunchKernelGGL(k_bilstm<128>, grid, dim3(256), 0, st, gate_table, whh, tokens, lengths, B, T, V, hdir_ws);

@@ -249,7 +249,8 @@ int launch_sa_balance_levels(const SaParams p[3], const int H[3], const int C[3]
 
 // ---- lstm.hip ---------------------------------------------------------------------------------------------
 int launch_bilstm_impl(const float* gate_table /*[2][V][4D]*/, const float* whh /*[2][D][4D] k-major*/,
-                       const int32_t* tokens /*[B, T]*/, const int32_t* lengths, int B, int T, int V, int D,
+                       const void* whh_x3 /*nullable: [2 dirs] scaled f16x3 images of whh (selects the f16x3 recurrence)*/,
+                       float whh_scale, const int32_t* tokens /*[B, T]*/, const int32_t* lengths, int B, int T, int V, int D,
                        float* hdir_ws /*[2][B][D]*/, float* out /*[B, D] mean of the two final hidden states*/,
                        hipStream_t st);
 

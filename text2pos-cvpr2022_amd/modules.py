@@ -115,6 +115,7 @@ class LanguageEncoder(nn.Module):
         self.known_words["<unk>"] = 0
         self.word_embedding = nn.Embedding(len(self.known_words), embedding_dim, padding_idx=0)
         self.lstm = nn.LSTM(input_size=embedding_dim, hidden_size=embedding_dim, bidirectional=True, num_layers=1)
+        self.precision = "f16x3"   # arithmetic of the inference recurrence ("fp32": exact fp32 MFMA); the owning model sets it
         self._pack = None
 
     @property
@@ -122,10 +123,14 @@ class LanguageEncoder(nn.Module):
         return self.word_embedding.weight.device
 
     def _weights(self):
-        ver = (packing.params_version(self), str(self.device))
+        ver = (packing.params_version(self), str(self.device), self.precision)
         if self._pack is None or self._pack[0] != ver:
-            t = packing.pack_text_weights(self, self.device)
-            self._pack = (ver, t, ops.make_text_weights(t["embedding"], t["w_ih"], t["w_hh"], t["bias"]))
+            try:
+                t = packing.pack_text_weights(self, self.device, x3=self.precision == "f16x3")
+            except packing.Fp16RangeError:   # a recurrent weight outside fp16's range: the exact path has no such limit
+                t = packing.pack_text_weights(self, self.device, x3=False)
+            self._pack = (ver, t, ops.make_text_weights(t["embedding"], t["w_ih"], t["w_hh"], t["bias"], t.get("w_hh_x3"),
+                                                        t.get("w_hh_scale", 0.0)))
         return self._pack[2]
 
     def _wants_grad(self):

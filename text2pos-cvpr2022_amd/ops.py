@@ -415,11 +415,15 @@ def match(desc0, desc1, weights: L.MatchWeights, sinkhorn_iters: int, threshold:
     return out
 
 
-def make_text_weights(embedding, w_ih, w_hh, bias) -> L.TextWeights:
+def make_text_weights(embedding, w_ih, w_hh, bias, w_hh_x3=None, w_hh_scale=0.0) -> L.TextWeights:
+    """w_hh_x3 (int16 device tensor, packing.pack_text_weights(x3=True)) selects the f16x3 recurrence; None = exact fp32."""
     w = L.TextWeights()
     for n, t in (("embedding", embedding), ("w_ih", w_ih), ("w_hh", w_hh), ("bias", bias)):
         _need(t, n, torch.float32)
         setattr(w, n, t.data_ptr())
+    if w_hh_x3 is not None:
+        _need(w_hh_x3, "w_hh_x3", torch.int16)
+        w.w_hh_x3, w.w_hh_scale = w_hh_x3.data_ptr(), float(w_hh_scale)
     return w
 
 

@@ -228,15 +228,22 @@ def pack_match_weights(model, device, precision: str = "f16x3") -> Dict[str, obj
     return p
 
 
-def pack_text_weights(lang, device) -> Dict[str, torch.Tensor]:
-    """lang: LanguageEncoder (this package).  nn.LSTM parameter layout: weight_ih_l0 [4D, D] (gates i,f,g,o)."""
+def pack_text_weights(lang, device, x3: bool = False) -> Dict[str, torch.Tensor]:
+    """lang: LanguageEncoder (this package).  nn.LSTM parameter layout: weight_ih_l0 [4D, D] (gates i,f,g,o).
+    x3: also the scaled f16x3 images of the two recurrent matrices (csrc/lstm.hip: k_bilstm_x3), one power-of-two scale."""
     lstm = lang.lstm
     w_ih = torch.stack([lstm.weight_ih_l0.detach().double().t(), lstm.weight_ih_l0_reverse.detach().double().t()])
     w_hh = torch.stack([lstm.weight_hh_l0.detach().double().t(), lstm.weight_hh_l0_reverse.detach().double().t()])
     bias = torch.stack([lstm.bias_ih_l0.detach().double() + lstm.bias_hh_l0.detach().double(),
                         lstm.bias_ih_l0_reverse.detach().double() + lstm.bias_hh_l0_reverse.detach().double()])
-    return dict(embedding=f32(lang.word_embedding.weight.detach()).to(device), w_ih=f32(w_ih).to(device),
-                w_hh=f32(w_hh).to(device), bias=f32(bias).to(device))
+    p = dict(embedding=f32(lang.word_embedding.weight.detach()).to(device), w_ih=f32(w_ih).to(device),
+             w_hh=f32(w_hh).to(device), bias=f32(bias).to(device))
+    if x3:
+        w32 = f32(w_hh)
+        sc = f16x3_scale(w32)
+        p["w_hh_scale"] = sc
+        p["w_hh_x3"] = torch.stack([pack_f16x3_scaled(w32[0], sc), pack_f16x3_scaled(w32[1], sc)]).contiguous().to(device)
+    return p
 
 
 def params_version(module: nn.Module) -> Tuple:

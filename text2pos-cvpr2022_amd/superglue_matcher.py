@@ -86,6 +86,7 @@ class SuperGlueMatch(nn.Module):
         d = self.embed_dim
         self.object_encoder = ObjectEncoder(d, known_classes, known_colors, args)
         self.language_encoder = LanguageEncoder(known_words, d, bi_dir=True)
+        self.language_encoder.precision = precision
         self.mlp_offsets = nn.Sequential(nn.Linear(d, d // 2), nn.ReLU(), nn.Linear(d // 2, 2))  # get_mlp_offset (:29-48)
         self.superglue = SuperGlue({"descriptor_dim": d, "GNN_layers": ["self", "cross"] * self.num_layers,
                                     "sinkhorn_iterations": self.sinkhorn_iters, "match_threshold": MATCH_THRESHOLD})
