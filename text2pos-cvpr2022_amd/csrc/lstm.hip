@@ -172,7 +172,6 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
     __shared__ int len_lds[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int dir = blockIdx.y;
-    const int row0 = blockIdx.x * 32;
     const float* gt = gate_table + (int64_t)dir * V * G4;
     const uint4* wd = whh_x3 + (int64_t)dir * 2 * PLANE_U4;
     const float inv_scale = 1.f / scale;
@@ -181,21 +180,6 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
     // opaque once per step.  D = 128: the 256 KB image fits (64 fragments of 4 registers per lane), the loads ARE hoisted
     // and the recurrence runs from registers.
     constexpr bool STREAM = D > 128;
-
-    for (int i = tid; i < 32 * LDHH; i += 256) { h_hi[i] = (_Float16)0.f; h_lo[i] = (_Float16)0.f; }
-    if (tid < 32) len_lds[tid] = (row0 + tid < B) ? lengths[row0 + tid] : 0;
-    __syncthreads();
-    int max_len = 0;
-    for (int i = 0; i < 32; i++) max_len = len_lds[i] > max_len ? len_lds[i] : max_len;
-    int my_len[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) my_len[e] = len_lds[(e & 3) + 8 * (e >> 2) + 4 * h];
-
-    float c[UT][16], hreg[UT][16];
-#pragma unroll
-    for (int u = 0; u < UT; u++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) { c[u][e] = 0.f; hreg[u][e] = 0.f; }
 
     const int unit0 = wave * (D / 4);
     // image tile of (gate q, unit tile u) of this wave: columns q D + unit0 + 32 u ...; uint4 index of (tile, step s, half h, lane)
@@ -211,7 +195,36 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
                 wlo[q][u] = wd[PLANE_U4 + i];
             }
     };
-    load_w(0, wc_hi, wc_lo);
+    // D = 128: the whole image of this wave (S16 x 4 tiles x hi, lo = 64 fragments = 256 registers) is loaded once
+    uint4 wr_hi[STREAM ? 1 : S16][4][UT], wr_lo[STREAM ? 1 : S16][4][UT];
+    if constexpr (STREAM) {
+        load_w(0, wc_hi, wc_lo);
+    } else {
+#pragma unroll
+        for (int s = 0; s < S16; s++) load_w(s, wr_hi[s], wr_lo[s]);
+    }
+
+    // persistent over the groups of 32 sequences (grid.x <= groups): with many short sequences (the fine stage encodes 60,000
+    // hint sentences of ~9 tokens) a workgroup per group would spend its life fetching the weight image
+    const int n_groups = (B + 31) / 32;
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int row0 = grp * 32;
+    __syncthreads();   // (the previous group's last reads of the planes / of len_lds)
+    for (int i = tid; i < 32 * LDHH; i += 256) { h_hi[i] = (_Float16)0.f; h_lo[i] = (_Float16)0.f; }
+    if (tid < 32) len_lds[tid] = (row0 + tid < B) ? lengths[row0 + tid] : 0;
+    __syncthreads();
+    int max_len = 0;
+    for (int i = 0; i < 32; i++) max_len = len_lds[i] > max_len ? len_lds[i] : max_len;
+    int my_len[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) my_len[e] = len_lds[(e & 3) + 8 * (e >> 2) + 4 * h];
+
+    float c[UT][16], hreg[UT][16];
+#pragma unroll
+    for (int u = 0; u < UT; u++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) { c[u][e] = 0.f; hreg[u][e] = 0.f; }
+
     // the token of every row of this lane, fetched one time step ahead (token -> table row -> accumulator is a chain of two
     // dependent loads in front of every step's MFMAs otherwise)
     int tok_next[16];
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
         // time step behind the last one: the image does not change)
         auto kstep = [&](int s, uint4 (&chi)[4][UT], uint4 (&clo)[4][UT], uint4 (&nhi)[4][UT], uint4 (&nlo)[4][UT]) {
             const half8 a_hi = *(const half8*)(hr_hi + 8 * s), a_lo = *(const half8*)(hr_lo + 8 * s);
-            load_w(s + 1 < S16 ? s + 1 : 0, nhi, nlo);
+            if constexpr (STREAM) load_w(s + 1 < S16 ? s + 1 : 0, nhi, nlo);
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -264,10 +277,7 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < S16; s += 2) {
-                kstep(s, wc_hi, wc_lo, wn_hi, wn_lo);
-                kstep(s + 1, wn_hi, wn_lo, wc_hi, wc_lo);
-            }
+            for (int s = 0; s < S16; s++) kstep(s, wr_hi[s], wr_lo[s], wn_hi, wn_lo);
         }
         __syncthreads();  // every wave has finished reading h_{t-1}
 #pragma unroll
@@ -299,6 +309,7 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
             const int r = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (r < B) hout[((int64_t)dir * B + r) * D + unit0 + u * 32 + l31] = hreg[u][e];
         }
+    }   // groups
 }
 
 __global__ void k_mean2(const float* __restrict__ hdir, int64_t n, float* __restrict__ out) {
@@ -316,6 +327,8 @@ int launch_bilstm_impl(const float* gate_table, const float* whh, const void* wh
     {
     ProfScope ps_(whh_x3 ? "bilstm_x3" : "bilstm", st);
     if (whh_x3 != nullptr) {
+        const unsigned per_dir = (unsigned)(num_cus() / 2 > 0 ? num_cus() / 2 : 1);   // one workgroup per CU, two directions
+        if (grid.x > per_dir) grid.x = per_dir;
         T2P_CHECK_ARG(((uintptr_t)whh_x3 & 15) == 0 && whh_scale > 0.f, "bilstm: the f16x3 image must be 16-byte aligned, its scale > 0");
         if (D == 256) {
             hipLaunchKernelGGL(k_bilstm_x3<256>, grid, dim3(256), 0, st, gate_table, (const uint4*)whh_x3, whh_scale, tokens, lengths,
