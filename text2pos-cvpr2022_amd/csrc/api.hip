@@ -614,7 +614,7 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
 
 size_t t2p_encode_text_workspace_bytes(int64_t batch, int32_t vocab, int32_t embed_dim) {
     const size_t D = embed_dim;
-    return align_up((size_t)2 * vocab * 4 * D * sizeof(float), 256) + align_up((size_t)2 * batch * D * sizeof(float), 256) +
+    return align_up((size_t)2 * (vocab + 1) * 4 * D * sizeof(float), 256) + align_up((size_t)2 * batch * D * sizeof(float), 256) +
            align_up((size_t)batch * D * sizeof(float), 256) + 256;
 }
 
@@ -632,14 +632,21 @@ int t2p_encode_text(const int32_t* tokens, const int32_t* lengths, int64_t batch
     }
     const int D = embed_dim;
     Bump b{(char*)workspace, 0, workspace_bytes};
-    float* table = b.take<float>((size_t)2 * vocab * 4 * D);
+    const int rows = vocab + 1;   // + one zero row per direction (lstm.hip)
+    float* table = b.take<float>((size_t)2 * rows * 4 * D);
     float* hdir = b.take<float>((size_t)2 * batch * D);
     float* raw = out_raw ? out_raw : b.take<float>((size_t)batch * D);
     // gate table [dir][V][4D] = embedding [V][D] x W_ih^T [D][4D] + (b_ih + b_hh)
-    for (int dir = 0; dir < 2; dir++)
+    for (int dir = 0; dir < 2; dir++) {
         T2P_TRY(launch_gemm(w->embedding, D, w->w_ih + (size_t)dir * D * 4 * D, w->bias + (size_t)dir * 4 * D,
-                            table + (size_t)dir * vocab * 4 * D, 4 * D, 0, vocab, D, 4 * D, 0, st));
-    T2P_TRY(launch_bilstm_impl(table, w->w_hh, w->w_hh_x3, w->w_hh_scale, tokens, lengths, (int)batch, max_len, vocab, D, hdir, raw, st));
+                            table + (size_t)dir * rows * 4 * D, 4 * D, 0, vocab, D, 4 * D, 0, st));
+        hipError_t e = hipMemsetAsync(table + ((size_t)dir * rows + vocab) * 4 * D, 0, (size_t)4 * D * sizeof(float), st);
+        if (e != hipSuccess) {
+            set_error("encode_text: memset failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    T2P_TRY(launch_bilstm_impl(table, w->w_hh, w->w_hh_x3, w->w_hh_scale, tokens, lengths, (int)batch, max_len, rows, D, hdir, raw, st));
     T2P_TRY(launch_rownorm(raw, D, batch, D, out, D, 0, st));
     return 0;
 }

@@ -14,6 +14,14 @@
 //     ahead; each wave reads a disjoint column set, so LDS staging would add nothing.
 //   * Variable lengths: a sequence is updated while step < len; the reverse direction reads token len-1-step, so
 //     its final state is the one after consuming token 0 -- the same states pack_padded_sequence produces.
+// T2P_LSTM_ABL (development only, results are wrong): 1 = no weight stream (the first fragments are reused), 2 = no gate-table
+// gather, 4 = no gate functions
+#ifndef T2P_LSTM_ABL
+#define T2P_LSTM_ABL 0
+#endif
+#ifndef T2P_LSTM_RING
+#define T2P_LSTM_RING 4
+#endif
 #include "t2p_common.h"
 
 namespace t2p {
@@ -144,15 +152,22 @@ __global__ __launch_bounds__(256, 1) void k_bilstm(const float* __restrict__ gat
 // three v_mfma_f32_32x32x16_f16 per 16 k (W_hh and h split hi + lo in fp16, fp32 accumulation: fp32-class error, as in the
 // cell branch): 384 MFMAs of 32 cycles per wave and step.  W_hh arrives as the host-packed register image of
 // packing.py::pack_f16x3_scaled (w' = s w, s a power of two; hi = fp16(w'), lo = fp16(w' - hi); one accumulator for
-// hi.hi + hi.lo + lo.hi that starts at s x the gate-table row and is drained as acc / s), streamed from L2 one k-step
-// ahead with 16-byte loads (1 MB per step and workgroup, as the fp32 kernel).  h_{t-1} lives in LDS as two fp16 planes.
+// hi.hi + hi.lo + lo.hi that starts at the gate-table row - the launcher scales the table by s - and is drained as acc / s),
+// streamed from L2 with 16-byte loads (1 MB per step and workgroup, as the fp32 kernel).  h_{t-1} lives in LDS as two fp16
+// planes.  The product runs tile by tile (gate x 32 units), so that a tile's MFMAs wait for their own 16 table values only:
+// measured on the first form of this kernel (k-step-major, all 128 table values in front of the first MFMA), the gate-table
+// gather was the largest single cost of a time step (9 of 28 us; the weight stream 6, the gate functions 2).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // Gate functions on the hardware exponential / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each; absolute error of the gate
 // values <= 2e-7).  The library expf / tanhf of the fp32 kernel cost ~35 instructions per value: 160 values per lane and time
 // step made the cell update as long as the recurrent product.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    if constexpr (T2P_LSTM_ABL & 4) return x;
+    return __builtin_amdgcn_rcpf(1.f + __expf(-x));
+}
 __device__ __forceinline__ float fast_tanh(float x) {
+    if constexpr (T2P_LSTM_ABL & 4) return x;
     const float t = __expf(-2.f * fabsf(x));            // in (0, 1]: no overflow; 1 - t is exact-ish near t = 1 (small |x|)
     return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
 }
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) _Float16 h_hi[32 * LDHH];
     __shared__ __attribute__((aligned(16))) _Float16 h_lo[32 * LDHH];
     __shared__ int len_lds[32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
     const int dir = blockIdx.y;
     const float* gt = gate_table + (int64_t)dir * V * G4;
     const uint4* wd = whh_x3 + (int64_t)dir * 2 * PLANE_U4;
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
     const int unit0 = wave * (D / 4);
     // image tile of (gate q, unit tile u) of this wave: columns q D + unit0 + 32 u ...; uint4 index of (tile, step s, half h, lane)
     auto widx = [&](int q, int u, int s) { return (((q * (D / 32) + wave * UT + u) * S16 + s) * 2 + h) * 32 + l31; };
-    uint4 wc_hi[4][UT], wc_lo[4][UT], wn_hi[4][UT], wn_lo[4][UT];
+    uint4 wn_hi[4][UT], wn_lo[4][UT];   // (dummies of kstep's signature)
     auto load_w = [&](int s, uint4 (&whi)[4][UT], uint4 (&wlo)[4][UT]) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -197,8 +212,29 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
     };
     // D = 128: the whole image of this wave (S16 x 4 tiles x hi, lo = 64 fragments = 256 registers) is loaded once
     uint4 wr_hi[STREAM ? 1 : S16][4][UT], wr_lo[STREAM ? 1 : S16][4][UT];
+    // D = 256: tile-major stream through a ring of RING fragment pairs: item i = (tile, k-step) sits in slot i % RING and the
+    // slot is refilled with item i + RING as soon as its MFMAs are issued (static register indices).  Measured per time step:
+    // RING 4 / 8 / 16 = 17.2 / 17.5 / 19.3 us (8 and 16 spill): the stream runs at the ~60 GB/s one CU draws from L2, not at
+    // its latency.  Tile t = (gate t & 3, unit tile t >> 2).
+    constexpr int NTILE = 4 * UT;
+    constexpr int RING = T2P_LSTM_RING;   // fragment pairs in flight (<= S16, a divisor of it): item i = (tile, k-step) sits in slot i % RING
+    uint4 rg_hi[STREAM ? RING : 1], rg_lo[STREAM ? RING : 1];
+    // (a tile's S16 fragments are contiguous: 64 uint4 per k-step.  The tile's base travels in SGPRs and is made opaque, so
+    // that the 2 x 128 fragment addresses of a time step are formed where they are used instead of being hoisted into
+    // 500 registers)
+    const int lane_u4 = h * 32 + l31;
+    auto tile_base = [&](int t) {
+        const uint4* b = wd + (((t & 3) * (D / 32) + wave * UT + (t >> 2)) * S16) * 64;
+        asm volatile("" : "+s"(b));
+        return b;
+    };
     if constexpr (STREAM) {
-        load_w(0, wc_hi, wc_lo);
+        const uint4* b0 = tile_base(0);
+#pragma unroll
+        for (int s = 0; s < RING; s++) {
+            rg_hi[s] = b0[s * 64 + lane_u4];
+            rg_lo[s] = b0[PLANE_U4 + s * 64 + lane_u4];
+        }
     } else {
 #pragma unroll
         for (int s = 0; s < S16; s++) load_w(s, wr_hi[s], wr_lo[s]);
@@ -233,32 +269,31 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
         for (int e = 0; e < 16; e++) {
             const int r = (e & 3) + 8 * (e >> 2) + 4 * h;
             const int len = my_len[e];
-            tok_next[e] = 0;
+            tok_next[e] = V - 1;   // the table's zero row: a row past its length adds nothing (and is not updated)
             if (step < len) tok_next[e] = tokens[(int64_t)(row0 + r) * T + (dir == 0 ? step : (len - 1 - step))];
         }
     };
     fetch_tokens(0);
 
     for (int step = 0; step < max_len; step++) {
+        // accumulators start at the (pre-scaled) gate-table rows: plain loads, issued tile by tile in the order the tiles are
+        // multiplied, so that a tile's MFMAs wait for its own 16 values only
         f32x16 acc[4][UT];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const bool active = step < my_len[e];
-            const float* trow = gt + (int64_t)tok_next[e] * G4;
+        for (int t = 0; t < NTILE; t++)
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int u = 0; u < UT; u++) acc[q][u][e] = active ? trow[q * D + unit0 + u * 32 + l31] * scale : 0.f;
-        }
+            for (int e = 0; e < 16; e++) {
+                const float* trow = gt + (int64_t)tok_next[e] * G4;
+                acc[t & 3][t >> 2][e] = (T2P_LSTM_ABL & 2) ? 0.f : trow[(t & 3) * D + unit0 + (t >> 2) * 32 + l31];
+            }
         fetch_tokens(step + 1);
-        if constexpr (STREAM) asm volatile("" : "+s"(wd));
         const _Float16* hr_hi = h_hi + l31 * LDHH + h * (D / 2);
         const _Float16* hr_lo = h_lo + l31 * LDHH + h * (D / 2);
         // one k-step: fragments `cur` feed the MFMAs while those of the following k-step land in `nxt` (the first of the next
         // time step behind the last one: the image does not change)
         auto kstep = [&](int s, uint4 (&chi)[4][UT], uint4 (&clo)[4][UT], uint4 (&nhi)[4][UT], uint4 (&nlo)[4][UT]) {
             const half8 a_hi = *(const half8*)(hr_hi + 8 * s), a_lo = *(const half8*)(hr_lo + 8 * s);
-            if constexpr (STREAM) load_w(s + 1 < S16 ? s + 1 : 0, nhi, nlo);
+            if constexpr (STREAM && !(T2P_LSTM_ABL & 1)) load_w(s + 1 < S16 ? s + 1 : 0, nhi, nlo);
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -270,10 +305,31 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
                 }
         };
         if constexpr (STREAM) {
-#pragma unroll 1
-            for (int s = 0; s < S16; s += 2) {   // (kept rolled: unrolled, all 16 k-steps' loads are scheduled up front and spill)
-                kstep(s, wc_hi, wc_lo, wn_hi, wn_lo);
-                kstep(s + 1, wn_hi, wn_lo, wc_hi, wc_lo);
+            half8 a_hi = *(const half8*)(hr_hi), a_lo = *(const half8*)(hr_lo), n_hi = a_hi, n_lo = a_lo;
+#pragma unroll
+            for (int t = 0; t < NTILE; t++) {
+                const uint4* cb = tile_base(t);
+                const uint4* nb = tile_base((t + 1) % NTILE);
+#pragma unroll
+                for (int s = 0; s < S16; s++) {
+                    const int sn = (s + 1) % S16;
+                    n_hi = *(const half8*)(hr_hi + 8 * sn);
+                    n_lo = *(const half8*)(hr_lo + 8 * sn);
+                    const half8 bh = __builtin_bit_cast(half8, rg_hi[s % RING]), bl = __builtin_bit_cast(half8, rg_lo[s % RING]);
+                    acc[t & 3][t >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh, acc[t & 3][t >> 2], 0, 0, 0);
+                    acc[t & 3][t >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl, acc[t & 3][t >> 2], 0, 0, 0);
+                    acc[t & 3][t >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh, acc[t & 3][t >> 2], 0, 0, 0);
+                    if constexpr (!(T2P_LSTM_ABL & 1)) {   // (the tile behind the last one is the first of the next time step)
+                        // item RING ahead: (t, s + RING), or (t + 1, s + RING - S16)
+                        const uint4* rb = s + RING < S16 ? cb : nb;
+                        const int rs = (s + RING) % S16;
+                        rg_hi[s % RING] = rb[rs * 64 + lane_u4];
+                        rg_lo[s % RING] = rb[PLANE_U4 + rs * 64 + lane_u4];
+                    }
+                    a_hi = n_hi;
+                    a_lo = n_lo;
+                    __builtin_amdgcn_sched_barrier(0);   // keeps the refills where they are (hoisted, 256 loads would spill)
+                }
             }
         } else {
 #pragma unroll
@@ -312,6 +368,10 @@ __global__ __launch_bounds__(256, 1) void k_bilstm_x3(const float* __restrict__ 
     }   // groups
 }
 
+__global__ void k_scale_inplace(float* __restrict__ x, int64_t n, float s) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+
 __global__ void k_mean2(const float* __restrict__ hdir, int64_t n, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (hdir[i] + hdir[n + i]) / 2.f;
@@ -324,6 +384,11 @@ int launch_bilstm_impl(const float* gate_table, const float* whh, const void* wh
                        const int32_t* lengths, int B, int T, int V, int D, float* hdir_ws, float* out, hipStream_t st) {
     if (B == 0) return 0;
     dim3 grid((unsigned)((B + 31) / 32), 2);
+    if (whh_x3 != nullptr) {   // the f16x3 kernel's accumulators start at scale x table row: scale the table once (a power of two)
+        const int64_t n = (int64_t)2 * V * 4 * D;
+        hipLaunchKernelGGL(k_scale_inplace, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (float*)gate_table, n, whh_scale);
+        T2P_CHECK_LAUNCH("bilstm_table_scale");
+    }
     {
     ProfScope ps_(whh_x3 ? "bilstm_x3" : "bilstm", st);
     if (whh_x3 != nullptr) {

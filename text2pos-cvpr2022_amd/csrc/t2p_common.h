@@ -248,6 +248,8 @@ int launch_ws_sa(int H, int C, const SaParams& p, hipStream_t st);
 int launch_sa_balance_levels(const SaParams p[3], const int H[3], const int C[3], hipStream_t st);
 
 // ---- lstm.hip ---------------------------------------------------------------------------------------------
+// gate_table: [2][V][4D] with V = vocabulary + 1: the LAST row of each direction is all zeros (what rows past their length
+// gather); the f16x3 path scales the table in place by whh_scale.
 int launch_bilstm_impl(const float* gate_table /*[2][V][4D]*/, const float* whh /*[2][D][4D] k-major*/,
                        const void* whh_x3 /*nullable: [2 dirs] scaled f16x3 images of whh (selects the f16x3 recurrence)*/,
                        float whh_scale, const int32_t* tokens /*[B, T]*/, const int32_t* lengths, int B, int T, int V, int D,
