@@ -19,5 +19,6 @@ cp gpurun_out/$tag/pmc_traffic.json profiles/${tag}_pmc_traffic.json
 timeout 600 python bench.py --steps 20 --warmup 5 2> gpurun_out/$tag/bench.err | tail -1 > gpurun_out/$tag/bench.json
 timeout 600 python bench_fine.py 2> gpurun_out/$tag/bench_fine.err | tail -1 > gpurun_out/$tag/bench_fine.json
 # keep the merge small: drop the raw traces
-find gpurun_out/$tag -name "*.db" -delete; find gpurun_out/$tag -name "*.csv" -delete
+cp $trace gpurun_out/$tag/kernel_trace.csv 2>/dev/null   # (kept for re-summarising; not committed)
+find gpurun_out/$tag -name "*.db" -delete; find gpurun_out/$tag -mindepth 2 -name "*.csv" -delete
 cat gpurun_out/$tag/pytest.txt; cut -c1-400 gpurun_out/$tag/bench.json; head -12 gpurun_out/$tag/kernel_stats.md

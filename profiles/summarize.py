@@ -4,8 +4,9 @@ usage: python profiles/summarize.py <results.db | *_kernel_trace.csv> <out.md> [
   * a rocpd sqlite database (ROCm 7.2 default output): the tool's own `top_kernels` view;
   * a `--output-format csv` kernel trace: one row per dispatch, so the table also carries the median and the largest
     launch.  bench.py launches every cell kernel a few times on small batches too (BatchNorm calibration, phase timings):
-    those dilute `avg`; `full avg` is the mean over the launches of at least half the largest duration, i.e. the
-    full-size chunks that `roofline.avg_launch_ms` of the bench line averages."""
+    those dilute `avg`; `full avg` is the mean over the launches of at least 3/4 of the largest duration, i.e. the
+    full-size chunks that `roofline.avg_launch_ms` of the bench line averages (the PCIe-inclusive phase runs blocks of
+    2,048 cells = half-size launches)."""
 import collections
 import csv
 import re
@@ -42,7 +43,7 @@ def from_csv(path, f):
         p = 100.0 * sum(v) / total
         if p < 0.01:
             continue
-        full = [x for x in v if x >= 0.5 * max(v)]
+        full = [x for x in v if x >= 0.75 * max(v)]
         f.write(f"| `{short(n)}` | {len(v)} | {sum(v):.0f} | {sum(v) / len(v):.1f} | {statistics.median(v):.1f} | {max(v):.1f} | "
                 f"{len(full)} | {sum(full) / len(full):.1f} | {p:.2f} |\n")
 
