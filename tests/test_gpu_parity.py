@@ -4,6 +4,7 @@ Bars: integer / index outputs bit-exact; fp32 embeddings within 1e-4 absolute (B
 float64 retrieval scores within 1e-12.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -226,6 +227,23 @@ def test_encode_cells_stagewise_vs_oracle(hip_model, oracle_model, vocab, self_l
     emb = [d for d in tr if "object_embeddings" in d][0]["object_embeddings"].numpy()
     assert np.abs(gtr["obj_emb"].cpu().numpy() - emb).max() < TOL
     assert np.abs(got.cpu().numpy() - want.numpy()).max() < TOL
+
+
+def test_odd_cell_shapes_vs_oracle():
+    """tests/tools/fuzz_cells.py on four seeds: cells of 1 .. 150 objects, objects made of 2 - 5 distinct points, collinear,
+    squeezed (every ball at its 32-neighbour cap) or spread out (balls that hold their centre only); both arithmetic
+    paths, one chunk and many."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_cells", os.path.join(os.path.dirname(__file__), "tools", "fuzz_cells.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    argv, n = sys.argv, torch.get_num_threads()
+    try:
+        sys.argv = ["fuzz_cells.py", "4", "0"]
+        fz.main()
+    finally:
+        sys.argv = argv
+        torch.set_num_threads(n)
 
 
 def test_encode_cells_exact_fp32_path(oracle_model, vocab):
