@@ -29,10 +29,14 @@ def default_transform(n_pts: int = 256, seed: Optional[int] = None):
 
 
 @torch.no_grad()
-def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], threshs: Sequence[int], cells_per_call: int = 64,
+def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], threshs: Sequence[int], cells_per_call: int = 512,
                texts_per_call: int = 1024):
     """Encode every cell and every query, rank in float64, report hit@k / close-by@k and recall within the thresholds
-    when the retrieved cell's centre is the estimate.  Returns (retrievals, accuracies dict)."""
+    when the retrieved cell's centre is the estimate.  Returns (retrievals, accuracies dict).
+    cells_per_call: the reference's loader hands over 64 cells per batch (evaluation/pipeline.py:303-308); cells are
+    independent, so the batch size does not change a bit of the result, and 64 cells (about a thousand objects) fill a
+    third of the GPU: 512 by default.  The host-side transform of every object (FixedPoints + NormalizeScale in NumPy)
+    is what bounds this loop either way; model.encode_raw_objects runs that chain on the GPU."""
     cells, poses = scenes.all_cells, scenes.all_poses
     enc = []
     for lo in range(0, len(cells), cells_per_call):
