@@ -22,6 +22,9 @@
 #ifndef T2P_ABL
 #define T2P_ABL 0
 #endif
+#ifndef T2P_SA1_SWIZ   // 0: K = 32 stages its rows in plain order (A/B of the bank-conflict fix)
+#define T2P_SA1_SWIZ 1
+#endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #include "t2p_common.h"
 
@@ -163,7 +166,12 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
     uint32_t gbits = 0;  // fp16-range guard: wave-uniform maximum (bit pattern, before out_scale) of the drained outputs
 
     const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
-    const int rgrp = (tid / C::F4_PER_ROW) * C::ITERS;  // first of this thread's 4 staged rows inside a batch
+    // first of this thread's ITERS staged rows inside a batch.  K = 32: a row is 8 lanes x 8 bytes, a ds_write_b64 is served in
+    // groups of 16 lanes = two rows, and with the 80-byte row stride rows r and r + 2 overlap in half of the 32 banks
+    // (SQ_LDS_BANK_CONFLICT: 15 % of SA1's LDS cycles) while r and r + 4 are disjoint: neighbouring lane groups swap row pairs
+    // so that a 16-lane group covers rows r and r + 4.
+    const int tgrp = tid / C::F4_PER_ROW;
+    const int rgrp = ((C::F4_PER_ROW == 8 && T2P_SA1_SWIZ) ? ((tgrp & ~3) | ((tgrp & 1) << 1) | ((tgrp >> 1) & 1)) : tgrp) * C::ITERS;
     const int c4 = tid % C::F4_PER_ROW;
     const uint32_t c4b = (uint32_t)c4 * 16u;
     typedef uint16_t metav __attribute__((ext_vector_type(C::ITERS)));
