@@ -182,7 +182,7 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             d[j] = dist2(x[j], y[j], z[j], cx, cy, cz);
-            mind[j] = d[j] < mind[j] ? d[j] : mind[j];
+            mind[j] = d[j] < mind[j] ? d[j] : mind[j];   // (fminf would add canonicalising v_max instructions: 86 vs 78 VALU)
             m[j] = __ballot(d[j] < r2);
         }
         int lower = 0, count = 0;
@@ -192,25 +192,27 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
             count += __popcll(m[j]);
         }
         const uint32_t tag = (uint32_t)c << 8;
+        // (unsigned 32-bit row positions from the object's uniform base: the stores then take their address as SGPR base +
+        // 32-bit lane offset instead of a 64-bit address built on the VALU - 8 of this loop's ~85 VALU instructions)
         if (count <= kMaxNbr) {  // (uniform) nothing to cut off
-            int pos = base + lower;
+            uint32_t pos = (uint32_t)(base + lower);
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const bool hit = d[j] < r2;
                 if (hit) rows_out[pos] = (uint16_t)(tag | (uint32_t)(i0 + j));
-                pos += hit ? 1 : 0;
+                pos += hit ? 1u : 0u;
             }
         } else {
-            int pos = lower;
+            uint32_t pos = (uint32_t)lower;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const bool hit = d[j] < r2;
-                if (hit && pos < kMaxNbr) rows_out[base + pos] = (uint16_t)(tag | (uint32_t)(i0 + j));
-                pos += hit ? 1 : 0;
+                if (hit && pos < (uint32_t)kMaxNbr) rows_out[(uint32_t)base + pos] = (uint16_t)(tag | (uint32_t)(i0 + j));
+                pos += hit ? 1u : 0u;
             }
         }
         const int kept = count < kMaxNbr ? count : kMaxNbr;
-        if (self_loops && lane == 0) rows_out[base + kept] = (uint16_t)(((c | 0x80) << 8) | c);
+        if (self_loops && lane == 0) rows_out[(uint32_t)(base + kept)] = (uint16_t)(((c | 0x80) << 8) | c);
         base += kept + (self_loops ? 1 : 0);
         if (c + 1 < n_c) {  // uniform
             float bd = mind[0];
