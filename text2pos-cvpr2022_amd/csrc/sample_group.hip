@@ -182,7 +182,9 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             d[j] = dist2(x[j], y[j], z[j], cx, cy, cz);
-            mind[j] = d[j] < mind[j] ? d[j] : mind[j];   // (fminf would add canonicalising v_max instructions: 86 vs 78 VALU)
+            // (fminf() adds canonicalising v_max instructions, an inline v_min_f32 breaks the packed distance math: both measured
+            // in instruction counts, 86 and 78 VALU per step against 74)
+            mind[j] = d[j] < mind[j] ? d[j] : mind[j];
             m[j] = __ballot(d[j] < r2);
         }
         int lower = 0, count = 0;
@@ -194,20 +196,21 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
         const uint32_t tag = (uint32_t)c << 8;
         // (unsigned 32-bit row positions from the object's uniform base: the stores then take their address as SGPR base +
         // 32-bit lane offset instead of a 64-bit address built on the VALU - 8 of this loop's ~85 VALU instructions)
+        char* const rows_b = (char*)rows_out;   // byte offsets: SGPR base + 32-bit lane offset, no shift per store
         if (count <= kMaxNbr) {  // (uniform) nothing to cut off
-            uint32_t pos = (uint32_t)(base + lower);
+            uint32_t off = 2u * (uint32_t)(base + lower);
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const bool hit = d[j] < r2;
-                if (hit) rows_out[pos] = (uint16_t)(tag | (uint32_t)(i0 + j));
-                pos += hit ? 1u : 0u;
+                if (hit) *(uint16_t*)(rows_b + off) = (uint16_t)(tag | (uint32_t)(i0 + j));
+                off += hit ? 2u : 0u;
             }
         } else {
             uint32_t pos = (uint32_t)lower;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const bool hit = d[j] < r2;
-                if (hit && pos < (uint32_t)kMaxNbr) rows_out[(uint32_t)base + pos] = (uint16_t)(tag | (uint32_t)(i0 + j));
+                if (hit && pos < (uint32_t)kMaxNbr) *(uint16_t*)(rows_b + 2u * ((uint32_t)base + pos)) = (uint16_t)(tag | (uint32_t)(i0 + j));
                 pos += hit ? 1u : 0u;
             }
         }
