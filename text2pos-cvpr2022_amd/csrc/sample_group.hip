@@ -182,8 +182,8 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             d[j] = dist2(x[j], y[j], z[j], cx, cy, cz);
-            // (fminf() adds canonicalising v_max instructions, an inline v_min_f32 breaks the packed distance math: both measured
-            // in instruction counts, 86 and 78 VALU per step against 74)
+            // (fminf() adds canonicalising v_max instructions; an inline v_min_f32 or an integer min on the bit patterns breaks the
+            // packed distance math: 86 / 78 / 78 VALU instructions per step against the 74 of this compare + select)
             mind[j] = d[j] < mind[j] ? d[j] : mind[j];
             m[j] = __ballot(d[j] < r2);
         }
