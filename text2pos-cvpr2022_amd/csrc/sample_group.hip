@@ -170,13 +170,14 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
                            float* qy, float* qz, uint16_t* __restrict__ rows_out, int self_loops, int* n_rows_out) {
     const int lane = threadIdx.x;
     const int i0 = lane * PPL;
-    float x[PPL], y[PPL], z[PPL], mind[PPL];
+    float x[PPL], y[PPL], z[PPL];
+    uint32_t mind[PPL];   // running minimum of the squared distances, as bit patterns (non-negative floats order like integers)
 #pragma unroll
     for (int j = 0; j < PPL; j++) {
         x[j] = px[i0 + j];
         y[j] = py[i0 + j];
         z[j] = pz[i0 + j];
-        mind[j] = INFINITY;
+        mind[j] = 0x7f800000u;   // +inf
     }
     int cur = 0;
     int base = 0;
@@ -193,9 +194,7 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             d[j] = dist2(x[j], y[j], z[j], cx, cy, cz);
-            // (fminf() adds canonicalising v_max instructions; an inline v_min_f32 or an integer min on the bit patterns breaks the
-            // packed distance math: 86 / 78 / 78 VALU instructions per step against the 74 of this compare + select)
-            mind[j] = d[j] < mind[j] ? d[j] : mind[j];
+            mind[j] = min(mind[j], __float_as_uint(d[j]));   // one v_min_u32 (a float compare + select takes two and an s_nop)
             m[j] = __ballot(d[j] < r2);
         }
         int lower = 0, count = 0;
@@ -230,14 +229,14 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
         base += kept + (self_loops ? 1 : 0);
         if (c + 1 < n_c) {  // uniform
             // (squared distances: non-negative, so the arg-max runs on bit patterns - see wave_max_u)
-            uint32_t bd = __float_as_uint(mind[0]);
+            uint32_t bd = mind[0];
 #pragma unroll
-            for (int j = 1; j < PPL; j++) bd = max(bd, __float_as_uint(mind[j]));
+            for (int j = 1; j < PPL; j++) bd = max(bd, mind[j]);
             const uint32_t mx = wave_max_u(bd);
             const unsigned long long tie = __ballot(bd == mx);
             int jb = PPL - 1;
 #pragma unroll
-            for (int j = PPL - 2; j >= 0; j--) jb = __float_as_uint(mind[j]) == mx ? j : jb;
+            for (int j = PPL - 2; j >= 0; j--) jb = mind[j] == mx ? j : jb;
             cur = __builtin_amdgcn_readlane(i0 + jb, (int)__builtin_ctzll(tie));
         }
     }
