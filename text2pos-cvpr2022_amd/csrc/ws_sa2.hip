@@ -369,7 +369,13 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         // DEFER (K <= 128, registers to spare): the atomics of batch t-1 ride between the MFMAs of batch t, fed from a
         // copy of its results; one more batch passes before a finished object may be flushed.
         constexpr bool DEFER = K <= 128;
-        f32x16 res[DEFER ? RT : 1][DEFER ? C::NTW : 1];
+        // PINGPONG (K = 128): two result arrays that swap roles from batch to batch - the MFMAs of batch t write one while the
+        // atomics of batch t-1 read the other - instead of one array and a 16-register copy per batch (which also put an
+        // s_nop 11 behind the last MFMA): SA2 -3.5 %.  K = 32 measured +1.2 % with it and keeps the copy.
+        constexpr bool PINGPONG = DEFER && K == 128;
+        constexpr int HALVES = PINGPONG ? 2 : 1;
+        f32x16 rr[HALVES][DEFER ? RT : 1][DEFER ? C::NTW : 1];
+        auto& res = rr[0];
         int prev_abuf = 0;
         if constexpr (DEFER) {
 #pragma unroll
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
-                    for (int e = 0; e < 16; e++) res[rt][nt][e] = 0.f;
+                    for (int e = 0; e < 16; e++) rr[0][rt][nt][e] = rr[HALVES - 1][rt][nt][e] = 0.f;
         }
         // atomics e0 .. e1-1 (flattened over row tile, column tile, accumulator register) of a finished batch
         auto atomics = [&](const f32x16 (&v)[DEFER ? RT : 1][DEFER ? C::NTW : 1], const uint2 (&four)[RT][4], int abuf,
@@ -396,7 +402,11 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             }
         };
         int t_end = 0;
-        for (int t = 0; valid(it_c); t++) {
+        int newest = 0;   // PINGPONG: the array the last batch filled
+        for (int t = 0; valid(it_c);) {
+#pragma unroll
+          for (int half = 0; half < HALVES; half++, t++) {
+            if (half > 0 && !valid(it_c)) break;
             t_end = t + 1;
             STAMP(0);
             {
@@ -421,7 +431,12 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
 
             const int buf = t & 1, sbuf = buf ^ 1, dbuf = (t + 2) & 3;
             BatchIt it_n = it_m;
-            f32x16 acc[RT][C::NTW];  // ONE accumulator for hi.hi + hi.lo + lo.hi (same scale); it starts at the bias block
+            // ONE accumulator for hi.hi + hi.lo + lo.hi (same scale); it starts at the bias block.  PINGPONG: it IS the result
+            // array of this batch
+            f32x16 acc_loc[PINGPONG ? 1 : RT][PINGPONG ? 1 : C::NTW];
+            f32x16 (*acc)[C::NTW];
+            if constexpr (PINGPONG) acc = rr[half ^ 1];
+            else acc = acc_loc;
             STAMP(1);
             // destination bytes of this lane's 16 accumulator rows (4 quads of 4 consecutive rows per row tile); written
             // two batches ago, fetched here so that the atomics behind the MFMAs do not start with an LDS round trip
@@ -459,7 +474,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
                 CHUNKS();
                 if constexpr (DEFER) {
                     constexpr int TOT = RT * C::NTW * 16;
-                    atomics(res, four, prev_abuf, (j * TOT) / C::NG, ((j + 1) * TOT) / C::NG);
+                    atomics(rr[PINGPONG ? half : 0], four, prev_abuf, (j * TOT) / C::NG, ((j + 1) * TOT) / C::NG);
                 }
                 SB();
 #pragma unroll
@@ -478,10 +493,14 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             const int abuf = C::ACC_BUFS == 2 ? (it_c.gi & 1) : 0;
             const bool obj_done = it_c.r0 + C::TR >= it_c.n;
             if constexpr (DEFER) {
+                if constexpr (PINGPONG) {
+                    newest = half ^ 1;
+                } else {
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++)
+                    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++) res[rt][nt] = acc[rt][nt];
+                        for (int nt = 0; nt < C::NTW; nt++) res[rt][nt] = acc[rt][nt];
+                }
                 prev_abuf = abuf;
                 // the object whose atomics ran in this batch may be flushed next; the one that just ended waits a batch
                 flush_g = flush_g1;
@@ -527,6 +546,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             __syncthreads();
             STAMP(7);
             trace_n++;
+          }
         }
         if (flush_g >= 0) {
             flush(flush_g, flush_buf);
@@ -539,7 +559,8 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) four[rt][q] = *(const uint2*)(dl + (wm * RT + rt) * 32 + 8 * q + 4 * h);
-            atomics(res, four, prev_abuf, 0, RT * C::NTW * 16);
+            if (PINGPONG && newest == 1) atomics(rr[HALVES - 1], four, prev_abuf, 0, RT * C::NTW * 16);
+            else atomics(rr[0], four, prev_abuf, 0, RT * C::NTW * 16);
             __syncthreads();
             if (flush_g1 >= 0) flush(flush_g1, flush_buf1);
         }
