@@ -25,6 +25,8 @@
 #ifndef T2P_GA2_V1
 #define T2P_GA2_V1 0
 #endif
+#include <type_traits>
+
 #include "t2p_common.h"
 
 namespace t2p {
@@ -296,6 +298,10 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
             mfma_block(i & 1, acc);
             float gmax_out = 0.f;
             (void)gmax_out;
+            // (a full batch - every batch but possibly the last of a launch - stores without the per-row bound: 16 compares and
+            // 16 exec-mask save / branch / restore sequences less per tile)
+            auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 const int trow0 = (wm * RT + rt) * 32;
@@ -318,12 +324,12 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                             if constexpr (SPLIT_IO == 2) {  // hand the activations on already split into fp16 hi / lo
                                 const fp16x2 hv = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
                                 const fp16x2 lv = __builtin_amdgcn_cvt_pkrtz((v - (float)hv[0]) * 2048.f, 0.f);
-                                if (r < n_rows) {
+                                if (FULL || r < n_rows) {
                                     ((__fp16*)p.out_hi + o0)[rr * p.ldo] = hv[0];
                                     ((__fp16*)p.out_lo + o0)[rr * p.ldo] = lv[0];
                                 }
                             } else {
-                                if (r < n_rows) (p.out + o0)[rr * p.ldo] = v;
+                                if (FULL || r < n_rows) (p.out + o0)[rr * p.ldo] = v;
                             }
                         }
                     } else {  // max over each 32-row tile = one object (ReLU = starting the max at 0)
@@ -331,11 +337,14 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
 #pragma unroll
                         for (int e = 0; e < 16; e++) m = fmaxf(m, acc[rt][nt][e]);
                         m = fmaxf(m, __shfl_xor(m, 32, 64));
-                        if (h == 0 && trow0 < n_rows)
+                        if (h == 0 && (FULL || trow0 < n_rows))
                             p.out[(g * (C::TR / 32) + wm * RT + rt) * (int64_t)p.ldo + slice * NW + lcol] = m;
                     }
                 }
             }
+            };
+            if (n_rows == C::TR) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
             if constexpr (X3 && MODE == WS_DENSE_STORE && SPLIT_IO != 2) guard_publish(p.amax_out, gmax_out);
             if (gn < p.n_groups) stage_write((i + 1) & 1);
             __syncthreads();
