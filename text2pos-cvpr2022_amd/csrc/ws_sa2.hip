@@ -369,10 +369,10 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         // DEFER (K <= 128, registers to spare): the atomics of batch t-1 ride between the MFMAs of batch t, fed from a
         // copy of its results; one more batch passes before a finished object may be flushed.
         constexpr bool DEFER = K <= 128;
-        // PINGPONG (K = 128): two result arrays that swap roles from batch to batch - the MFMAs of batch t write one while the
-        // atomics of batch t-1 read the other - instead of one array and a 16-register copy per batch (which also put an
-        // s_nop 11 behind the last MFMA): SA2 -3.5 %.  K = 32 measured +1.2 % with it and keeps the copy.
-        constexpr bool PINGPONG = DEFER && K == 128;
+        // PINGPONG (= DEFER): two result arrays that swap roles from batch to batch - the MFMAs of batch t write one while the
+        // atomics of batch t-1 read the other, the batch loop is unrolled by two - instead of one array and a 16-register copy
+        // per batch (which also put an s_nop 11 behind the last MFMA): SA2 -2..3 %, SA1 -5 %.
+        constexpr bool PINGPONG = DEFER;
         constexpr int HALVES = PINGPONG ? 2 : 1;
         f32x16 rr[HALVES][DEFER ? RT : 1][DEFER ? C::NTW : 1];
         auto& res = rr[0];
