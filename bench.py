@@ -266,24 +266,36 @@ def main():
     gather_events = []   # (start, end) torch events around the one exchange step, on the stream it runs on
 
     def step():
+        """One pass of the path through distributed.sharded_retrieval (the function pipeline.run_coarse runs): this rank's
+        cell block -> (N > 1: the one all-gather) -> this rank's query block ranked against the full database."""
         with torch.no_grad():
             main = torch.cuda.current_stream()
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side):   # launched first: the text branch runs underneath the cell kernels
                 queries = model.language_encoder.encode_tokens(d_tok, d_len, normalize=True)
-            # the fp16-range guard accumulates in a device word during the step; it is read once after the timed region
-            cells = model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
-                                                chunk_objects=args.chunk_objects, check_overflow=False,
-                                                streams=args.cell_streams)
-            if world > 1:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record(main)
-                cells = TD.all_gather_rows(cells, n_cells_total)       # the one exchange step (RCCL over xGMI)
-                ev[1].record(main)
-                gather_events.append(ev)
-            main.wait_stream(side)
-            queries.record_stream(main)
-            return ops.sim_topk(queries, cells, TOPK)
+
+            def encode_cells(lo, hi):
+                assert (lo, hi) == (c_lo, c_hi)
+                # the fp16-range guard accumulates in a device word during the step; it is read once after the timed region
+                return model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
+                                                   chunk_objects=args.chunk_objects, check_overflow=False,
+                                                   streams=args.cell_streams)
+
+            def encoded_queries(lo, hi):
+                assert (lo, hi) == (q_lo, q_hi)
+                main.wait_stream(side)
+                queries.record_stream(main)
+                return queries
+
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+            def around_exchange(what):      # events around the one exchange step (RCCL over xGMI), on the stream it runs on
+                ev[0 if what == "begin" else 1].record(main)
+                if what == "end":
+                    gather_events.append(ev)
+
+            return TD.sharded_retrieval(encode_cells, encoded_queries, lambda q, c, k: ops.sim_topk(q, c, k),
+                                        n_cells_total, n_q_total, TOPK, gather_result=False, around_exchange=around_exchange)
 
     def barrier():
         torch.cuda.synchronize()

@@ -31,6 +31,11 @@ extern "C" {
 
 #define T2P_ABI_VERSION 17
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
+#define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
+                                           cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
+                                           one chunk: ~0.6 MB per object, i.e. ~38 GB at the default chunk for a batch that
+                                           fills it (t2p_encode_cells_workspace_bytes gives the exact figure; a second
+                                           stream's call needs its own workspace) */
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)

@@ -141,3 +141,92 @@ def test_all_gather_rows_single_process_is_identity():
         assert TD.all_gather_rows(x, 5) is x
     finally:
         dist.destroy_process_group()
+
+
+# ---- BASELINE configs[4]: the evaluation pipeline (coarse retrieval + fine localisation) sharded over ranks -------------
+def _toy_scene(seed=11, n_cells=13, n_poses=21):
+    """A small synthetic scene in the package's own data model (odd sizes: uneven blocks on 2 ranks)."""
+    from text2pos_amd import data as D, synthetic as S
+    rng = np.random.default_rng(seed)
+    cells, poses = [], []
+    dirs = ["north", "south", "east", "west", "on-top"]
+    for i in range(n_cells):
+        objs = []
+        for j in range(int(rng.integers(6, 12))):
+            c = rng.random(3) * np.array([1.0, 1.0, 0.3])
+            n = int(rng.integers(30, 90))
+            objs.append(D.Object3d(j, 1000 * i + j, c + 0.05 * rng.standard_normal((n, 3)),
+                                   np.repeat(np.clip(rng.random((1, 3)), 0, 1), n, axis=0),
+                                   S.LABELS[int(rng.integers(0, len(S.LABELS)))]))
+        x, y = 30.0 * (i % 4), 30.0 * (i // 4)
+        cells.append(D.Cell(i, "toy1", objs, 30.0, np.array([x, y, 0.0, x + 30.0, y + 30.0, 10.0])))
+    for q in range(n_poses):
+        c = cells[int(rng.integers(0, n_cells))]
+        descs = [D.DescriptionBestCell(dirs[int(rng.integers(0, 5))], o.get_color_text(), o.label, o.id, True)
+                 for o in [c.objects[int(k)] for k in rng.integers(0, len(c.objects), 6)]]
+        poses.append(D.Pose(rng.random(3), c.bbox_w[0:3] + rng.random(3) * 30.0, c.id, "toy1", descs))
+    return cells, poses
+
+
+class _StubCoarse:
+    """CPU stand-in with the CellRetrievalNetwork surface run_coarse uses; its outputs depend on the SAMPLED points, so a
+    rank-dependent FixedPoints draw would show up as a different retrieval."""
+    embed_dim, device = 16, torch.device("cpu")
+
+    def encode_objects(self, objects, object_points):
+        rows = []
+        for objs, pts in zip(objects, object_points):
+            pos = pts.pos.double().view(len(objs), -1, 3)
+            f = torch.cat([pos.mean(1).sum(0), pos.abs().amax(1).sum(0), pts.x.double().mean(0),
+                           torch.tensor([len(objs) / 10.0], dtype=torch.float64)])
+            rows.append(torch.cat([torch.sin(f * (i + 1)) for i in range(2)])[: self.embed_dim])
+        return torch.nn.functional.normalize(torch.stack(rows).float(), dim=-1)
+
+    def encode_text(self, texts):
+        rows = [torch.tensor([(sum(map(ord, t)) * (i + 3)) % 97 / 97.0 - 0.5 for i in range(self.embed_dim)]) for t in texts]
+        return torch.nn.functional.normalize(torch.stack(rows).float(), dim=-1)
+
+
+class _StubFine:
+    device = torch.device("cpu")
+
+    def __call__(self, objects, hints, object_points):
+        from types import SimpleNamespace
+        b, pad = len(objects), len(objects[0])
+        key = torch.stack([p.pos.double().sum() for p in object_points])            # depends on the sampled points
+        m0 = ((torch.arange(pad)[None] + (key * 1000).long()[:, None]) % 9) - 2      # some -1 / -2 = unmatched
+        m0 = torch.where(m0 < 6, m0, torch.full_like(m0, -1)).clamp(min=-1)
+        off = torch.sin(key)[:, None, None] * torch.ones(b, 6, 2, dtype=torch.float64) * 0.1
+        return SimpleNamespace(matches0=m0, offsets=off)
+
+
+def _pipeline_tables(group_world):
+    import text2pos_amd  # noqa: F401
+    from text2pos_amd import io as IO, pipeline as PL
+    cells, poses = _toy_scene()
+    sc = IO.Scenes(cells, poses)
+    return PL.evaluate(_StubCoarse(), _StubFine(), sc, PL.PerCellTransform(64, 3), top_k=(1, 3, 5), threshs=(5, 10, 15),
+                       pad_size=8, queries_per_call=4, topk_fn=_topk)
+
+
+def _worker_pipeline(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = _pipeline_tables(world)
+    torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pipeline_equals_single_process(tmp_path, world):
+    """pipeline.evaluate under a process group (cells + queries of the coarse stage through distributed.sharded_retrieval,
+    queries of the fine stage in blocks) returns, on every rank, exactly what the single-process run returns: retrieval lists,
+    hit / close-by tables, coarse and fine localisation tables."""
+    want = _pipeline_tables(1)
+    mp.spawn(_worker_pipeline, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert len(want["retrievals"]) == 21 and all(len(r) == 5 for r in want["retrievals"])
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=False)
+        assert got["retrievals"] == want["retrievals"], f"rank {r}"
+        for name in ("hit", "close", "localisation", "fine_mean", "fine_offset", "fine_mean_conf"):
+            assert got[name] == want[name], (r, name)

@@ -404,6 +404,9 @@ def test_encode_cells_chunking_is_invisible(hip_model):
         again = hip_model.encode_objects_packed(*args, cell_ptr).cpu()
     assert torch.equal(one, again), "non-deterministic"
     assert torch.equal(one, many)
+    # a chunk is limited by the 32-bit table offsets of the SA kernels: refused up front with a message that says so
+    with torch.no_grad(), pytest.raises(RuntimeError, match="chunk_objects=70000 outside"):
+        hip_model.encode_objects_packed(*args, cell_ptr, chunk_objects=70000)
 
 
 def test_encode_cells_ragged_extremes_vs_oracle(hip_model, oracle_model):
@@ -936,6 +939,58 @@ def test_retrieval_properties_full_size():
     # self-retrieval: a cell queried by its own embedding ranks first with score ~1
     idx4, s4 = t2p.retrieve_topk(c, c[:50].contiguous(), 1)
     assert torch.equal(idx4.cpu()[:, 0], torch.arange(50)) and (s4 - 1).abs().max() < 1e-6
+
+
+def _config3_database(n_cells, seed=3):
+    """BASELINE configs[2]'s database shape: unit rows with exact duplicates on both sides of each of the 8 shard edges."""
+    from text2pos_amd import distributed as TD
+    g = torch.Generator().manual_seed(seed)
+    c = torch.nn.functional.normalize(torch.randn(n_cells, 256, generator=g), dim=-1)
+    for r in range(1, 8):
+        edge = TD.shard_range(n_cells, r, 8)[0]
+        c[edge - 1] = c[5 * r]
+        c[edge] = c[5 * r]
+    return c
+
+
+@pytest.mark.parametrize("n_cells", [100_000, 100_001])
+def test_retrieval_config3_one_ranks_share(n_cells):
+    """BASELINE configs[2] as far as one GPU goes: ONE rank's query block (10,000 / 8 = 1,250 queries) ranked against the
+    gathered 100,000-row (and the uneven 100,001-row) database, k = 10, duplicates on the 8 shard edges: bit-exact against
+    the reference's float64 NumPy ranking (training/coarse.py:134-140).  Then the same database ranked shard by shard with
+    the shards' index offsets and merged: equal to the unsharded result (what the lower-traffic variant of SURVEY 8(e)
+    relies on, and the index bookkeeping of distributed.sharded_retrieval)."""
+    import text2pos_amd as t2p
+    from oracle.model import retrieve_topk_f64
+    from text2pos_amd import distributed as TD
+    nq, k = 1250, 10
+    c = _config3_database(n_cells)
+    g = torch.Generator().manual_seed(17)
+    q = torch.nn.functional.normalize(torch.randn(nq, 256, generator=g), dim=-1)
+    q[:7] = c[[5, 10, 15, 20, 25, 30, 35]]          # queries that ARE duplicated rows: their copies tie for rank 1
+    dc, dq = c.to(_dev()), q.to(_dev())
+    idx, score = t2p.retrieve_topk(dc, dq, k)
+    idx_h, score_h = idx.cpu().numpy(), score.cpu().numpy()
+    cn, qn = c.numpy(), q.numpy()
+    for lo in range(0, nq, 250):                     # (the oracle sorts all 100k scores per query: blocks bound its memory)
+        widx, wscore = retrieve_topk_f64(cn, qn[lo: lo + 250], k)
+        assert np.array_equal(idx_h[lo: lo + 250], widx), f"queries {lo}..{lo + 250}"
+        assert np.abs(score_h[lo: lo + 250] - wscore).max() < 1e-12
+    for r in range(7):                               # the three copies of row 5 r' (itself + both sides of edge r') lead, by index
+        edge = TD.shard_range(n_cells, r + 1, 8)[0]
+        assert idx_h[r, :3].tolist() == sorted([5 * (r + 1), edge - 1, edge])
+    # shard by shard with index offsets, merged on the host by (score desc, index asc)
+    cand_i, cand_s = [], []
+    for r in range(8):
+        lo, hi = TD.shard_range(n_cells, r, 8)
+        assert hi - lo in (12_500, 12_501)
+        i_r, s_r = t2p.retrieve_topk(dc[lo:hi], dq, k, index_offset=lo)
+        cand_i.append(i_r.cpu().numpy())
+        cand_s.append(s_r.cpu().numpy())
+    cand_i, cand_s = np.concatenate(cand_i, 1), np.concatenate(cand_s, 1)
+    order = np.lexsort((cand_i, -cand_s), axis=1)[:, :k]
+    assert np.array_equal(np.take_along_axis(cand_i, order, 1), idx_h)
+    assert np.array_equal(np.take_along_axis(cand_s, order, 1), score_h)
 
 
 # ---- fine stage (SURVEY 8(f) #1) ------------------------------------------------------------------------------------

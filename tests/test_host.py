@@ -416,6 +416,51 @@ class Net(nn.Module):
         assert all(torch.equal(got[k], want[k]) for k in want)
 
 
+def _stack_global_payload(module, name, args=()):
+    """A protocol-4 pickle that resolves `module`.`name` with STACK_GLOBAL and calls it (REDUCE) with `args`."""
+    import pickle
+    import pickletools  # noqa: F401  (documentation of the opcodes used below)
+    def short_unicode(s_):
+        b = s_.encode()
+        return b"\x8c" + bytes([len(b)]) + b
+    body = b"\x80\x04" + short_unicode(module) + short_unicode(name) + b"\x93"      # PROTO 4, two strings, STACK_GLOBAL
+    body += pickle.dumps(tuple(args), protocol=4)[2:-1]                                # the argument tuple (no PROTO / STOP)
+    return body + b"R."                                                               # REDUCE, STOP
+
+
+def test_unpicklers_refuse_dotted_names_and_foreign_callables(tmp_path):
+    """under pickle protocol 4 `find_class` resolves dotted names attribute by attribute, so an allowlist keyed
+    on the MODULE alone ("torch.nn.modules.*") reaches any callable ("torch.os.getcwd" inside torch.nn.modules.module).
+    Neither loader may execute such a payload; names that merely live in an allowed module's namespace are refused too."""
+    import io as _io
+    import pickle
+    from text2pos_amd import io as IO
+    hits = []
+    import os as _os
+    real = _os.getcwd
+    _os.getcwd = lambda: hits.append("called") or real()
+    try:
+        for module, name in (("torch.nn.modules.module", "torch.os.getcwd"), ("torch._utils", "torch.os.getcwd"),
+                             ("torch.nn.modules.module", "OrderedDict.fromkeys")):
+            blob = _stack_global_payload(module, name)
+            out = IO._CheckpointUnpickler(_io.BytesIO(blob)).load()       # resolves to an inert shell, never the callable
+            assert not hits and isinstance(out, (IO._Shell, IO._DictShell)), (module, name, out)
+            with pytest.raises(pickle.UnpicklingError):
+                IO._SceneUnpickler(_io.BytesIO(blob)).load()
+            assert not hits
+        # a plain name that an allowed module only IMPORTS (not an nn.Module class defined there) is refused outright
+        for module, name in (("torch.nn.modules.module", "warnings"), ("torch.nn.modules.module", "OrderedDict")):
+            with pytest.raises(pickle.UnpicklingError):
+                IO._CheckpointUnpickler(_io.BytesIO(_stack_global_payload(module, name))).load()
+        # ... and torch._utils only yields its tensor / parameter rebuild functions
+        out = IO._CheckpointUnpickler(_io.BytesIO(_stack_global_payload("torch._utils", "_rebuild_not_a_thing"))).load()
+        assert isinstance(out, IO._Shell)
+        assert not IO._allowed_global("torch._utils", "_get_device_index", True)
+        assert IO._allowed_global("torch._utils", "_rebuild_tensor_v2", True) and IO._allowed_global("torch._utils", "_rebuild_parameter", True)
+    finally:
+        _os.getcwd = real
+
+
 def test_draw_rotations_and_oracle_rotate_z():
     """Host draw of T.RandomRotate(120, axis=2) + its CPU restatement: unit (cos, sin) rows inside the range, z and the
     xy norms untouched, and the matrix convention pos @ [[c, s, 0], [-s, c, 0], [0, 0, 1]]."""

@@ -62,6 +62,21 @@ class CellRetrievalNetwork(nn.Module):
         self._pack = None
 
     # ---- text branch -----------------------------------------------------------------------------------------
+
+    # `precision` also selects the text branch's recurrence: one switch for the whole model, also when it is flipped after
+    # construction (bench.py's fp32 pass and the on_overflow="fp32" recomputation do exactly that)
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        if value not in ("f16x3", "fp32"):
+            raise ValueError("precision must be 'f16x3' or 'fp32'")
+        self._precision = value
+        lang = self._modules.get("language_encoder") if "_modules" in self.__dict__ else None
+        if lang is not None:
+            lang.precision = value
     def encode_text(self, descriptions):
         """List[str] -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:69-75).  With gradients enabled the text
         branch runs its training-mode recurrence and the result carries a grad_fn (training/coarse.py:44)."""

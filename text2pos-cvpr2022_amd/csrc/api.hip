@@ -206,6 +206,11 @@ int check_cfg(const t2p_cell_config* cfg) {
     T2P_CHECK_ARG(cfg->knn_k >= 1 && cfg->knn_k <= 32, "encode_cells: knn_k=%d outside [1,32]", cfg->knn_k);
     T2P_CHECK_ARG(cfg->precision == 0 || cfg->precision == 1, "encode_cells: precision=%d (0 = fp32, 1 = f16x3)",
                   cfg->precision);
+    // 32-bit byte offsets into the per-chunk tables (n_obj * 128 points * 128 floats * 4 B < 2^32) and 16-bit object-local
+    // indices cap a chunk at 65,535 objects; checked here, not deep inside a kernel launcher
+    T2P_CHECK_ARG(cfg->chunk_objects >= 0 && cfg->chunk_objects <= T2P_MAX_CHUNK_OBJECTS,
+                  "encode_cells: chunk_objects=%d outside [0, %d] (0 = default %d); the workspace takes ~0.6 MB per object of a chunk",
+                  cfg->chunk_objects, T2P_MAX_CHUNK_OBJECTS, T2P_DEFAULT_CHUNK_OBJECTS);
     T2P_CHECK_ARG(!cfg->class_embed || cfg->class_idx != nullptr, "encode_cells: class_embed needs class_idx");
     T2P_CHECK_ARG(!cfg->color_embed || cfg->color_idx != nullptr, "encode_cells: color_embed needs color_idx");
     return 0;
@@ -595,6 +600,9 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
             const int m = cell_ptr_host[c + 1] - cell_ptr_host[c];
             max_cell = m > max_cell ? m : max_cell;
         }
+        T2P_CHECK_ARG(n <= T2P_MAX_CHUNK_OBJECTS,
+                      "encode_cells: cell %lld alone holds %lld objects; a chunk (whole cells) is limited to %d objects",
+                      (long long)c0, (long long)n, T2P_MAX_CHUNK_OBJECTS);
         Bump b{(char*)workspace, 0, workspace_bytes};
         CellWs ws;
         const size_t need = carve(b, n, nb, *cfg, &ws);

@@ -456,10 +456,12 @@ __global__ __launch_bounds__(64) void k_dedup_rows(const float* __restrict__ xyz
         const int n = n_rows[o];
         const uint4* list4 = (const uint4*)list;
         int out = 0;
-        uint4 cur = n > 0 ? list4[lane] : uint4{0, 0, 0, 0};
+        // (a lane's 8 rows are fetched only when they lie inside the object's max_rows slice: the last step of a long list
+        // would otherwise read up to 766 bytes past it - past the caller's tensor for the last object)
+        uint4 cur = (n > 0 && lane * 8 + 8 <= max_rows) ? list4[lane] : uint4{0, 0, 0, 0};
         for (int b = 0; b < n; b += 512) {
             uint4 nxt = uint4{0, 0, 0, 0};
-            if (b + 512 < n) nxt = list4[(b + 512) / 8 + lane];
+            if (b + 512 < n && b + 512 + lane * 8 + 8 <= max_rows) nxt = list4[(b + 512) / 8 + lane];
             const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
             uint32_t v[8];
             bool keep[8];
@@ -494,6 +496,8 @@ __global__ __launch_bounds__(64) void k_dedup_rows(const float* __restrict__ xyz
 int launch_dedup_rows(const float* xyz, const float* rgb, int64_t n_obj, int n_pts, uint16_t* rows, uint16_t* n_rows,
                       int n_cent, hipStream_t st) {
     T2P_CHECK_ARG(n_pts == kMaxPts && xyz && rgb && rows && n_rows, "dedup_rows: built for %d points per object", kMaxPts);
+    T2P_CHECK_ARG(n_cent > 0 && (n_cent * (kMaxNbr + 1)) % 8 == 0 && ((uintptr_t)rows & 15) == 0,
+                  "dedup_rows: the row lists are read 16 bytes at a time: n_cent * 33 must be a multiple of 8 (n_cent = %d)", n_cent);
     if (n_obj == 0) return 0;
     const int64_t grid = n_obj < (int64_t)num_cus() * 32 ? n_obj : (int64_t)num_cus() * 32;
     ProfScope ps_("dedup_rows", st);

@@ -6,7 +6,7 @@ Contiguous blocks keep `global cell index = shard offset + local index`, so the 
 to the single-GPU result.  The compute steps are injected (encode_fn / topk_fn), which is how the gloo CPU tests
 exercise the partition + collective + index logic without a GPU.
 """
-from typing import Callable, Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -19,10 +19,17 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def rank_and_world(group=None) -> Tuple[int, int]:
+    """(rank, world size) of the process group; (0, 1) when torch.distributed is not initialised (single-GPU runs)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Gather row blocks of unequal size (shard_range layout) into the full [n_total, D] matrix on every rank.
     One collective: shards are padded to the largest block so that all_gather_into_tensor applies."""
-    world = dist.get_world_size(group)
+    _, world = rank_and_world(group)
     if world == 1:
         return local
     sizes = [shard_range(n_total, r, world) for r in range(world)]
@@ -42,16 +49,23 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
 def sharded_retrieval(encode_local_cells: Callable[[int, int], torch.Tensor],
                       encode_local_queries: Callable[[int, int], torch.Tensor],
                       topk_fn: Callable[[torch.Tensor, torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]],
-                      n_cells: int, n_queries: int, k: int, group=None, gather_result: bool = True):
+                      n_cells: int, n_queries: int, k: int, group=None, gather_result: bool = True,
+                      around_exchange: Optional[Callable[[str], None]] = None):
     """encode_local_cells(lo, hi) -> [hi-lo, D] embeddings of this rank's cell block (same for queries);
     topk_fn(queries, cells, k) -> (idx int64 [nq, k], score f64 [nq, k]).
-    Returns (idx, score) for all queries on every rank (gather_result) or for this rank's query block."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    Returns (idx, score) for all queries on every rank (gather_result) or for this rank's query block.
+    around_exchange("begin" | "end") is called right before / after the one collective of the path (bench.py records
+    stream events there).  Without an initialised process group this is the single-GPU path (no collective)."""
+    rank, world = rank_and_world(group)
     c_lo, c_hi = shard_range(n_cells, rank, world)
     q_lo, q_hi = shard_range(n_queries, rank, world)
     cells_local = encode_local_cells(c_lo, c_hi)
     queries_local = encode_local_queries(q_lo, q_hi)
+    if around_exchange is not None and world > 1:
+        around_exchange("begin")
     cells_all = all_gather_rows(cells_local, n_cells, group)          # the one exchange step of the path
+    if around_exchange is not None and world > 1:
+        around_exchange("end")
     idx, score = topk_fn(queries_local, cells_all, k)
     if not gather_result or world == 1:
         return idx, score

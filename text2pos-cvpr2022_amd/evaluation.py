@@ -104,11 +104,14 @@ def create_hint_description(pose) -> List[str]:
 
 
 def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Sequence[str]], transform, pad_size: int,
-             top_k, threshs, queries_per_call: int = 64):
+             top_k, threshs, queries_per_call: int = 64, group=None):
     """Fine localisation of every query against its max(top_k) retrieved cells (evaluation/pipeline.py:172-279).
     `model(objects, hints, object_points)` is SuperGlueMatch (or anything returning .matches0 [B, pad] / .offsets
     [B, hints, 2]); unlike the reference, which calls the model once per query (10 samples), `queries_per_call` queries
-    share a call.  Returns (accuracies_mean, accuracies_offset, accuracies_mean_conf)."""
+    share a call.  Returns (accuracies_mean, accuracies_offset, accuracies_mean_conf).
+    With an initialised torch.distributed process group the queries are split over the ranks in contiguous blocks
+    (samples are independent) and the per-query estimates are all-gathered: every rank returns the same tables."""
+    from . import distributed as TD
     from .data import Object3d, batch_object_points
     from .superglue_matcher import get_pos_in_cell
     kmax = max(top_k)
@@ -124,19 +127,22 @@ def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Seque
         return padded[cell_id]
 
     nq = len(poses)
+    rank, world = TD.rank_and_world(group)
+    q_lo, q_hi = TD.shard_range(nq, rank, world)
     pos_mean = np.zeros((nq, kmax, 2))
     pos_off = np.zeros((nq, kmax, 2))
     conf = np.zeros((nq, kmax), dtype=np.int64)
-    for q0 in range(0, nq, queries_per_call):
-        q1 = min(q0 + queries_per_call, nq)
+    for q0 in range(q_lo, q_hi, queries_per_call):
+        q1 = min(q0 + queries_per_call, q_hi)
         objects, hints, points = [], [], []
         for q in range(q0, q1):
             h = create_hint_description(poses[q])
-            for cid in retrievals[q]:
+            for c, cid in enumerate(retrievals[q]):
                 objs = pad(cid)
                 objects.append(objs)
                 hints.append(h)
-                points.append(batch_object_points(objs, transform))
+                tf = transform.for_cell(q * kmax + c) if hasattr(transform, "for_cell") else transform
+                points.append(batch_object_points(objs, tf))
         with torch.no_grad():  # evaluation/pipeline.py:171
             out = model(objects, hints, points)
         m0 = np.asarray(out.matches0.detach().cpu() if hasattr(out.matches0, "detach") else out.matches0)
@@ -146,6 +152,14 @@ def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Seque
             pos_mean[q, c] = get_pos_in_cell(objs, m0[i], np.zeros_like(off[i]))
             pos_off[q, c] = get_pos_in_cell(objs, m0[i], off[i])
             conf[q, c] = int(np.sum(m0[i] >= 0))
+    if world > 1:   # every rank gets every query's estimates (3 small gathers; float64 / int64 travel unchanged)
+        import torch.distributed as dist
+        dev = getattr(model, "device", None) if dist.get_backend(group) == "nccl" else None
+        def gather(a):
+            t = torch.from_numpy(np.ascontiguousarray(a[q_lo:q_hi]).reshape(q_hi - q_lo, -1))
+            t = TD.all_gather_rows(t.to(dev) if dev is not None else t, nq, group)
+            return t.cpu().numpy().reshape(a.shape)
+        pos_mean, pos_off, conf = gather(pos_mean), gather(pos_off), gather(conf)
     acc_mean = localisation_accuracies(poses, retrievals, cells_dict, top_k, threshs, pos_mean)
     acc_off = localisation_accuracies(poses, retrievals, cells_dict, top_k, threshs, pos_off)
     # the single most confident candidate (most matched objects; first on ties), evaluated as top-1

@@ -36,8 +36,16 @@ _NUMPY_MODULES = ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "n
 _NUMPY_NAMES = {"_reconstruct", "ndarray", "dtype", "scalar", "_frombuffer"}
 
 
+_TORCH_REBUILD = {"_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_tensor_v3", "_rebuild_parameter",
+                  "_rebuild_parameter_with_state", "_rebuild_qtensor", "_rebuild_device_tensor_from_numpy",
+                  "_rebuild_device_tensor_from_cpu_tensor", "_rebuild_wrapper_subclass", "_rebuild_sparse_tensor",
+                  "_rebuild_nested_tensor", "_rebuild_meta_tensor_no_storage"}
+
+
 def _allowed_global(module: str, name: str, torch_ok: bool) -> bool:
     module = {"__builtin__": "builtins", "copy_reg": "copyreg"}.get(module, module)   # protocol <= 2 spells them the py2 way
+    if "." in name:   # protocol 4 resolves dotted names attribute by attribute: "torch.os.system" under an allowed module
+        return False  # would reach any callable.  Nothing legitimate here is a nested attribute.
     if module == "builtins":
         return name in _SAFE_BUILTINS
     if module == "collections":
@@ -49,7 +57,7 @@ def _allowed_global(module: str, name: str, torch_ok: bool) -> bool:
     if not torch_ok:
         return False
     if module == "torch._utils":
-        return name.startswith("_rebuild_")
+        return name in _TORCH_REBUILD
     if module == "torch":
         return name.endswith("Storage") or name in ("Size", "device", "Tensor", "dtype", "float32", "float64", "int64")
     if module == "torch.nn.parameter":
@@ -141,9 +149,15 @@ class _CheckpointUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if _allowed_global(module, name, torch_ok=True):
             try:
-                return super().find_class(module, name)
+                obj = super().find_class(module, name)
             except (ImportError, AttributeError):
-                pass
+                obj = None
+            # torch.nn.modules.*: only nn.Module classes DEFINED in that module (not what the module happens to import)
+            if obj is not None and module.startswith("torch.nn.modules."):
+                if not (isinstance(obj, type) and issubclass(obj, nn.Module) and obj.__module__ == module):
+                    raise pickle.UnpicklingError(f"checkpoint names {module}.{name}, which is not an nn.Module class of that module")
+            if obj is not None:
+                return obj
         # everything else (the reference's models.*, torch_geometric.*, easydict, argparse.Namespace, ... - importable or
         # not) becomes an inert shell: a bare nn.Module or a dict that keeps the state the pickle assigns
         key = f"{module}.{name}"

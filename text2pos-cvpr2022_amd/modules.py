@@ -127,7 +127,10 @@ class LanguageEncoder(nn.Module):
         if self._pack is None or self._pack[0] != ver:
             try:
                 t = packing.pack_text_weights(self, self.device, x3=self.precision == "f16x3")
-            except packing.Fp16RangeError:   # a recurrent weight outside fp16's range: the exact path has no such limit
+            except packing.Fp16RangeError as e:   # a recurrent weight outside fp16's range: the exact path has no such limit
+                import warnings
+                warnings.warn(f"LanguageEncoder: {e}; the text branch runs its exact fp32 recurrence instead (about 3x "
+                              "slower than the f16x3 one)", RuntimeWarning, stacklevel=3)
                 t = packing.pack_text_weights(self, self.device, x3=False)
             self._pack = (ver, t, ops.make_text_weights(t["embedding"], t["w_ih"], t["w_hh"], t["bias"], t.get("w_hh_x3"),
                                                         t.get("w_hh_scale", 0.0)))

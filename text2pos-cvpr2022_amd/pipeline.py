@@ -5,7 +5,9 @@
         --path_coarse ./checkpoints/coarse.pth --path_fine ./checkpoints/fine.pth [--scenes 2013_05_28_drive_0010_sync ...]
 
 Checkpoints are the reference's whole-module pickles (io.load_reference_checkpoint) or plain state_dicts.
-BASELINE.json configs[4]; one process per GPU shards the cells exactly like bench.py (distributed.sharded_retrieval).
+BASELINE.json configs[4].  Multi-GPU: launched with torch.distributed.run (one process per GPU), run_coarse shards the
+cells and the queries over the ranks through distributed.sharded_retrieval - the function bench.py's step runs - with one
+RCCL all-gather of the cell embeddings; the fine stage then splits the queries over the ranks (evaluate()).
 """
 import argparse
 from types import SimpleNamespace
@@ -28,26 +30,58 @@ def default_transform(n_pts: int = 256, seed: Optional[int] = None):
     return D.Compose([D.FixedPoints(n_pts, generator=np.random.default_rng(seed)), D.NormalizeScale()])
 
 
+class PerCellTransform:
+    """FixedPoints + NormalizeScale whose random draw depends on (seed, global cell index) only, so that a cell gets the same
+    256 points whichever rank encodes it: the sharded pipeline then reproduces the single-process result bit for bit.
+    (`default_transform` keeps one sequential generator, like the reference's dataloader; its draws depend on the order in
+    which a process walks the cells.)"""
+
+    def __init__(self, n_pts: int = 256, seed: int = 0):
+        self.n_pts, self.seed = n_pts, seed
+
+    def for_cell(self, cell_index: int):
+        return default_transform(self.n_pts, self.seed * 1_000_003 + cell_index)
+
+
 @torch.no_grad()
 def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], threshs: Sequence[int], cells_per_call: int = 512,
-               texts_per_call: int = 1024):
+               texts_per_call: int = 1024, group=None, topk_fn=None):
     """Encode every cell and every query, rank in float64, report hit@k / close-by@k and recall within the thresholds
     when the retrieved cell's centre is the estimate.  Returns (retrievals, accuracies dict).
+
+    The retrieval goes through distributed.sharded_retrieval: with an initialised torch.distributed process group (one
+    process per GPU, backend "nccl" = RCCL) every rank encodes its contiguous block of the cells and of the queries, ONE
+    all-gather exchanges the cell embeddings, every rank ranks its query block against the full database, and the [Nq, k]
+    index lists are gathered, so every rank returns the same tables; without a process group it is the single-GPU path
+    (BASELINE configs[4]; evaluation/pipeline.py:60-137).
     cells_per_call: the reference's loader hands over 64 cells per batch (evaluation/pipeline.py:303-308); cells are
     independent, so the batch size does not change a bit of the result, and 64 cells (about a thousand objects) fill a
     third of the GPU: 512 by default.  The host-side transform of every object (FixedPoints + NormalizeScale in NumPy)
-    is what bounds this loop either way; model.encode_raw_objects runs that chain on the GPU."""
+    is what bounds this loop either way; model.encode_raw_objects runs that chain on the GPU.
+    topk_fn(queries, cells, k): the ranking kernel (default retrieval.retrieve_topk; the gloo CPU test injects the oracle's)."""
+    from . import distributed as TD
     cells, poses = scenes.all_cells, scenes.all_poses
-    enc = []
-    for lo in range(0, len(cells), cells_per_call):
-        chunk = cells[lo: lo + cells_per_call]
-        objects = [list(c.objects) for c in chunk]
-        enc.append(model.encode_objects(objects, [D.batch_object_points(o, transform) for o in objects]))
-    cell_enc = torch.cat(enc)
     texts = scenes.texts
-    text_enc = torch.cat([model.encode_text(texts[lo: lo + texts_per_call]) for lo in range(0, len(texts), texts_per_call)])
+
+    def encode_cells(lo, hi):
+        enc = []
+        for a in range(lo, hi, cells_per_call):
+            b = min(a + cells_per_call, hi)
+            objects = [list(c.objects) for c in cells[a:b]]
+            if hasattr(transform, "for_cell"):
+                points = [D.batch_object_points(o, transform.for_cell(a + i)) for i, o in enumerate(objects)]
+            else:
+                points = [D.batch_object_points(o, transform) for o in objects]
+            enc.append(model.encode_objects(objects, points))
+        return torch.cat(enc) if enc else torch.zeros((0, model.embed_dim), device=model.device)
+
+    def encode_queries(lo, hi):
+        enc = [model.encode_text(texts[a: min(a + texts_per_call, hi)]) for a in range(lo, hi, texts_per_call)]
+        return torch.cat(enc) if enc else torch.zeros((0, model.embed_dim), device=model.device)
+
     kmax = int(max(top_k))
-    idx, _ = retrieve_topk(cell_enc, text_enc, kmax)
+    rank_fn = topk_fn if topk_fn is not None else (lambda q, c, k: retrieve_topk(c, q, k))
+    idx, _ = TD.sharded_retrieval(encode_cells, encode_queries, rank_fn, len(cells), len(texts), kmax, group)
     idx = np.asarray(idx.cpu()) if hasattr(idx, "cpu") else np.asarray(idx)
     db_ids = [c.id for c in cells]
     centers = np.array([c.get_center()[0:2] for c in cells])
@@ -61,12 +95,14 @@ def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], thresh
 
 @torch.no_grad()
 def evaluate(model_coarse, model_fine, scenes: IO.Scenes, transform, top_k=(1, 5, 10), threshs=(5, 10, 15), pad_size=16,
-             queries_per_call: int = 64) -> Dict[str, object]:
-    retrievals, out = run_coarse(model_coarse, scenes, transform, top_k, threshs)
+             queries_per_call: int = 64, group=None, topk_fn=None) -> Dict[str, object]:
+    """Coarse retrieval + fine localisation.  `group`: torch.distributed process group (None = the default group when one
+    is initialised, else single GPU); every rank returns the same tables."""
+    retrievals, out = run_coarse(model_coarse, scenes, transform, top_k, threshs, group=group, topk_fn=topk_fn)
     out["retrievals"] = retrievals
     if model_fine is not None:
         mean, off, conf = E.run_fine(model_fine, scenes.all_poses, scenes.cells_dict, retrievals, transform, pad_size,
-                                     list(top_k), list(threshs), queries_per_call)
+                                     list(top_k), list(threshs), queries_per_call, group=group)
         out.update(fine_mean=mean, fine_offset=off, fine_mean_conf=conf)
     return out
 
@@ -115,10 +151,19 @@ def main(argv: Optional[List[str]] = None):
     ap.add_argument("--use_features", nargs="+", default=["class", "color", "position"])
     ap.add_argument("--seed", type=int, default=0, help="seed of the T.FixedPoints draw")
     a = ap.parse_args(argv)
+    # one process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from its environment)
+    import os
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    say = print if rank == 0 else (lambda *x, **k: None)
     scenes = IO.load_scenes(a.base_path, a.scenes)
-    print(f"{len(scenes.all_cells)} cells, {len(scenes.all_poses)} poses from {a.scenes}")
+    say(f"{len(scenes.all_cells)} cells, {len(scenes.all_poses)} poses from {a.scenes}")
     words, classes = scenes.get_known_words(), scenes.get_known_classes()
-    dev = torch.device("cuda", 0)
     sd, ck = IO.load_reference_checkpoint(a.path_coarse, return_args=True)
     ca = args_from_checkpoint(_model_args(a.coarse_embed_dim, use_features=a.use_features), ck, "coarse")
     coarse = CellRetrievalNetwork(classes, D.COLOR_NAMES, words, ca)
@@ -131,14 +176,18 @@ def main(argv: Optional[List[str]] = None):
         fine = SuperGlueMatch(classes, D.COLOR_NAMES, words, fa)
         fine.load_state_dict(sd)
         fine = fine.to(dev).eval()
-    out = evaluate(coarse, fine, scenes, default_transform(n_pts, a.seed), a.top_k, a.threshs, a.pad_size)
-    print("Retrieval accuracies (hit@k):", out["hit"], " close-by@k:", out["close"])
-    print("Coarse (cell centre):")
-    E.print_accuracies(out["localisation"])
-    if fine is not None:
-        for name in ("fine_mean", "fine_offset", "fine_mean_conf"):
-            print(name + ":")
-            E.print_accuracies(out[name])
+    # per-cell seeding: the sampled points of a cell do not depend on which rank encodes it
+    out = evaluate(coarse, fine, scenes, PerCellTransform(n_pts, a.seed), a.top_k, a.threshs, a.pad_size)
+    if rank == 0:
+        print("Retrieval accuracies (hit@k):", out["hit"], " close-by@k:", out["close"])
+        print("Coarse (cell centre):")
+        E.print_accuracies(out["localisation"])
+        if fine is not None:
+            for name in ("fine_mean", "fine_offset", "fine_mean_conf"):
+                print(name + ":")
+                E.print_accuracies(out[name])
+    if world > 1:
+        dist.destroy_process_group()
     return out
 
 

@@ -96,6 +96,21 @@ class SuperGlueMatch(nn.Module):
         self._overflow = None   # fp16-range guard word of the object encoder's f16x3 calls (include/t2p.h)
 
     # ---- cached weight images -------------------------------------------------------------------------------------
+
+    # `precision` also selects the text branch's recurrence: one switch for the whole model, also when it is flipped after
+    # construction (bench.py's fp32 pass and the on_overflow="fp32" recomputation do exactly that)
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        if value not in ("f16x3", "fp32"):
+            raise ValueError("precision must be 'f16x3' or 'fp32'")
+        self._precision = value
+        lang = self._modules.get("language_encoder") if "_modules" in self.__dict__ else None
+        if lang is not None:
+            lang.precision = value
     def _object_pack(self):
         ver = (packing.params_version(self.object_encoder), str(self.device))
         if self._opack is None or self._opack[0] != ver:
@@ -152,6 +167,8 @@ class SuperGlueMatch(nn.Module):
         if bool(getattr(a, "class_embed", False)) != (class_idx is not None) or \
                 bool(getattr(a, "color_embed", False)) != (color_idx is not None):
             raise RuntimeError("args.class_embed / args.color_embed need class_idx / color_idx")
+        if "color" not in a.use_features and not getattr(a, "class_embed", False):
+            rgb = torch.zeros_like(rgb)   # models/object_encoder.py:86-90 (same rule as CellRetrievalNetwork.encode_objects_packed)
         cfg = ops.make_cell_config(n_pts=xyz.shape[1], embed_dim=d, pointnet_features=a.pointnet_features,
                                    use_features=tuple(a.use_features), self_loops=self.add_self_loops,
                                    radius=self.object_encoder.pointnet.radii, precision=self.precision,
