@@ -176,9 +176,13 @@ typedef struct t2p_cell_config {
      * fire for a checkpoint that would just have fitted, never the other way round.  The caller clears it, reads it after the stream has drained, and must
      * not trust the call's output when it is set (the Python host raises or re-runs with precision = 0).  NULL: no check. */
     int32_t* overflow_flag;
-    /* A/B switches between equivalent execution plans (0 = the default plan; results are bit-identical either way):
+    /* A/B switches between equivalent execution plans (0 = the default plan).  Bits 0 and 1 leave every output bit
+     * unchanged; bit 2 swaps SA level 2's kernel for one that adds the same products in another k grouping (fp32 rounding):
      *   bit 0: keep the edge rows of repeated points in SA level 1's row lists (default: t2p_dedup_rows drops them)
-     *   bit 1: f16x3 only: gather the centroid tables of SA levels 2 and 3 from HBM (default: built in LDS per object) */
+     *   bit 1: f16x3 only: gather the centroid tables of SA levels 2 and 3 from HBM (default: built in LDS per object);
+     *          SA level 2 then runs on the column-slice kernel of ws_sa2.hip
+     *   bit 2: f16x3 only: SA level 2 on the column-slice kernel of ws_sa2.hip (default: the row-owning kernel of
+     *          sa_rows.hip: a wave holds the whole 128 x 128 weight matrix and multiplies its own 32-row tiles) */
     int32_t tuning;
 } t2p_cell_config;
 

@@ -643,24 +643,37 @@ def test_dedup_rows_drops_only_repeats():
 
 
 def test_execution_plans_are_bit_identical(hip_model):
-    """t2p_cell_config.tuning switches between equivalent plans (repeated points' rows kept / dropped; centroid tables of
-    SA levels 2-3 gathered from HBM / built in LDS): the cell embeddings must not differ in a single bit."""
+    """t2p_cell_config.tuning switches between equivalent plans.  Bits 0 / 1 (repeated points' rows kept / dropped; centroid
+    tables of SA levels 2-3 gathered from HBM / built in LDS) must not change a single bit of any output.  Bit 2 moves SA
+    level 2 from the row-owning kernel (sa_rows.hip, the default with LDS tables) to the column-slice kernel (ws_sa2.hip, also
+    what bit 1 selects): the same f16x3 products summed in another k grouping, so the two families agree to fp32 rounding
+    (SA1's output, in front of the switch, bit for bit) and each family is bit-identical within itself."""
     from text2pos_amd import synthetic as S
     xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(77, 40)
     args = _to_dev(xyz, rgb, center, mean_rgb)
-    outs = []
+    outs = {}
     try:
-        for tuning in (0, 1, 2, 3):
+        for tuning in range(8):
             hip_model.tuning = tuning
             with torch.no_grad():
-                out, tr = hip_model.encode_objects_packed(*args, cell_ptr, want_trace=("sa_out", "obj_emb"))
-            outs.append((out, tr))
+                outs[tuning] = hip_model.encode_objects_packed(*args, cell_ptr, want_trace=("sa_out", "obj_emb"))
     finally:
         hip_model.tuning = 0
-    for out, tr in outs[1:]:
-        assert torch.equal(out, outs[0][0]) and torch.equal(tr["obj_emb"], outs[0][1]["obj_emb"])
-        for l in range(3):
-            assert torch.equal(tr["sa_out"][l], outs[0][1]["sa_out"][l]), f"SA{l + 1} output"
+    families = ((0, 1), (2, 3, 4, 5, 6, 7))     # SA2 on sa_rows.hip / on ws_sa2.hip
+    for fam in families:
+        ref_out, ref_tr = outs[fam[0]]
+        for t in fam[1:]:
+            out, tr = outs[t]
+            assert torch.equal(out, ref_out) and torch.equal(tr["obj_emb"], ref_tr["obj_emb"]), f"tuning {t}"
+            for l in range(3):
+                assert torch.equal(tr["sa_out"][l], ref_tr["sa_out"][l]), f"tuning {t}: SA{l + 1} output"
+    (a_out, a_tr), (b_out, b_tr) = outs[0], outs[2]
+    assert torch.equal(a_tr["sa_out"][0], b_tr["sa_out"][0]), "SA1 runs the same kernel in both families"
+    c2 = 128                                      # feature columns of SA2's output rows ([features | xyz 0 | pad])
+    d2 = (a_tr["sa_out"][1][:, :c2] - b_tr["sa_out"][1][:, :c2]).abs().max().item()
+    scale2 = b_tr["sa_out"][1][:, :c2].abs().max().item()
+    assert 0.0 < d2 < 2e-5 * max(1.0, scale2), f"SA2 outputs of the two kernels: max|delta| = {d2:.3e} (scale {scale2:.2e})"
+    assert (a_tr["obj_emb"] - b_tr["obj_emb"]).abs().max().item() < 2e-5 and (a_out - b_out).abs().max().item() < 2e-5
     # the two halves of the batch on two HIP streams (own workspaces) give the same rows
     with torch.no_grad():
         two = hip_model.encode_objects_packed(*args, cell_ptr, streams=2)

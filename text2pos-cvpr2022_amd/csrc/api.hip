@@ -285,6 +285,8 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
             bp[l].prefix_ws = ws.prefix[l];
             bp[l].bounds_ws = ws.bounds[l];
             bp[l].W_x3 = cfg.precision == 1 ? W.sa_w2_x3[l] : nullptr;
+            bp[l].wp = (lds_btab && l > 0) ? W.sa_w1[l] : nullptr;   // (non-null = LDS centroid table: selects the launch shape)
+            bp[l].plan = (cfg.tuning & 4) ? 1 : 0;
         }
         T2P_TRY(launch_sa_balance_levels(bp, Geo::H, Geo::C, st));
     }
@@ -338,6 +340,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.bounds_ws = ws.bounds[l];
         p.balanced = 1;
         p.amax_out = gslot(G_F1 + l);
+        p.plan = (cfg.tuning & 4) ? 1 : 0;
         T2P_TRY(launch_ws_sa(H, C, p, st));
     }
     // ---- global abstraction: [x | pos] -> 512 -> 1024, max over the object's 32 points ------------------------

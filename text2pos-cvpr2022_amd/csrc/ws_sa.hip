@@ -369,8 +369,9 @@ int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st
 int sa2_launch_shape(int H, int Cout, int64_t n_obj, int* tile_rows, int* n_wg);  // ws_sa2.hip
 
 // tile rows / workgroup count of the kernel launch_ws_sa will pick for (H, Cout)
-static int sa_launch_shape(int H, int Cout, bool x3, int64_t n_obj, int* tile_rows, int* n_wg) {
-    if (x3) return sa2_launch_shape(H, Cout, n_obj, tile_rows, n_wg);
+static int sa_launch_shape(int H, int Cout, const SaParams& p, int64_t n_obj, int* tile_rows, int* n_wg) {
+    if (sa_rows_selected(H, Cout, p)) return sa_rows_launch_shape(n_obj, tile_rows, n_wg);
+    if (p.W_x3 != nullptr) return sa2_launch_shape(H, Cout, n_obj, tile_rows, n_wg);
     int n = num_cus();
     if (n > n_obj) n = (int)n_obj;
     *n_wg = n;
@@ -389,7 +390,7 @@ int launch_sa_balance_levels(const SaParams p[3], const int H[3], const int C[3]
         j.n_rows[l] = p[l].n_rows;
         j.prefix[l] = p[l].prefix_ws;
         j.bounds[l] = p[l].bounds_ws;
-        T2P_TRY(sa_launch_shape(H[l], C[l], p[l].W_x3 != nullptr, p[l].n_obj, &j.tile_rows[l], &j.n_wg[l]));
+        T2P_TRY(sa_launch_shape(H[l], C[l], p[l], p[l].n_obj, &j.tile_rows[l], &j.n_wg[l]));
     }
     ProfScope ps_("sa_balance", st);
     hipLaunchKernelGGL(k_balance_levels, dim3(3), dim3(1024), 0, st, j);
@@ -401,6 +402,7 @@ int launch_ws_sa(int H, int Cout, const SaParams& p, hipStream_t st) {
     T2P_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.Bc) & 15) == 0, "ws_sa: tables must be 16-byte aligned");
     if (p.W_x3 != nullptr) {  // f16x3 split-precision path: the interleaved kernel (ws_sa2.hip)
         T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_sa: packed f16x3 weights must be 16-byte aligned");
+        if (sa_rows_selected(H, Cout, p)) return launch_sa_rows(H, Cout, p, st);
         return launch_ws_sa2(H, Cout, p, st);
     } else {
         if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2>(p, st, "ws_edge_sa_k32_n64");
