@@ -21,6 +21,11 @@
 //   * natural k order (lane half h owns k = 16 s + 8 h .. + 7 of MFMA step s): the host's register-order weight image is
 //     re-indexed at load time; every fp32 accumulation runs hi.hi, hi.lo, lo.hi per step like ws_sa2.hip, with another
 //     grouping of the k's (results agree to fp32 rounding, not bit for bit).
+// T2P_RABL (development only, results are wrong): 1 = no ring DMA, 2 = no atomics, 4 = no drain stores / table build,
+// 8 = no MFMAs (first and last of a step kept)
+#ifndef T2P_RABL
+#define T2P_RABL 0
+#endif
 #include "t2p_common.h"
 
 namespace t2p {
@@ -34,6 +39,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gl_void;
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#if T2P_RABL & 2
+#define DS_MAX_STR "; no atomic %0 %1 %2"
+#else
+#define DS_MAX_STR "ds_max_f32 %0, %1 offset:%2"
+#endif
 
 constexpr int kSubR = 1024;   // objects of a workgroup's range cached at a time (row counts, self-loop bases)
 
@@ -76,8 +87,9 @@ __device__ __forceinline__ float sub_half_r(float v, fp16x2 h) {   // v - (float
 
 // workgroup barrier that orders LDS traffic only (no vmcnt: outstanding LDS-DMA pieces of the ring must survive it)
 __device__ __forceinline__ void lds_barrier_r() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// counted wait for the ring: the 12 youngest DMA instructions (three slots) may stay in flight
-__device__ __forceinline__ void wait_ring() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+// counted wait for the ring: the 8 youngest DMA instructions (two slots) may stay in flight; the slot the wait retires is
+// read right away, the slot emptied one step earlier is refilled BEHIND the wait in the same step
+__device__ __forceinline__ void wait_ring() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 __device__ __forceinline__ void wait_all_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct TileRef {   // a tile of this wave: object (index inside the cached sub-range), first row, rows of the object
@@ -116,9 +128,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                 w_lo[nt][s] = __builtin_bit_cast(half8, wp[PLANE_U4 + idx]);
             }
     }
-    float biasv[C::NTW];
-#pragma unroll
-    for (int nt = 0; nt < C::NTW; nt++) biasv[nt] = p.bias[nt * 32 + rr];
+    // The bias is NOT part of the accumulation: a tile's first MFMAs start from 0, the LDS accumulator takes a FLOAT max of the
+    // raw products (ds_max_f32 orders negative values correctly) from a -inf start, and the drain forms relu(max + bias).
+    // (A bias block as the first MFMA's C operand costs 64 registers of a budget that is full.)
+    constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x4 bias4;         // this thread's four output columns in the drain (column quad = tid % (N / 4))
+    {
+        const int c4 = tid % (N / 4);
+        bias4 = *(const f32x4*)(p.bias + c4 * 4);
+    }
     // position rows of the layer-1 weights, this thread's column quad (centroid table build)
     constexpr int QPR = K / 4;                 // column quads per table row
     constexpr int CGS = C::NT / QPR;           // centroid groups of the workgroup
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
         dma_chunk[q] = (uint32_t)((((lane & 7) ^ ((r >> 1) & 7))) * 16);
     }
 
-    for (int i = tid; i < NC * N; i += C::NT) acc_lds[i] = 0;
+    for (int i = tid; i < NC * N; i += C::NT) acc_lds[i] = (int)0xFF800000;   // -inf
     uint32_t gbits = 0;   // fp16-range guard: wave-uniform maximum (bit pattern, before out_scale) of the drained outputs
 
     const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
@@ -197,60 +215,61 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
         __syncthreads();
 
         // ---- this wave's tile stream ------------------------------------------------------------------------------------
-        // (wave-uniform values read from LDS are moved to SGPRs: the tile stream's control flow stays scalar)
+        // Tiles of an object go round-robin to the waves: wave w owns rows [32 (w + NW i), +32).  All stream state is wave-uniform
+        // and lives in SGPRs (row counts / self-loop bases are fetched from LDS once per object).
         auto rows_of = [&](int gi) { return __builtin_amdgcn_readfirstlane((int)nr[gi]); };
-        auto ntile = [&](int gi) { return (rows_of(gi) + 31) >> 5; };
-        // first tile of this wave at or after object gi (cnt = none)
-        auto first_tile = [&](int gi) -> TileRef {
-            while (gi < cnt && ntile(gi) <= wave) gi++;
-            return TileRef{gi, wave * 32, gi < cnt ? rows_of(gi) : 0};
-        };
-        auto next_tile = [&](const TileRef& t) -> TileRef {
-            if (t.r0 + NW * 32 < t.n) return TileRef{t.gi, t.r0 + NW * 32, t.n};
-            return first_tile(t.gi + 1);
-        };
-        // row metadata of (tile, lane): list entry min(r0 + rr, n - 1): rows past the end repeat the last row (max is idempotent)
-        auto tile_meta = [&](const TileRef& t) -> uint32_t {
-            int idx = t.r0 + rr;
-            idx = idx < t.n ? idx : t.n - 1;
-            const uint16_t* rows_l = (const uint16_t*)(lds + C::ROWS_OFF + ((ga + t.gi) % 3) * C::ROWS_BUF);
+        // row metadata of (object gi, first row r0, lane): list entry min(r0 + rr, n - 1) - rows past the end repeat the last row
+        // (max is idempotent)
+        auto tile_meta = [&](int gi, int r0, int n) -> uint32_t {
+            int idx = r0 + rr;
+            idx = idx < n ? idx : n - 1;
+            const uint16_t* rows_l = (const uint16_t*)(lds + C::ROWS_OFF + ((ga + gi) % 3) * C::ROWS_BUF);
             return (uint32_t)rows_l[idx];
         };
-        // DMA byte offsets (into p.A) of a tile's rows for the four instructions of a slot
-        auto tile_voff = [&](const TileRef& t, uint32_t m, uint32_t (&voff)[4]) {
+        // byte offset (into p.A) of the lane's row
+        auto row_byte = [&](int gi, uint32_t sb0, uint32_t m) -> uint32_t {
             const uint32_t src = m & 0xFFu, d = m >> 8;
-            const uint32_t g = (uint32_t)(ga + t.gi);
-            const uint32_t sb0 = (uint32_t)__builtin_amdgcn_readfirstlane(sbase[t.gi]);
+            const uint32_t g = (uint32_t)(ga + gi);
             const uint32_t srow = (d & 0x80u) ? (sb0 + src) : (g * (uint32_t)C::ND + src);
-            const uint32_t rowbyte = srow * (uint32_t)(K * 4);
+            return srow * (uint32_t)(K * 4);
+        };
+        // ... and of the rows each DMA instruction of a slot fetches
+        auto tile_voff = [&](uint32_t rowbyte, uint32_t (&voff)[4]) {
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 voff[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)dma_sel[q], (int)rowbyte) + dma_chunk[q];
         };
+        auto dma_piece = [&](const uint32_t (&voff)[4], int u, int q) {
+            if constexpr (!(T2P_RABL & 1))
+                dma16(p.A, voff[q] + (uint32_t)(u * 128), ringb + (uint32_t)(u * C::SLOT_BYTES + q * 1024));
+        };
         auto issue_slot = [&](const uint32_t (&voff)[4], int u) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) dma16(p.A, voff[q] + (uint32_t)(u * 128), ringb + (uint32_t)(u * C::SLOT_BYTES + q * 1024));
+            for (int q = 0; q < 4; q++) dma_piece(voff, u, q);
         };
 
         // ---- per-object phases --------------------------------------------------------------------------------------------
-        auto flush = [&](int g) {   // accumulator -> output rows of object g; leaves the accumulator at +0
+        auto flush = [&](int g) {   // accumulator -> output rows of object g: relu(max + bias); leaves the accumulator at -inf
             float* o = p.out + (int64_t)g * NC * (int64_t)p.ldo;
             int top = 0;
+            static_assert(C::NT % (N / 4) == 0, "a thread keeps its column quad over the drain");
 #pragma unroll
             for (int k = 0; k < NC * N / 4 / C::NT; k++) {
                 const int i = tid + k * C::NT;
                 const int c = i / (N / 4), c4 = i % (N / 4);
                 typedef int i32x4 __attribute__((ext_vector_type(4)));
-                i32x4* a = (i32x4*)(acc_lds + c * N + c4 * 4);
-                const i32x4 bits = *a;
+                f32x4* a = (f32x4*)(acc_lds + c * N + c4 * 4);
+                const f32x4 raw = *a;
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    top = bits[e] > top ? bits[e] : top;
-                    v[e] = __int_as_float(bits[e]) * p.out_scale;
+                    const float r = fmaxf(raw[e] + bias4[e], 0.f);      // (a centroid without rows stays at -inf: 0, as before)
+                    const int bits = __float_as_int(r);
+                    top = bits > top ? bits : top;
+                    v[e] = r * p.out_scale;
                 }
                 *(f32x4*)(o + c * (int64_t)p.ldo + c4 * 4) = v;
-                *a = i32x4{0, 0, 0, 0};
+                *(i32x4*)a = i32x4{(int)0xFF800000, (int)0xFF800000, (int)0xFF800000, (int)0xFF800000};
             }
             guard_track_bits(gbits, top);
         };
@@ -278,43 +297,49 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
         if (cnt > 1) dma_cpos(ga + 1);
         lds_barrier_r();
 
-        TileRef cur = first_tile(0);
-        bool cur_fetched = false;        // the four slots of `cur` are in flight / landed
-        uint32_t m_cur = 0;              // metadata of this lane's row of `cur` (valid when cur_fetched)
+        bool cur_fetched = false;        // the four slots of this wave's next tile (first of object gi) are in flight / landed
+        uint32_t m_cur = 0;              // ... and this is the metadata of the lane's row of it
 
         for (int gi = 0; gi < cnt; gi++) {
             // ---- tiles of object gi that belong to this wave -------------------------------------------------------------
-            bool did_tile = false;
+            const int n_g = rows_of(gi), n_g1 = gi + 1 < cnt ? rows_of(gi + 1) : 0;
+            const uint32_t sb_g = (uint32_t)__builtin_amdgcn_readfirstlane(sbase[gi]);
+            const uint32_t sb_g1 = gi + 1 < cnt ? (uint32_t)__builtin_amdgcn_readfirstlane(sbase[gi + 1]) : 0u;
+            int r0 = wave * 32;
+            bool have = r0 < n_g;
+            const bool did_tile = have;
             half8 a_hi, a_lo;
-            bool prepped = false;    // a_hi / a_lo hold step 0 of `cur`
-            while (cur.gi == gi) {
-                did_tile = true;
+            bool prepped = false;    // a_hi / a_lo hold step 0 of the current tile
+            f32x16 acc[C::NTW];
+            bool pend = false;       // the last result block of the previous tile still waits for its atomics (rows: fourp)
+            uint2 fourp[4] = {};
+            while (have) {
                 if (!cur_fetched) {
-                    m_cur = tile_meta(cur);
+                    m_cur = tile_meta(gi, r0, n_g);
                     uint32_t v0[4];
-                    tile_voff(cur, m_cur, v0);
+                    tile_voff(row_byte(gi, sb_g, m_cur), v0);
 #pragma unroll
                     for (int u = 0; u < C::SLOTS; u++) issue_slot(v0, u);
-                    cur_fetched = true;
                 }
                 // look ahead: the next tile is prefetched while this one is multiplied, if its row list is in LDS already
                 // (same object or the next one); otherwise the same addresses are fetched again to keep the DMA count of the
                 // counted waits (the slot is dead by then)
-                const TileRef nxt = next_tile(cur);
-                const bool nxt_ok = nxt.gi < cnt && nxt.gi <= gi + 1;
-                uint32_t m_nxt = m_cur;
+                const bool chain = r0 + NW * 32 < n_g;                              // next tile in the same object
+                const bool nxt_ok = chain || (gi + 1 < cnt && wave * 32 < n_g1);
+                const int gi_n = chain ? gi : (nxt_ok ? gi + 1 : gi);
+                const int r0_n = chain ? r0 + NW * 32 : (nxt_ok ? wave * 32 : r0);
+                const int n_n = (chain || !nxt_ok) ? n_g : n_g1;
+                const uint32_t sb_n = (chain || !nxt_ok) ? sb_g : sb_g1;
+                // its metadata: the LDS read is issued here, decoded inside step 0
+                uint32_t m_nxt = tile_meta(gi_n, r0_n, n_n);
                 uint32_t vn[4];
-                {
-                    const TileRef src = nxt_ok ? nxt : cur;
-                    m_nxt = tile_meta(src);
-                    tile_voff(src, m_nxt, vn);
-                }
                 // this tile: centroid of the lane's row -> table row, accumulator row
                 const uint32_t dl = (m_cur >> 8) & 127u;
                 const uint32_t brow = (uint32_t)C::BT_OFF + dl * (uint32_t)C::BT_STRIDE + (uint32_t)(h * 32);
-                // (inline asm: hipcc puts s_waitcnt vmcnt(0) in front of an ordinary ds_read it cannot separate from the
+                // (inline asm: hipcc puts s_waitcnt vmcnt(0) in front of an ordinary LDS access it cannot separate from the
                 // outstanding LDS-DMA pieces, which would drain the ring once per tile)
                 asm volatile("ds_write_b16 %0, %1" ::"v"(dstl_addr + (uint32_t)(rr * 2)), "v"(dl * (uint32_t)(N * 4)) : "memory");
+                uint2 four[4];   // accumulator-row byte offsets of this lane's 16 result rows 8 q + 4 h + {0..3} (fetched in step 6)
 
                 auto read_step = [&](int s, uint32_t brow_, f32x4 (&x)[2], f32x4 (&b)[2]) {
                     const int u = s >> 1, par = s & 1;
@@ -324,115 +349,157 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                         b[j] = *(const f32x4*)(lds + brow_ + s * 64 + j * 16);
                     }
                 };
-                auto prep = [&](const f32x4 (&x)[2], const f32x4 (&b)[2], half8& oh, half8& ol) {
-                    fp16x2 hh[4], ll[4];
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const f32x4 t = x[j] - b[j];
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = fmaxf(t[e], 0.f);
-                        hh[2 * j] = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-                        hh[2 * j + 1] = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                        ll[2 * j] = __builtin_amdgcn_cvt_pkrtz(sub_half_r<0>(v[0], hh[2 * j]), sub_half_r<1>(v[1], hh[2 * j]));
-                        ll[2 * j + 1] = __builtin_amdgcn_cvt_pkrtz(sub_half_r<0>(v[2], hh[2 * j + 1]), sub_half_r<1>(v[3], hh[2 * j + 1]));
-                    }
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    u32x4 ph, pl;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        ph[e] = __builtin_bit_cast(uint32_t, hh[e]);
-                        pl[e] = __builtin_bit_cast(uint32_t, ll[e]);
-                    }
-                    oh = __builtin_bit_cast(half8, ph);
-                    ol = __builtin_bit_cast(half8, pl);
+                // conversion of one step's 8 values in 8 half-chunks of 4 VALU operations (pair pr = values 2 pr, 2 pr + 1):
+                // first half v = relu(x - b), second half hi = fp16(v) toward zero, lo = fp16(v - hi)
+                auto prep_a = [&](int pr, const f32x4 (&x)[2], const f32x4 (&b)[2], float (&v)[2]) {
+                    const int j = pr >> 1, e0 = (pr & 1) * 2;
+                    v[0] = fmaxf(x[j][e0] - b[j][e0], 0.f);
+                    v[1] = fmaxf(x[j][e0 + 1] - b[j][e0 + 1], 0.f);
+                };
+                auto prep_b = [&](const float (&v)[2], uint32_t& wh, uint32_t& wl) {
+                    const fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+                    const fp16x2 ll = __builtin_amdgcn_cvt_pkrtz(sub_half_r<0>(v[0], hh), sub_half_r<1>(v[1], hh));
+                    wh = __builtin_bit_cast(uint32_t, hh);
+                    wl = __builtin_bit_cast(uint32_t, ll);
+                };
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                auto row_addr = [&](const uint2 (&f4)[4], int e) -> uint32_t {
+                    const uint32_t pair = (e & 2) ? f4[e >> 2].y : f4[e >> 2].x;
+                    return (uint32_t)(C::ACC_OFF + rr * 4) + ((e & 1) ? (pair >> 16) : (pair & 0xFFFFu));
                 };
 
                 if (!prepped) {   // step 0 of this tile (first tile of an object, or a tile that was not prefetched)
                     wait_ring();
                     f32x4 x[2], b[2];
                     read_step(0, brow, x, b);
-                    prep(x, b, a_hi, a_lo);
+                    uint32_t nh[4], nl[4];
+#pragma unroll
+                    for (int pr = 0; pr < 4; pr++) {
+                        float v[2];
+                        prep_a(pr, x, b, v);
+                        prep_b(v, nh[pr], nl[pr]);
+                    }
+                    a_hi = __builtin_bit_cast(half8, u32x4{nh[0], nh[1], nh[2], nh[3]});
+                    a_lo = __builtin_bit_cast(half8, u32x4{nl[0], nl[1], nl[2], nl[3]});
                 }
-                f32x16 acc[C::NTW];
-#pragma unroll
-                for (int nt = 0; nt < C::NTW; nt++)
-#pragma unroll
-                    for (int e = 0; e < 16; e++) acc[nt][e] = biasv[nt];
+                uint32_t brow_n = 0;
 
-                // the next tile's first step can be prepared inside this one only when it reads the same centroid table
-                const bool chain = nxt_ok && nxt.gi == gi;
-                const uint32_t dl_n = (m_nxt >> 8) & 127u;
-                const uint32_t brow_n = (uint32_t)C::BT_OFF + dl_n * (uint32_t)C::BT_STRIDE + (uint32_t)(h * 32);
-                half8 n_hi = a_hi, n_lo = a_lo;
+                // ---- steps 0 .. S16-2: [reads of step s+1] [4 MFMAs hi.hi] [8 x (half-chunk of the conversion, 1 MFMA)] --------
+                // One wave per SIMD: the instruction order IS the schedule, so it is pinned with sched_barrier fences: the LDS
+                // round trip of the reads hides behind the first four MFMAs, every later MFMA carries ~4 VALU operations.  Step 0
+                // also decodes the next tile (row offsets -> DMA addresses), odd steps refill the slot the previous step emptied.
 #pragma unroll
-                for (int s = 0; s < C::S16; s++) {
+                for (int s = 0; s < C::S16 - 1; s++) {
                     f32x4 x[2], b[2];
-                    bool have_next = true;
-                    if (s + 1 < C::S16) {
-                        if (((s + 1) & 1) == 0) wait_ring();      // first step of the next slot
-                        read_step(s + 1, brow, x, b);
-                    } else if (chain) {
-                        wait_ring();                             // slot 0 of the next tile
-                        read_step(0, brow_n, x, b);
-                    } else {
-                        have_next = false;
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++) acc[nt] = MFMA16(a_hi, w_hi[nt][s], acc[nt]);
-#pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++) acc[nt] = MFMA16(a_hi, w_lo[nt][s], acc[nt]);
-                    if (have_next) prep(x, b, n_hi, n_lo);
-                    // slot u is consumed once the second of its two steps has been read and converted: refill it
-                    // (WAR: the reads of the slot must have RETURNED before its refill is issued, not merely been issued: the
-                    // explicit wait also pins the order - hipcc otherwise puts the DMA right behind the ds_reads)
-                    if ((s & 1) == 0) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        issue_slot(vn, s >> 1);
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++) acc[nt] = MFMA16(a_lo, w_hi[nt][s], acc[nt]);
-                    a_hi = n_hi;
-                    a_lo = n_lo;
-                }
-                prepped = chain;
-                // max-aggregation: integer atomic max into the object's LDS accumulator (the max against +0 is the ReLU)
-                {
-                    uint2 four[4];   // accumulator-row byte offsets of this lane's 16 result rows 8 q + 4 h + {0..3}
-                    {
+                    if (((s + 1) & 1) == 0) wait_ring();      // first step of the next slot
+                    read_step(s + 1, brow, x, b);
+                    if (s == C::S16 - 2) {
                         const uint32_t a4 = dstl_addr + (uint32_t)(h * 8);
                         asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:16\n\tds_read_b64 %2, %4 offset:32\n\t"
-                                     "ds_read_b64 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                                     "ds_read_b64 %3, %4 offset:48"
                                      : "=&v"(four[0]), "=&v"(four[1]), "=&v"(four[2]), "=&v"(four[3]) : "v"(a4) : "memory");
                     }
-                    // (inline asm for the same reason as above; the results sit in AGPRs, which a DS instruction reads directly.
-                    // The s_nop covers the MFMA -> LDS-data hazard the compiler no longer sees.)
-                    const uint32_t col = (uint32_t)(C::ACC_OFF + rr * 4);
-                    uint32_t ad[16];
+                    SB();
+                    if (s == 0) {
 #pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const uint32_t pair = (e & 2) ? four[e >> 2].y : four[e >> 2].x;
-                        ad[e] = col + ((e & 1) ? (pair >> 16) : (pair & 0xFFFFu));
+                        for (int nt = 0; nt < C::NTW - 1; nt++) acc[nt] = MFMA16(a_hi, w_hi[nt][0], kZero16);
+                        if (pend) {   // the previous tile's last result block: its MFMAs are long done, its registers are free below
+#pragma unroll
+                            for (int e = 0; e < 16; e++)
+                                asm volatile(DS_MAX_STR ::"v"(row_addr(fourp, e)), "a"(acc[C::NTW - 1][e]), "n"((C::NTW - 1) * 128) : "memory");
+                        }
+                        acc[C::NTW - 1] = MFMA16(a_hi, w_hi[C::NTW - 1][0], kZero16);
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < C::NTW; nt++) acc[nt] = MFMA16(a_hi, w_hi[nt][s], acc[nt]);
                     }
-                    asm volatile("s_nop 15" ::: "memory");
+                    SB();
+                    uint32_t nh[4], nl[4];
+                    float v[2];
+                    uint32_t rowbyte_n = 0;
 #pragma unroll
-                    for (int nt = 0; nt < C::NTW; nt++)
+                    for (int c = 0; c < 8; c++) {
+                        if ((c & 1) == 0) prep_a(c >> 1, x, b, v);
+                        else prep_b(v, nh[c >> 1], nl[c >> 1]);
+                        if (s == 0) {          // next tile: row offset of the lane's row, the rows of every DMA lane, table row
+                            if (c == 2) rowbyte_n = row_byte(gi_n, sb_n, m_nxt);
+                            if (c == 4) tile_voff(rowbyte_n, vn);
+                            if (c == 6) brow_n = (uint32_t)C::BT_OFF + ((m_nxt >> 8) & 127u) * (uint32_t)C::BT_STRIDE + (uint32_t)(h * 32);
+                        }
+                        if ((s & 1) && (c & 1)) dma_piece(vn, s >> 1, c >> 1);   // refill of slot (s - 1) / 2, emptied in step s - 1
+                        if (c < 4) acc[c] = MFMA16(a_hi, w_lo[c][s], acc[c]);
+                        else acc[c - 4] = MFMA16(a_lo, w_hi[c - 4][s], acc[c - 4]);
+                        SB();
+                    }
+                    a_hi = __builtin_bit_cast(half8, u32x4{nh[0], nh[1], nh[2], nh[3]});
+                    a_lo = __builtin_bit_cast(half8, u32x4{nl[0], nl[1], nl[2], nl[3]});
+                }
+                // ---- last step, column block by column block: a finished block's atomics ride under the next block's MFMAs --------
+                {
+                    constexpr int s = C::S16 - 1;
+                    f32x4 x[2], b[2];
+                    if (chain) {
+                        wait_ring();                             // slot 0 of the next tile
+                        read_step(0, brow_n, x, b);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(four[0]), "+v"(four[1]), "+v"(four[2]), "+v"(four[3])::"memory");
+                    SB();
+                    uint32_t ad[16];
+                    uint32_t nh[4], nl[4];
+                    float v[2];
+#pragma unroll
+                    for (int i = 0; i < 3 * C::NTW; i++) {
+                        const int nt = i / 3, k = i % 3;
+                        if (k == 0) acc[nt] = MFMA16(a_hi, w_hi[nt][s], acc[nt]);
+                        else if (k == 1) acc[nt] = MFMA16(a_hi, w_lo[nt][s], acc[nt]);
+                        else acc[nt] = MFMA16(a_lo, w_hi[nt][s], acc[nt]);
+                        if (i < 4) {
+#pragma unroll
+                            for (int e = 4 * i; e < 4 * i + 4; e++) ad[e] = row_addr(four, e);
+                        }
+                        if (chain && i < 8) {
+                            if ((i & 1) == 0) prep_a(i >> 1, x, b, v);
+                            else prep_b(v, nh[i >> 1], nl[i >> 1]);
+                        }
+                        if (i < 8 && (i & 1)) dma_piece(vn, s >> 1, i >> 1);      // refill of the last slot
+                        // block nb = (i - 4) / 3 is complete two MFMAs before chunk i = 3 nb + 4: 8 atomics here, 8 in the next chunk
+                        if (i >= 4 && ((i - 4) % 3) < 2 && (i - 4) / 3 < C::NTW - 1) {
+                            const int nb = (i - 4) / 3, e0 = ((i - 4) % 3) * 8;
+#pragma unroll
+                            for (int e = e0; e < e0 + 8; e++)
+                                asm volatile(DS_MAX_STR ::"v"(ad[e]), "a"(acc[nb][e]), "n"(nb * 128) : "memory");
+                        }
+                        SB();
+                    }
+                    if (chain) {
+                        a_hi = __builtin_bit_cast(half8, u32x4{nh[0], nh[1], nh[2], nh[3]});
+                        a_lo = __builtin_bit_cast(half8, u32x4{nl[0], nl[1], nl[2], nl[3]});
+#pragma unroll
+                        for (int q = 0; q < 4; q++) fourp[q] = four[q];
+                        pend = true;
+                    } else {      // last tile of this wave in the object: the last block goes out now
+                        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
                         for (int e = 0; e < 16; e++)
-                            asm volatile("ds_max_i32 %0, %1 offset:%2" ::"v"(ad[e]), "a"(acc[nt][e]), "n"(nt * 128) : "memory");
+                            asm volatile(DS_MAX_STR ::"v"(ad[e]), "a"(acc[C::NTW - 1][e]), "n"((C::NTW - 1) * 128) : "memory");
+                        pend = false;
+                    }
                 }
-                cur = nxt;
+                prepped = chain;
+                have = chain;
+                r0 = r0_n;
                 cur_fetched = nxt_ok;
                 m_cur = m_nxt;
             }
+            if (!did_tile) cur_fetched = false;
             // ---- object gi is complete for this wave ------------------------------------------------------------------------
             // the DMA pieces this wave issued for later objects (row lists, positions) are older than any ring piece a
             // counted wait has since retired - unless the wave had no tile here
             if (!did_tile) wait_all_vm();
             lds_barrier_r();                                    // A: all atomics of object gi are in the accumulator
-            flush(ga + gi);
+            if constexpr (!(T2P_RABL & 4)) flush(ga + gi);
             if (gi + 1 < cnt) {
-                build_b(ga + gi + 1);
+                if constexpr (!(T2P_RABL & 4)) build_b(ga + gi + 1);
                 if (gi + 3 < cnt) dma_rows(ga + gi + 3);
                 if (gi + 2 < cnt) dma_cpos(ga + gi + 2);
             }
