@@ -161,6 +161,64 @@ def cpu_baseline(S, seed, n_cells_sample, n_query_sample):
     }
 
 
+def measured_peaks():
+    """On-box peaks from the two micro-kernels of profiles/microbench/peaks.hip (built by build.py into libt2p_peaks.so):
+    dense v_mfma_f32_32x32x16_f16 rate with every SIMD busy, float4 copy bandwidth over 2 GiB + 2 GiB."""
+    import ctypes
+    path = os.path.join(ROOT, "profiles", "microbench", "libt2p_peaks.so")
+    if not os.path.exists(path):
+        return {"error": "profiles/microbench/libt2p_peaks.so is not built (python __graft_entry__.py build)"}
+    lib = ctypes.CDLL(path)
+    tf, gb = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    rc1 = lib.t2p_peak_mfma_f16(ctypes.byref(tf))
+    rc2 = lib.t2p_peak_copy(ctypes.byref(gb))
+    return {"mfma_f16_tflops": tf.value if rc1 == 0 else None, "copy_gbps": gb.value if rc2 == 0 else None,
+            "nominal_mfma_f16_tflops": F16_MFMA_PEAK_TFLOPS, "nominal_hbm_gbps": 8000.0,
+            "source": "profiles/microbench/peaks.hip (32x32x16 f16 MFMA loop, 4 waves per SIMD; float4 copy, bytes read + written)"}
+
+
+def edge_rows(ops, torch, d_xyz, d_rgb):
+    """Edge rows of the three SA levels over all objects: ball-query hits + one self loop per centroid (what the SA kernels
+    multiply), and level 1's rows without the edges of repeated points (what it multiplies after t2p_dedup_rows; counted
+    here with an exact comparison, the kernel's hash table may keep a few more)."""
+    e = [0, 0, 0]
+    e1_dedup = 0
+    n_obj = d_xyz.shape[0]
+    for lo in range(0, n_obj, 8192):
+        x, c = d_xyz[lo: lo + 8192], d_rgb[lo: lo + 8192]
+        gt = ops.sample_group(x)
+        for l in range(3):
+            e[l] += int(gt["cnt"][l].sum().item()) + gt["cnt"][l].numel()
+        # repeats: same six float bit patterns as an earlier point of the object
+        bits = torch.cat([x, c], dim=2).contiguous().view(torch.int32).to(torch.int64)
+        key = torch.zeros(bits.shape[:2], dtype=torch.int64, device=x.device)
+        for k in range(6):
+            key = key * 1000003 + bits[:, :, k]
+        ks, idx = torch.sort(key, dim=1, stable=True)
+        rep_s = torch.zeros_like(ks, dtype=torch.bool)
+        rep_s[:, 1:] = ks[:, 1:] == ks[:, :-1]
+        rep = torch.zeros_like(rep_s)
+        rep.scatter_(1, idx, rep_s)
+        nbr, cnt = gt["nbr"][0].long(), gt["cnt"][0].long()
+        valid = torch.arange(32, device=x.device)[None, None, :] < cnt[:, :, None]
+        is_rep = torch.gather(rep[:, None, :].expand(-1, nbr.shape[1], -1), 2, nbr)
+        e1_dedup += int((valid & ~is_rep).sum().item()) + cnt.numel()
+    return e, e1_dedup
+
+
+def executed_flops(e, e1_dedup, n_obj, n_cells, knn_edges):
+    """FLOPs (2 per multiply-add) the f16x3 plan executes per step, algorithmic widths (no zero padding): layer 2 of every SA
+    edge row, the layer-1 point tables per dense point (4.1 of DESIGN.md), GA, the PointNet++ heads, the object head and the
+    cell graph.  SURVEY 8(d)'s F_object also counts layer 1 per EDGE, which this design removes algebraically."""
+    sa2 = 2.0 * (32 * 64 * e1_dedup + 128 * 128 * e[1] + 256 * 256 * e[2])
+    tables = 2.0 * n_obj * (256 * 6 * 32 + 128 * 67 * 128 + 64 * 131 * 256)
+    ga = 2.0 * n_obj * 32 * (259 * 512 + 512 * 1024)
+    heads = n_obj * (1048576.0 + 262144.0 + 590592.0)
+    graph = 2.0 * n_obj * 2 * 256 * 256 + 2.0 * knn_edges * 256 * 256 + n_cells * 262144.0
+    return {"sa_layer2": sa2, "sa_layer1_tables": tables, "ga": ga, "heads": heads, "cell_graph": graph,
+            "total": sa2 + tables + ga + heads + graph}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +242,10 @@ def main():
     ap.add_argument("--no-two-stream", action="store_true", help="skip the extra two-stream measurement")
     ap.add_argument("--tuning", type=int, default=0, help="t2p_cell_config.tuning (A/B between equivalent execution plans)")
     ap.add_argument("--no-fp32-pass", action="store_true", help="skip the extra exact-fp32 pass behind the timed region")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the report-only measurements behind the timed region (on-box peaks, the fixed-16 / single-object "
+                         "cell variants, the fine stage)")
+    ap.add_argument("--fine-queries", type=int, default=200, help="queries of the fine-stage measurement (x top-10 candidates)")
     ap.add_argument("--fp32-steps", type=int, default=2)
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="arithmetic of the MFMA-heavy layers: f16x3 split-precision (default) or exact fp32 MFMA")
@@ -410,7 +472,8 @@ def main():
             dist.all_reduce(t)
             n_flip = int(t.item())
         fp32_info = {"fp32_ms_per_step": fp32_elapsed / args.fp32_steps * 1e3, "fp32_steps": args.fp32_steps,
-                     "f16x3_vs_fp32_max_abs": delta,
+                     "f16x3_vs_fp32_max_abs_all_cells": delta_all,
+                     "f16x3_vs_fp32_max_abs_cells_with_identical_knn_graph": delta,
                      "f16x3_vs_fp32": {"max_abs_object_embeddings_all_objects": d_obj,
                                        "max_abs_cell_embeddings_cells_with_identical_knn_graph": delta,
                                        "cells_with_a_knn_tie_flip": n_flip, "cells": n_cells_total,
@@ -470,10 +533,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         # algorithmic work of the dominant kernel: 2*256*256 FLOP per SA3 edge row (ball-query edges + self loops)
         with torch.no_grad():
-            e3 = 0
-            for lo in range(0, n_obj, 16384):
-                gt = ops.sample_group(d_xyz[lo: lo + 16384])
-                e3 += int(gt["cnt"][2].sum().item()) + gt["cnt"][2].numel()
+            e_lvl, e1_dedup = edge_rows(ops, torch, d_xyz, d_rgb)
+        e3 = e_lvl[2]
         launches, total_ms = prof.get(DOMINANT, (0, 0.0))
         flops_per_step = 2.0 * 256 * 256 * e3
         achieved = (flops_per_step * args.steps) / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
@@ -501,6 +562,22 @@ def main():
                                       "WRITE_SIZE passes of this command; not measured in this run)")
         except Exception:
             traffic = None
+        # the other SA levels and the whole step, same convention (algorithmic FLOPs executed / hipEvent time)
+        sizes_np = np.diff(cell_ptr).astype(np.int64)
+        knn_edges = int((sizes_np * np.minimum(sizes_np, 8)).sum())
+        ex = executed_flops(e_lvl, e1_dedup if not (args.tuning & 1) else e_lvl[0], n_obj, c_hi - c_lo, knn_edges)
+        sa_levels = {}
+        for name, rows_l, hc in (("ws_edge_sa_k32_n64", e1_dedup if not (args.tuning & 1) else e_lvl[0], 32 * 64),
+                                 ("ws_edge_sa_k128_n128", e_lvl[1], 128 * 128), ("ws_edge_sa_k256_n256", e_lvl[2], 256 * 256)):
+            ln, ms = prof.get(name, (0, 0.0))
+            tf = 2.0 * hc * rows_l * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else None
+            sa_levels[name] = {"edge_rows_per_step": rows_l, "ms_per_step": ms / args.steps, "achieved_tflops": tf,
+                               "frac_of_peak": tf / peak if tf else None,
+                               "frac_of_f16x3_ceiling": (3.0 * tf / peak if tf else None) if args.precision == "f16x3" else None}
+        whole_step = {"executed_flop_per_step": ex, "achieved_tflops": ex["total"] / (ms_per_step * 1e-3) / 1e12,
+                      "frac_of_peak": ex["total"] / (ms_per_step * 1e-3) / 1e12 / peak,
+                      "note": "algorithmic FLOPs this plan executes (layer 1 of the SA MLPs per point, not per edge; SA1 rows after "
+                              "t2p_dedup_rows) over the whole timed step, text branch and ranking excluded"}
         out = {
             "metric": "cells+queries encoded/sec and top-k retrieval QPS, 256-pt cells, 12k-cell DB",
             "value": (n_cells_total + n_q_total) / (elapsed / args.steps),
@@ -513,13 +590,16 @@ def main():
                                     f"+ {args.queries} queries/GPU (6 hints), embed_dim=256, top-{TOPK} over {n_cells_total} cells"),
                        "cells_total": n_cells_total, "queries_total": n_q_total, "objects_rank0": n_obj,
                        "weights": "random init (torch.manual_seed(1234)), BatchNorm statistics " +
-                                  ("calibrated by one train-mode pass over 64 cells" if args.bn == "calibrated" else "random"),
+                                  ("calibrated by one train-mode pass over 64 cells (deviation from SURVEY 8(d), which randomises "
+                                   "them: random statistics collapse every embedding onto one direction; --bn random restores it)"
+                                   if args.bn == "calibrated" else "random (SURVEY 8(d))"),
                        "parallelism": f"cells+queries sharded x{world}, 1 all-gather" if world > 1 else "single GPU"},
             "kernel_ms_per_step": phases, "phase_rates": phase_rates,
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_source, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
                          "algorithmic_flop_per_step": flops_per_step, "sa3_edge_rows_per_step": e3,
+                         "sa_levels": sa_levels, "whole_step": whole_step,
                          "note": ("algorithmic FLOPs = 2*256*256 per SA3 edge row; the f16x3 path executes 3 f16 MFMA FLOPs per "
                                   "algorithmic FLOP, so its ceiling on this metric is peak/3 = 833 TFLOP/s"
                                   if args.precision == "f16x3" else "exact fp32 MFMA path")},
@@ -532,6 +612,31 @@ def main():
             out.update(fp32_info)
         if exchange:
             out["exchange"] = exchange
+        if not args.no_extras and world == 1 and args.cell_variant == "ragged":
+            # report-only measurements, all outside the timed region: on-box peaks, SURVEY 8(d)'s two other cell shapes
+            # (the cost is per object, so objects/s is the comparable figure), the fine stage (BASELINE configs[3])
+            log("extras: on-box peaks")
+            del h_pinned
+            torch.cuda.empty_cache()
+            out["measured_peaks"] = measured_peaks()
+            variants = {}
+            for vname, vfixed, vcells in (("fixed16", 16, 4000), ("single", 1, 12000)):
+                log(f"extras: cell variant {vname}")
+                vx = generate_cells(S, SEED, vcells, 0, vcells, workers, vfixed)
+                vd = [torch.from_numpy(a).to(dev) for a in vx[:4]]
+                with torch.no_grad():
+                    tv, _ = timed(lambda: model.encode_objects_packed(*vd, vx[4], chunk_objects=args.chunk_objects), 2)
+                variants[vname] = {"cells": vcells, "objects": int(vx[4][-1]), "ms": tv * 1e3, "cells_per_s": vcells / tv,
+                                   "objects_per_s": int(vx[4][-1]) / tv}
+                del vd, vx
+            variants["ragged"] = {"cells": c_hi - c_lo, "objects": n_obj, "cells_per_s": phase_rates["cells_per_s"],
+                                  "objects_per_s": phase_rates["objects_per_s"]}
+            out["cell_variants"] = variants
+            log("extras: fine stage")
+            import bench_fine
+            fine = bench_fine.run(queries=args.fine_queries, topk=10, steps=3, warmup=1, precision=args.precision)
+            out["fine_stage"] = {k: fine[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "queries_per_s",
+                                                      "matcher_kernels_ms_per_step")}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
             big_host = (os.cpu_count() or 1) >= 32
             n_cells_cpu = args.cpu_cells or (256 if big_host else 16)

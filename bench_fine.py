@@ -21,14 +21,10 @@ sys.path.insert(0, ROOT)
 import bench as B  # noqa: E402  (shares the input generator)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--queries", type=int, default=1000)
-    ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3")
-    args = ap.parse_args()
+def run(queries=1000, topk=10, steps=3, warmup=1, precision="f16x3"):
+    """One fine-stage measurement; returns the JSON-ready dict (bench.py --fine / its default report call this too)."""
+    from types import SimpleNamespace
+    args = SimpleNamespace(queries=queries, topk=topk, steps=steps, warmup=warmup, precision=precision)
     import torch
     import text2pos_amd as t2p
     from text2pos_amd import ops, synthetic as S
@@ -75,7 +71,7 @@ def main():
     matcher_ms = sum(v for k, v in phases.items() if k.startswith("match_"))
     assert bool((out.P >= 0).all()) and bool((out.matches0 >= -1).all()) and bool((out.matches0 < 6).all())
     assert model.overflow_detected() == 0, "fp16-range guard fired: the f16x3 numbers are invalid"
-    print(json.dumps({
+    return ({
         "metric": "fine stage: (query, candidate cell) pairs matched per second (16 objects x 6 hints, embed_dim 128)",
         "value": n_pairs / (elapsed / args.steps), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -85,7 +81,18 @@ def main():
         "queries_per_s": args.queries / (elapsed / args.steps),
         "matched_fraction": float((out.matches1 >= 0).float().mean()),
         "kernel_ms_per_step": phases, "matcher_kernels_ms_per_step": round(matcher_ms, 3),
-    }), flush=True)
+    })
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3")
+    a = ap.parse_args()
+    print(json.dumps(run(a.queries, a.topk, a.steps, a.warmup, a.precision)), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,98 @@
+// On-box peaks that bench.py prints next to the nominal ones ("re-measure on the box and state the values used").
+//   t2p_peak_mfma_f16:  dense v_mfma_f32_32x32x16_f16 rate, every SIMD of the chip busy (4 waves per CU-SIMD, 8 independent
+//                       accumulators per wave), TFLOP/s
+//   t2p_peak_copy:      float4 copy of a buffer far larger than the 256 MB Infinity Cache, GB/s (read + written bytes)
+// Built by text2pos-cvpr2022_amd/build.py into profiles/microbench/libt2p_peaks.so; measurement code, not part of the product.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_mfma_peak(float* out, int iters) {
+    half8 a, b;
+    for (int e = 0; e < 8; e++) {
+        a[e] = (_Float16)(0.001f * (threadIdx.x + e));
+        b[e] = (_Float16)(0.002f * (threadIdx.x % 7 + e));
+    }
+    f32x16 acc[8];
+    for (int i = 0; i < 8; i++)
+        for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; i++)
+        for (int e = 0; e < 16; e++) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+static double time_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+extern "C" int t2p_peak_mfma_f16(double* tflops) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int blocks = cus * 4, iters = 20000;   // 4 blocks x 4 waves per CU = 4 waves per SIMD
+    float* out = nullptr;
+    if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess) return 2;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, out, 1000);   // warm-up
+    double best = 1e30;
+    for (int r = 0; r < 3; r++) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, out, iters);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        const double ms = time_ms(e0, e1);
+        best = ms < best ? ms : best;
+    }
+    const double flop = (double)blocks * 4 /*waves*/ * iters * 8 * (2.0 * 32 * 32 * 16);
+    *tflops = flop / (best * 1e-3) / 1e12;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(out);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+extern "C" int t2p_peak_copy(double* gbps) {
+    const size_t bytes = (size_t)2 << 30;   // 2 GiB source + 2 GiB destination
+    f32x4 *src = nullptr, *dst = nullptr;
+    if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&dst, bytes) != hipSuccess) {
+        if (src) hipFree(src);
+        return 2;
+    }
+    hipMemset(src, 1, bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const size_t n = bytes / 16;
+    hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, src, dst, n);
+    double best = 1e30;
+    for (int r = 0; r < 3; r++) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, src, dst, n);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        const double ms = time_ms(e0, e1);
+        best = ms < best ? ms : best;
+    }
+    *gbps = 2.0 * bytes / (best * 1e-3) / 1e9;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(src);
+    hipFree(dst);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}

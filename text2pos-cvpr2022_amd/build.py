@@ -72,9 +72,23 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> str
     return LIB
 
 
+def build_peaks() -> str:
+    """profiles/microbench/libt2p_peaks.so: the two micro-kernels bench.py uses to state on-box peaks (dense f16 MFMA rate,
+    float4 copy bandwidth).  Measurement code, kept out of the product library."""
+    src = os.path.join(HERE, "..", "profiles", "microbench", "peaks.hip")
+    lib = os.path.join(HERE, "..", "profiles", "microbench", "libt2p_peaks.so")
+    if _stale(lib, [src]):
+        r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", lib, src],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on peaks.hip:\n" + r.stderr)
+    return os.path.abspath(lib)
+
+
 if __name__ == "__main__":
     if "--variant" in sys.argv:  # python build.py --variant NAME DEF1 DEF2 ...
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
     else:
         print(build_hip(force="--force" in sys.argv, verbose=True))
+        print(build_peaks())
