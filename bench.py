@@ -618,7 +618,16 @@ def main():
             log("extras: on-box peaks")
             del h_pinned
             torch.cuda.empty_cache()
-            out["measured_peaks"] = measured_peaks()
+            out["measured_peaks"] = mp = measured_peaks()
+            if mp.get("mfma_f16_tflops") and achieved and args.precision == "f16x3":
+                # the same fractions against what THIS box sustains on a bare MFMA loop (clocks sag under matrix load)
+                m = mp["mfma_f16_tflops"]
+                out["roofline"]["frac_of_measured_peak"] = achieved / m
+                out["roofline"]["mfma_flops_frac_of_measured_peak"] = 3.0 * achieved / m
+                for v in sa_levels.values():
+                    if v["achieved_tflops"]:
+                        v["mfma_flops_frac_of_measured_peak"] = 3.0 * v["achieved_tflops"] / m
+                whole_step["frac_of_measured_peak"] = whole_step["achieved_tflops"] / m
             variants = {}
             for vname, vfixed, vcells in (("fixed16", 16, 4000), ("single", 1, 12000)):
                 log(f"extras: cell variant {vname}")
