@@ -176,13 +176,15 @@ typedef struct t2p_cell_config {
      * fire for a checkpoint that would just have fitted, never the other way round.  The caller clears it, reads it after the stream has drained, and must
      * not trust the call's output when it is set (the Python host raises or re-runs with precision = 0).  NULL: no check. */
     int32_t* overflow_flag;
-    /* A/B switches between equivalent execution plans (0 = the default plan).  Bits 0 and 1 leave every output bit
-     * unchanged; bit 2 swaps SA level 2's kernel for one that adds the same products in another k grouping (fp32 rounding):
+    /* A/B switches between equivalent execution plans (0 = the default plan).  Bit 0 leaves every output bit unchanged; the
+     * others swap a kernel for one that adds the same f16x3 products in another k grouping (results agree to fp32 rounding):
      *   bit 0: keep the edge rows of repeated points in SA level 1's row lists (default: t2p_dedup_rows drops them)
-     *   bit 1: f16x3 only: gather the centroid tables of SA levels 2 and 3 from HBM (default: built in LDS per object);
-     *          SA level 2 then runs on the column-slice kernel of ws_sa2.hip
+     *   bit 1: f16x3 only: gather the centroid tables of all SA levels from HBM (default: built in LDS); SA levels 1 and 2
+     *          then run on the column-slice kernel of ws_sa2.hip
      *   bit 2: f16x3 only: SA level 2 on the column-slice kernel of ws_sa2.hip (default: the row-owning kernel of
-     *          sa_rows.hip: a wave holds the whole 128 x 128 weight matrix and multiplies its own 32-row tiles) */
+     *          sa_rows.hip: a wave holds the whole 128 x 128 weight matrix and multiplies its own 32-row tiles)
+     *   bit 3: f16x3 only: SA level 1 on the column-slice kernel of ws_sa2.hip (default: sa_groups.hip: independent waves,
+     *          each owning a group of 16 centroids of an object with a private LDS accumulator) */
     int32_t tuning;
 } t2p_cell_config;
 

@@ -643,37 +643,47 @@ def test_dedup_rows_drops_only_repeats():
 
 
 def test_execution_plans_are_bit_identical(hip_model):
-    """t2p_cell_config.tuning switches between equivalent plans.  Bits 0 / 1 (repeated points' rows kept / dropped; centroid
-    tables of SA levels 2-3 gathered from HBM / built in LDS) must not change a single bit of any output.  Bit 2 moves SA
-    level 2 from the row-owning kernel (sa_rows.hip, the default with LDS tables) to the column-slice kernel (ws_sa2.hip, also
-    what bit 1 selects): the same f16x3 products summed in another k grouping, so the two families agree to fp32 rounding
-    (SA1's output, in front of the switch, bit for bit) and each family is bit-identical within itself."""
+    """t2p_cell_config.tuning switches between equivalent plans.  Bit 0 (repeated points' rows kept / dropped) and the
+    HBM / LDS form of the centroid tables must not change a single bit of any output.  Bits 1-3 also choose the kernel of SA
+    levels 1 and 2: the centroid-group kernel (sa_groups.hip) / the row-owning kernel (sa_rows.hip) by default, the column-slice
+    kernel (ws_sa2.hip) otherwise - the same f16x3 products summed in another k grouping.  Plans that run the same kernels form
+    a family that is bit-identical within itself; the families agree to fp32 rounding."""
     from text2pos_amd import synthetic as S
     xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(77, 40)
     args = _to_dev(xyz, rgb, center, mean_rgb)
     outs = {}
     try:
-        for tuning in range(8):
+        for tuning in range(16):
             hip_model.tuning = tuning
             with torch.no_grad():
                 outs[tuning] = hip_model.encode_objects_packed(*args, cell_ptr, want_trace=("sa_out", "obj_emb"))
     finally:
         hip_model.tuning = 0
-    families = ((0, 1), (2, 3, 4, 5, 6, 7))     # SA2 on sa_rows.hip / on ws_sa2.hip
-    for fam in families:
-        ref_out, ref_tr = outs[fam[0]]
-        for t in fam[1:]:
-            out, tr = outs[t]
-            assert torch.equal(out, ref_out) and torch.equal(tr["obj_emb"], ref_tr["obj_emb"]), f"tuning {t}"
-            for l in range(3):
-                assert torch.equal(tr["sa_out"][l], ref_tr["sa_out"][l]), f"tuning {t}: SA{l + 1} output"
-    (a_out, a_tr), (b_out, b_tr) = outs[0], outs[2]
-    assert torch.equal(a_tr["sa_out"][0], b_tr["sa_out"][0]), "SA1 runs the same kernel in both families"
-    c2 = 128                                      # feature columns of SA2's output rows ([features | xyz 0 | pad])
-    d2 = (a_tr["sa_out"][1][:, :c2] - b_tr["sa_out"][1][:, :c2]).abs().max().item()
-    scale2 = b_tr["sa_out"][1][:, :c2].abs().max().item()
-    assert 0.0 < d2 < 2e-5 * max(1.0, scale2), f"SA2 outputs of the two kernels: max|delta| = {d2:.3e} (scale {scale2:.2e})"
-    assert (a_tr["obj_emb"] - b_tr["obj_emb"]).abs().max().item() < 2e-5 and (a_out - b_out).abs().max().item() < 2e-5
+    # (SA1 on the old kernel, SA2 on the old kernel): bit 1 moves both, bit 3 SA1, bit 2 SA2
+    family = lambda t: (bool(t & 0b1010), bool(t & 0b0110))
+    ref = {}
+    for t in range(16):
+        out, tr = outs[t]
+        if family(t) not in ref:
+            ref[family(t)] = t
+            continue
+        ref_out, ref_tr = outs[ref[family(t)]]
+        assert torch.equal(out, ref_out) and torch.equal(tr["obj_emb"], ref_tr["obj_emb"]), f"tuning {t}"
+        for l in range(3):
+            assert torch.equal(tr["sa_out"][l], ref_tr["sa_out"][l]), f"tuning {t}: SA{l + 1} output"
+    assert len(ref) == 4
+    b_out, b_tr = outs[ref[(True, True)]]                  # all levels on ws_sa2.hip (round 2's plan)
+    for fam, t in ref.items():
+        a_out, a_tr = outs[t]
+        if not fam[0]:
+            assert not torch.equal(a_tr["sa_out"][0][:, :64], b_tr["sa_out"][0][:, :64]), "another kernel, another rounding"
+        else:
+            assert torch.equal(a_tr["sa_out"][0], b_tr["sa_out"][0]), "SA1 runs the same kernel"
+        for l, c in ((0, 64), (1, 128), (2, 256)):     # feature columns of the output rows ([features | xyz 0 | pad])
+            d = (a_tr["sa_out"][l][:, :c] - b_tr["sa_out"][l][:, :c]).abs().max().item()
+            scale = b_tr["sa_out"][l][:, :c].abs().max().item()
+            assert d < 2e-5 * max(1.0, scale), f"family {fam}: SA{l + 1} outputs differ by {d:.3e} (scale {scale:.2e})"
+        assert (a_tr["obj_emb"] - b_tr["obj_emb"]).abs().max().item() < 2e-5 and (a_out - b_out).abs().max().item() < 2e-5
     # the two halves of the batch on two HIP streams (own workspaces) give the same rows
     with torch.no_grad():
         two = hip_model.encode_objects_packed(*args, cell_ptr, streams=2)

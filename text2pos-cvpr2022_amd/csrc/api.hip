@@ -245,6 +245,9 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     // f16x3: the SA kernels of levels 1 and 2 build their centroid tables in LDS (ws_sa2.hip, BL); the HBM tables B_2 / B_3
     // are then neither written nor read.  The fp32 kernels (ws_sa.hip) gather all three from HBM.
     const bool lds_btab = cfg.precision == 1 && !(cfg.tuning & 2);
+    // ... and level 0 runs on the centroid-group kernel (sa_groups.hip), which builds its tables per group as well
+    const bool lds_btab0 = lds_btab && !(cfg.tuning & 8);
+    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0);
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st, guard));
     // models/object_encoder.py:86: the PointNet++ only runs when the "class" feature does not come from class_embedding
     const bool run_pointnet = cfg.use_class && !cfg.class_embed;
@@ -259,7 +262,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         // [xyz | 0] tail of the F_l rows) for every level, and the K = 6 point table A_1 of level 0
         for (int l = 0; l < 3; l++) {
             const int cf = l == 0 ? 3 : Geo::C[l - 1];
-            gt.B[l] = (lds_btab && l > 0) ? nullptr : ws.B[l];
+            gt.B[l] = (l > 0 ? lds_btab : lds_btab0) ? nullptr : ws.B[l];
             gt.wp[l] = W.sa_w1[l] + (size_t)cf * Geo::H[l];
             gt.H[l] = Geo::H[l];
             gt.tail[l] = ws.F[l];
@@ -285,8 +288,8 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
             bp[l].prefix_ws = ws.prefix[l];
             bp[l].bounds_ws = ws.bounds[l];
             bp[l].W_x3 = cfg.precision == 1 ? W.sa_w2_x3[l] : nullptr;
-            bp[l].wp = (lds_btab && l > 0) ? W.sa_w1[l] : nullptr;   // (non-null = LDS centroid table: selects the launch shape)
-            bp[l].plan = (cfg.tuning & 4) ? 1 : 0;
+            bp[l].wp = (l > 0 ? lds_btab : lds_btab0) ? W.sa_w1[l] : nullptr;   // (non-null = LDS centroid table: selects the launch shape)
+            bp[l].plan = sa_plan;
         }
         T2P_TRY(launch_sa_balance_levels(bp, Geo::H, Geo::C, st));
     }
@@ -319,7 +322,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         SaParams p{};
         p.A = ws.A[l];
         p.Bc = ws.B[l];
-        p.wp = (lds_btab && l > 0) ? W.sa_w1[l] + (size_t)cf * Geo::H[l] : nullptr;
+        p.wp = (l > 0 ? lds_btab : lds_btab0) ? W.sa_w1[l] + (size_t)cf * Geo::H[l] : nullptr;
         p.W = W.sa_w2[l];
         p.W_x3 = cfg.precision == 1 ? W.sa_w2_x3[l] : nullptr;
         p.bias = cfg.precision == 1 ? W.sa_b2_x3[l] : W.sa_b2[l];
@@ -340,7 +343,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.bounds_ws = ws.bounds[l];
         p.balanced = 1;
         p.amax_out = gslot(G_F1 + l);
-        p.plan = (cfg.tuning & 4) ? 1 : 0;
+        p.plan = sa_plan;
         T2P_TRY(launch_ws_sa(H, C, p, st));
     }
     // ---- global abstraction: [x | pos] -> 512 -> 1024, max over the object's 32 points ------------------------
