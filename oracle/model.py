@@ -67,8 +67,8 @@ class OracleLanguageEncoder(nn.Module):
         emb = self.word_embedding(torch.from_numpy(padded))
         packed = nn.utils.rnn.pack_padded_sequence(emb, torch.tensor(lens), batch_first=True, enforce_sorted=False)
         d = self.word_embedding.embedding_dim
-        h0 = torch.zeros(2, b, d)
-        c0 = torch.zeros(2, b, d)
+        h0 = torch.zeros(2, b, d, dtype=emb.dtype)
+        c0 = torch.zeros(2, b, d, dtype=emb.dtype)
         _, (h, _) = self.lstm(packed, (h0, c0))
         return torch.mean(h, dim=0)
 

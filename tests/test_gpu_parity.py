@@ -698,18 +698,17 @@ def test_segment_max_and_linear_match_torch():
 
 
 @pytest.mark.parametrize("use_features,pointnet_features,self_loops,grad_bar",
-                         [(["class", "color", "position"], 2, True, 5e-3), (["class", "position"], 1, False, 0.2)])
+                         [(["class", "color", "position"], 2, True, 5e-3)])
 def test_cell_branch_training_step_matches_autograd(vocab, use_features, pointnet_features, self_loops, grad_bar):
     """model.train(); positive = model.encode_objects(...); loss.backward() (training/coarse.py:32-58) on the HIP
     training-mode path against torch.autograd through the oracle in train() mode: batch-statistics BatchNorm per cell inside
     the PointNet++ and per batch elsewhere, gradients of every parameter that takes part, BatchNorm running estimates.
     Bars: 1e-4 on the unit-norm output; each gradient within 5e-3 of its largest entry (measured over three seeds: <= 3e-3
     in the SA3 layers, <= 1e-3 elsewhere; fp32 through ~20 batch-normalised layers, and the winners of near-tied maxima may
-    differ between the two implementations).  The second configuration (no colour feature, features1, plain ball-query
-    neighbourhoods) only guards against gross errors (bar 0.2): with the synthetic weights some objects get near-zero
-    feature rows in front of an F.normalize, which makes the gradients of this 3-cell batch ill-conditioned - the fp32
-    oracle itself deviates from its own float64 evaluation by up to 0.25 there (profiles/oracle_grad_conditioning.py) - while the
-    forward output still has to meet 1e-4."""
+    differ between the two implementations).  The configuration without the colour feature (features1, plain ball-query
+    neighbourhoods), whose 3-cell gradients are ill-conditioned in fp32 - the fp32 oracle deviates from its own float64
+    evaluation by up to 0.25 there (profiles/oracle_grad_conditioning.py) -, is judged against the FLOAT64 oracle at the
+    reference's batch size in test_training_step_at_the_reference_batch_size."""
     import weights as W
     import text2pos_amd as t2p
     from oracle import model as OM
@@ -758,6 +757,92 @@ def test_cell_branch_training_step_matches_autograd(vocab, use_features, pointne
             assert (b.cpu() - rb[name]).abs().max().item() < 1e-4 * max(1.0, rb[name].abs().max().item()), name
         elif name.endswith("num_batches_tracked"):
             assert int(b) == int(rb[name]), name
+
+
+@pytest.fixture
+def _oracle_threads_then_restore():
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))   # the oracle's eager graph: 8-16 intra-op threads are fastest
+    yield
+    torch.set_num_threads(n)
+
+
+@pytest.mark.parametrize("kw,self_loops", [({}, True), (dict(use_features=["class", "position"], pointnet_features=1), False)])
+def test_training_step_at_the_reference_batch_size(vocab, kw, self_loops, _oracle_threads_then_restore):
+    """BASELINE configs[0]: one training step of training/coarse.py:31-62 at the reference's batch size - 64 cells (6-26
+    objects each) + 64 descriptions, model.train(), anchor = encode_text, positive = encode_objects, PairwiseRankingLoss(0.35),
+    backward - on the HIP path, against torch.autograd through the oracle evaluated in FLOAT64 (same weights, same fp32
+    geometry: FPS / ball query / kNN take fp32 inputs either way).  Across ~1,000 objects some max-aggregation winners are
+    near-ties, so an fp32 evaluation - the oracle's own included - deviates from the float64 gradients by up to a few 1e-2
+    of a parameter's largest entry in a handful of layers.  The bar is therefore two-sided: every HIP gradient is within 5e-3
+    of the float64 one (relative to the parameter's largest gradient entry, floor 1 % of the step's gradient scale) OR no
+    further from it than 1.5 x the fp32 oracle's own deviation; at least 85 % of the parameters meet the 5e-3 bar outright
+    (measured: 55 of 58, against 36 of 58 for the fp32 oracle; without the colour feature 43 of 50 against 3 of 50)."""
+    import weights as W
+    import text2pos_amd as t2p
+    from oracle import model as OM
+    from text2pos_amd import synthetic as S
+    n_cells, margin = 64, 0.35
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(61, n_cells)
+    texts = S.make_texts(61, 0, n_cells)
+
+    def oracle(dtype):
+        om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(**kw), self_loops)
+        W.fill_state_dict(om, 23)
+        om.train()
+        om = om.to(dtype)
+        for p in om.parameters():
+            p.requires_grad_(True)
+        return om
+
+    def reference_loss(im, s):        # training/losses.py:138-164
+        im = im / torch.norm(im, dim=1, keepdim=True)
+        s = s / torch.norm(s, dim=1, keepdim=True)
+        scores = torch.mm(im, s.transpose(1, 0))
+        diagonal = scores.diag()
+        cost_s = torch.clamp((margin - diagonal).expand_as(scores) + scores, min=0)
+        cost_im = torch.clamp((margin - diagonal).expand_as(scores).transpose(1, 0) + scores, min=0)
+        eye = torch.eye(len(im), dtype=torch.bool)
+        return (cost_s.masked_fill(eye, 0).sum() + cost_im.masked_fill(eye, 0).sum()) / len(im)
+
+    enc_text = lambda om: torch.nn.functional.normalize(om.language_encoder(texts))   # (encode_text itself is no_grad)
+    om32 = oracle(torch.float32)
+    l32 = reference_loss(enc_text(om32), om32.encode_objects_packed_grad(xyz, rgb, center, mean_rgb, cell_ptr))
+    l32.backward()
+    om64 = oracle(torch.float64)
+    orig_float = torch.Tensor.float
+    torch.Tensor.float = lambda self, *a, **k: self.double()     # (the oracle casts some of its inputs with .float())
+    try:
+        l64 = reference_loss(enc_text(om64), om64.encode_objects_packed_grad(xyz, rgb, center, mean_rgb, cell_ptr))
+        l64.backward()
+    finally:
+        torch.Tensor.float = orig_float
+    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(**kw), self_loops)
+    hm.load_state_dict(om32.state_dict(), strict=True)
+    hm = hm.to(_dev())
+    hm.train()
+    lh = t2p.PairwiseRankingLoss(margin)(hm.encode_text(texts), hm.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr))
+    lh.backward()
+    assert abs(lh.item() - l64.item()) < 2e-6 * abs(l64.item()), (lh.item(), l64.item(), l32.item())
+    r32, r64 = dict(om32.named_parameters()), dict(om64.named_parameters())
+    g_all = max(float(q.grad.abs().max()) for q in r64.values() if q.grad is not None)
+    bn = dict(om32.named_buffers())
+    rows = []
+    for name, p in hm.named_parameters():
+        g = r64[name].grad
+        if g is None:                                     # unused classifier heads
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        if name.endswith(".0.bias") and name[:-len(".0.bias")] + ".1.running_mean" in bn:
+            continue                                      # bias in front of a BatchNorm: zero gradient, rounding noise on both sides
+        scale = max(1e-2 * g_all, g.abs().max().item())
+        e32 = (r32[name].grad.double() - g).abs().max().item() / scale
+        eh = (p.grad.cpu().double() - g).abs().max().item() / scale
+        assert eh < max(5e-3, 1.5 * e32), (name, eh, e32)
+        rows.append((eh, e32, name))
+    assert len(rows) >= 45 and sum(r[0] < 5e-3 for r in rows) >= 0.85 * len(rows), sorted(rows, reverse=True)[:6]
+    assert any(n.startswith("language_encoder.") for _, _, n in rows) and any(n.startswith("graph1.") for _, _, n in rows)
 
 
 def test_cell_branch_training_with_embedding_ablations(vocab):
