@@ -39,6 +39,9 @@ class CellRetrievalNetwork(nn.Module):
         (FloatingPointError) or "fp32" (warn and recompute the call on the exact fp32 MFMA path)."""
         super().__init__()
         self.embed_dim = args.embed_dim
+        # width the kernels run: 128 / 256 as is, anything else up to 384 zero-padded to 384 (training/args.py:19 defaults to
+        # 300); the padded channels are exactly 0 and are cut off again before a result leaves this class
+        self.kernel_dim = packing.kernel_embed_dim(int(args.embed_dim))
         self.use_features = args.use_features
         self.variation = args.variation
         self.args = args
@@ -59,6 +62,7 @@ class CellRetrievalNetwork(nn.Module):
         self.object_encoder = ObjectEncoder(d, known_classes, known_colors, args)
         self.language_encoder = LanguageEncoder(known_words, d, bi_dir=True)
         self.language_encoder.precision = precision
+        self.language_encoder.kernel_dim = self.kernel_dim
         self._pack = None
 
     # ---- text branch -----------------------------------------------------------------------------------------
@@ -115,12 +119,23 @@ class CellRetrievalNetwork(nn.Module):
                                "(encode_objects derives them from the Object3d labels; pass class_idx / color_idx to "
                                "encode_objects_packed)")
         radii = self.object_encoder.pointnet.radii
-        return ops.make_cell_config(n_pts=n_pts, embed_dim=self.embed_dim, pointnet_features=a.pointnet_features,
+        return ops.make_cell_config(n_pts=n_pts, embed_dim=self.kernel_dim, pointnet_features=a.pointnet_features,
                                     use_features=tuple(a.use_features), self_loops=self.add_self_loops,
                                     knn_k=self.graph1.k, variation=self.variation, radius=radii,
                                     chunk_objects=chunk_objects, precision=precision or self.precision,
                                     class_idx=class_idx, color_idx=color_idx, tuning=self.tuning,
                                     overflow_flag=self._overflow_word() if (precision or self.precision) == "f16x3" else None)
+
+    def _trim(self, out):
+        """Cuts the zero padding of kernel_dim off an [n, kernel_dim] result (or an (embeddings, trace) pair)."""
+        if self.kernel_dim == self.embed_dim:
+            return out
+        if isinstance(out, tuple):
+            emb, tr = out
+            if isinstance(tr, dict) and tr.get("obj_emb") is not None:
+                tr["obj_emb"] = tr["obj_emb"][:, : self.embed_dim].contiguous()
+            return emb[:, : self.embed_dim].contiguous(), tr
+        return out[:, : self.embed_dim].contiguous()
 
     def _check_forward_only(self):
         if self.training:
@@ -143,6 +158,8 @@ class CellRetrievalNetwork(nn.Module):
         stream with its own workspace; the kernels of a call fill every CU, so the gain is the other half's work under each
         kernel's tail (measured 1.8 %, profiles/microbench/two_stream_overlap.py).  Cells are independent: same result."""
         if self.training and not want_trace:
+            if self.kernel_dim != self.embed_dim:
+                raise NotImplementedError(f"training-mode path at embed_dim={self.embed_dim}: built for 128 and 256")
             from .train_cell import encode_objects_train
             return encode_objects_train(self, xyz, rgb, center, mean_rgb, cell_ptr, class_idx, color_idx)
         self._check_forward_only()
@@ -152,8 +169,8 @@ class CellRetrievalNetwork(nn.Module):
         if "color" not in self.args.use_features and not getattr(self.args, "class_embed", False):
             rgb = torch.zeros_like(rgb)   # models/object_encoder.py:86-90: the PointNet++ then sees x = 0
         if streams == 2 and not want_trace and cp.shape[0] > 2 and self.precision in ("f16x3", "fp32"):
-            return self._encode_two_streams(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx, color_idx,
-                                            check_overflow)
+            return self._trim(self._encode_two_streams(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx,
+                                                       color_idx, check_overflow))
         cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx)
         out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
         if check_overflow and self.precision == "f16x3" and cp.shape[0] > 1:
@@ -166,7 +183,7 @@ class CellRetrievalNetwork(nn.Module):
                 warnings.warn(msg + "; recomputing this call on the exact fp32 path", RuntimeWarning)
                 cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx, precision="fp32")
                 out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
-        return out
+        return self._trim(out)
 
     def _encode_two_streams(self, xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx, color_idx,
                             check_overflow):
@@ -178,7 +195,7 @@ class CellRetrievalNetwork(nn.Module):
         if getattr(self, "_aux_stream", None) is None:
             self._aux_stream = torch.cuda.Stream(device=dev)
         aux = self._aux_stream
-        out = torch.empty((n_cells, self.embed_dim), dtype=torch.float32, device=dev)
+        out = torch.empty((n_cells, self.kernel_dim), dtype=torch.float32, device=dev)
         out.record_stream(aux)
         pack = self._cell_pack()
         aux.wait_stream(main)

@@ -190,8 +190,8 @@ int check_cfg(const t2p_cell_config* cfg) {
             set_error("encode_cells: objects_only supports embed_dim in {64, 128, ..., 512}, got %d", cfg->embed_dim);
             return T2P_E_UNSUPPORTED;
         }
-    } else if (cfg->embed_dim != 256 && cfg->embed_dim != 128) {
-        set_error("encode_cells: embed_dim=%d not built for the cell head (128, 256)", cfg->embed_dim);
+    } else if (cfg->embed_dim != 256 && cfg->embed_dim != 128 && cfg->embed_dim != 384) {
+        set_error("encode_cells: embed_dim=%d not built for the cell head (128, 256, 384; the host pads e.g. 300 to 384)", cfg->embed_dim);
         return T2P_E_UNSUPPORTED;
     }
     T2P_CHECK_ARG(cfg->variation == 0 || cfg->variation == 1, "encode_cells: variation=%d (0 = max, 1 = mean)",

@@ -401,16 +401,21 @@ int launch_bilstm_impl(const float* gate_table, const float* whh, const void* wh
         } else if (D == 128) {
             hipLaunchKernelGGL(k_bilstm_x3<128>, grid, dim3(256), 0, st, gate_table, (const uint4*)whh_x3, whh_scale, tokens, lengths,
                                B, T, V, hdir_ws);
+        } else if (D == 384) {   // (embed_dim 300 zero-padded by the host: a padded hidden unit stays exactly 0)
+            hipLaunchKernelGGL(k_bilstm_x3<384>, grid, dim3(256), 0, st, gate_table, (const uint4*)whh_x3, whh_scale, tokens, lengths,
+                               B, T, V, hdir_ws);
         } else {
-            set_error("bilstm: embed_dim=%d not instantiated (128, 256)", D);
+            set_error("bilstm: embed_dim=%d not instantiated (128, 256, 384)", D);
             return T2P_E_UNSUPPORTED;
         }
     } else if (D == 256) {
         hipLaunchKernelGGL(k_bilstm<256>, grid, dim3(256), 0, st, gate_table, whh, tokens, lengths, B, T, V, hdir_ws);
     } else if (D == 128) {
         hipLaunchKernelGGL(k_bilstm<128>, grid, dim3(256), 0, st, gate_table, whh, tokens, lengths, B, T, V, hdir_ws);
+    } else if (D == 384) {
+        hipLaunchKernelGGL(k_bilstm<384>, grid, dim3(256), 0, st, gate_table, whh, tokens, lengths, B, T, V, hdir_ws);
     } else {
-        set_error("bilstm: embed_dim=%d not instantiated (128, 256)", D);
+        set_error("bilstm: embed_dim=%d not instantiated (128, 256, 384)", D);
         return T2P_E_UNSUPPORTED;
     }
     }

@@ -197,7 +197,7 @@ size_t sim_topk_workspace_bytes(int64_t nq, int64_t nc, int k) {
 int launch_sim_topk(const float* Q, const float* Cm, int64_t nq, int64_t nc, int dim, int k, int64_t c_index_offset,
                     int64_t* out_idx, double* out_score, void* ws, size_t ws_bytes, hipStream_t st) {
     T2P_CHECK_ARG(k >= 1 && k <= KCAP, "sim_topk: k=%d outside [1,%d]", k, KCAP);
-    T2P_CHECK_ARG(dim == 256 || dim == 128, "sim_topk: dim=%d not instantiated (128, 256)", dim);
+    T2P_CHECK_ARG(dim == 256 || dim == 128 || dim == 384, "sim_topk: dim=%d not instantiated (128, 256, 384)", dim);
     T2P_CHECK_ARG(nc < 0x7fffffff, "sim_topk: nc too large");
     T2P_CHECK_ARG((((uintptr_t)Q) & 15) == 0 && (((uintptr_t)Cm) & 15) == 0, "sim_topk: Q and C must be 16-byte aligned");
     if (nq == 0) return 0;
@@ -217,6 +217,8 @@ int launch_sim_topk(const float* Q, const float* Cm, int64_t nq, int64_t nc, int
     ProfScope ps_("sim_partial", st);
     if (dim == 256)
         hipLaunchKernelGGL(k_sim_partial<256>, grid, dim3(256), 0, st, Q, Cm, nq, nc, cps, ps, pi, sp);
+    else if (dim == 384)
+        hipLaunchKernelGGL(k_sim_partial<384>, grid, dim3(256), 0, st, Q, Cm, nq, nc, cps, ps, pi, sp);
     else
         hipLaunchKernelGGL(k_sim_partial<128>, grid, dim3(256), 0, st, Q, Cm, nq, nc, cps, ps, pi, sp);
     }

@@ -451,7 +451,7 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
             }
             for (int i = tid; i < nd * NW; i += C::NTH) {
                 const int c = i / NW, col = i % NW;
-                p.out[(d0 + c) * (int64_t)p.ldo + col] = __int_as_float(acc_lds[i]);
+                p.out[(d0 + c) * (int64_t)p.ldo + slice * NW + col] = __int_as_float(acc_lds[i]);   // (this slice's columns)
             }
             __syncthreads();
         }
@@ -509,6 +509,8 @@ int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st) {
     WS_CASE(WS_EDGE_KNN, 256, 256, 256, 8, 1, 1, 0)
     WS_CASE(WS_EDGE_KNN, 128, 128, 128, 4, 1, 0, 0)  // embed_dim 128: 4 waves, one 32-column block each
     WS_CASE(WS_EDGE_KNN, 128, 128, 128, 4, 1, 1, 0)
+    WS_CASE(WS_EDGE_KNN, 384, 384, 128, 4, 1, 0, 0)  // embed_dim 300 zero-padded to 384: three 128-column slices, 4 waves each
+    WS_CASE(WS_EDGE_KNN, 384, 384, 128, 4, 1, 1, 0)
     // SA2 / SA3 layer-1 point tables ([feat | pos | zero pad] -> H) and GA layer 1
     WS_CASE(WS_DENSE_STORE, 96, 128, 128, 4, 2, 0, 0)
     WS_CASE(WS_DENSE_STORE, 160, 256, 256, 4, 1, 0, 0)

@@ -116,6 +116,7 @@ class LanguageEncoder(nn.Module):
         self.word_embedding = nn.Embedding(len(self.known_words), embedding_dim, padding_idx=0)
         self.lstm = nn.LSTM(input_size=embedding_dim, hidden_size=embedding_dim, bidirectional=True, num_layers=1)
         self.precision = "f16x3"   # arithmetic of the inference recurrence ("fp32": exact fp32 MFMA); the owning model sets it
+        self.kernel_dim = packing.kernel_embed_dim(int(embedding_dim))   # hidden width the kernel runs (zero-padded, see packing.py)
         self._pack = None
 
     @property
@@ -123,15 +124,15 @@ class LanguageEncoder(nn.Module):
         return self.word_embedding.weight.device
 
     def _weights(self):
-        ver = (packing.params_version(self), str(self.device), self.precision)
+        ver = (packing.params_version(self), str(self.device), self.precision, self.kernel_dim)
         if self._pack is None or self._pack[0] != ver:
             try:
-                t = packing.pack_text_weights(self, self.device, x3=self.precision == "f16x3")
+                t = packing.pack_text_weights(self, self.device, x3=self.precision == "f16x3", pad_to=self.kernel_dim)
             except packing.Fp16RangeError as e:   # a recurrent weight outside fp16's range: the exact path has no such limit
                 import warnings
                 warnings.warn(f"LanguageEncoder: {e}; the text branch runs its exact fp32 recurrence instead (about 3x "
                               "slower than the f16x3 one)", RuntimeWarning, stacklevel=3)
-                t = packing.pack_text_weights(self, self.device, x3=False)
+                t = packing.pack_text_weights(self, self.device, x3=False, pad_to=self.kernel_dim)
             self._pack = (ver, t, ops.make_text_weights(t["embedding"], t["w_ih"], t["w_hh"], t["bias"], t.get("w_hh_x3"),
                                                         t.get("w_hh_scale", 0.0)))
         return self._pack[2]
@@ -147,7 +148,9 @@ class LanguageEncoder(nn.Module):
                                      m.bias_hh_l0, m.weight_ih_l0_reverse, m.weight_hh_l0_reverse, m.bias_ih_l0_reverse,
                                      m.bias_hh_l0_reverse)
             return nn.functional.normalize(raw, dim=-1) if normalize else raw
-        out, raw = ops.encode_text(tokens, lengths, self._weights(), self.word_embedding.num_embeddings, d, want_raw=True)
+        out, raw = ops.encode_text(tokens, lengths, self._weights(), self.word_embedding.num_embeddings, self.kernel_dim, want_raw=True)
+        if self.kernel_dim != d:      # zero padding of the hidden width: cut off (it does not change the norm)
+            out, raw = out[:, :d].contiguous(), raw[:, :d].contiguous()
         return out if normalize else raw
 
     def forward(self, descriptions, normalize: bool = False):

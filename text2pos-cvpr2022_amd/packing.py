@@ -104,11 +104,64 @@ def pack_gemm_x3(w_kmajor: torch.Tensor, scale: float) -> torch.Tensor:
     return torch.stack([hi, lo]).view(torch.int16).contiguous()
 
 
+def kernel_embed_dim(d: int) -> int:
+    """Width the kernels run an embed_dim at: 128 and 256 as they are; anything else up to 384 (the reference's argparse
+    default is 300, training/args.py:19) zero-padded to 384 - the cell head, the biLSTM and the ranking kernel are built for
+    multiples of 128.  Zero weight rows / columns and zero biases keep every padded channel EXACTLY 0 through Linear + ReLU,
+    max / mean aggregation, F.normalize, the kNN distances (they add +0) and the LSTM cell (i = f = o = 1/2, g = 0: c = h = 0),
+    so the first `d` columns are the unpadded model's outputs."""
+    if d in (128, 256):
+        return d
+    if 1 <= d <= 384:
+        return 384
+    raise NotImplementedError(f"embed_dim={d}: the kernels are built for 128, 256 and (zero-padded) anything up to 384")
+
+
+def _pad_to(t: torch.Tensor, rows: int = None, cols: int = None) -> torch.Tensor:
+    """Zero-pad a 1-d / 2-d tensor to [rows][cols] (None = keep)."""
+    if t.dim() == 1:
+        n = cols if cols is not None else rows
+        if n is None or n == t.shape[0]:
+            return t
+        out = torch.zeros(n, dtype=t.dtype, device=t.device)
+        out[: t.shape[0]] = t
+        return out.contiguous()
+    r = t.shape[0] if rows is None else rows
+    c = t.shape[1] if cols is None else cols
+    if (r, c) == tuple(t.shape):
+        return t
+    out = torch.zeros((r, c), dtype=t.dtype, device=t.device)
+    out[: t.shape[0], : t.shape[1]] = t
+    return out.contiguous()
+
+
+def _pad_cell_pack(p: Dict[str, object], d: int, dp: int, cell_head: bool):
+    """embed_dim d -> dp in every tensor of the fp32 pack that has an embed_dim-sized axis (k-major [in][out] matrices)."""
+    p["pn_w"], p["pn_b"] = _pad_to(p["pn_w"], cols=dp), _pad_to(p["pn_b"], cols=dp)
+    for pre in ("col", "pos"):
+        p[pre + "_w2"], p[pre + "_b2"] = _pad_to(p[pre + "_w2"], cols=dp), _pad_to(p[pre + "_b2"], cols=dp)
+    nfeat = p["merge_w"].shape[0] // d                      # concat slots [class | color | position], d rows each
+    m = torch.zeros((nfeat * dp, dp), dtype=p["merge_w"].dtype, device=p["merge_w"].device)
+    for f in range(nfeat):
+        m[f * dp: f * dp + d, :d] = p["merge_w"][f * d: (f + 1) * d]
+    p["merge_w"], p["merge_b"] = m.contiguous(), _pad_to(p["merge_b"], cols=dp)
+    for name in ("class_embedding", "color_embedding"):
+        p[name] = _pad_to(p[name], cols=dp)
+    if cell_head:
+        for name in ("g_wp", "g_wq", "g_w2", "lin_w1", "lin_w2"):
+            p[name] = _pad_to(p[name], rows=dp, cols=dp)
+        for name in ("g_bp", "g_b2", "lin_b1", "lin_b2"):
+            p[name] = _pad_to(p[name], cols=dp)
+
+
 def pack_cell_weights(model, device, x3: bool = True) -> Dict[str, object]:
     """model: CellRetrievalNetwork or SuperGlueMatch (this package; the latter has no cell head).  Returns name -> fp32
     device tensor(s) for ops.make_cell_weights.  x3=False leaves the f16x3 images out (precision="fp32": weights outside
     fp16's range are then fine)."""
     p = _pack_cell_weights_fp32(model, device)
+    d, dp = int(model.embed_dim), int(getattr(model, "kernel_dim", model.embed_dim))
+    if dp != d:
+        _pad_cell_pack(p, d, dp, hasattr(model, "graph1"))
     if x3:
         _add_x3_images(p, device, hasattr(model, "graph1"))
     return p
@@ -228,15 +281,35 @@ def pack_match_weights(model, device, precision: str = "f16x3") -> Dict[str, obj
     return p
 
 
-def pack_text_weights(lang, device, x3: bool = False) -> Dict[str, torch.Tensor]:
+def pack_text_weights(lang, device, x3: bool = False, pad_to: int = None) -> Dict[str, torch.Tensor]:
     """lang: LanguageEncoder (this package).  nn.LSTM parameter layout: weight_ih_l0 [4D, D] (gates i,f,g,o).
-    x3: also the scaled f16x3 images of the two recurrent matrices (csrc/lstm.hip: k_bilstm_x3), one power-of-two scale."""
+    x3: also the scaled f16x3 images of the two recurrent matrices (csrc/lstm.hip: k_bilstm_x3), one power-of-two scale.
+    pad_to: hidden width the kernel runs (kernel_embed_dim): every gate block, the input axis and the embedding rows are
+    zero-padded to it."""
     lstm = lang.lstm
-    w_ih = torch.stack([lstm.weight_ih_l0.detach().double().t(), lstm.weight_ih_l0_reverse.detach().double().t()])
-    w_hh = torch.stack([lstm.weight_hh_l0.detach().double().t(), lstm.weight_hh_l0_reverse.detach().double().t()])
-    bias = torch.stack([lstm.bias_ih_l0.detach().double() + lstm.bias_hh_l0.detach().double(),
-                        lstm.bias_ih_l0_reverse.detach().double() + lstm.bias_hh_l0_reverse.detach().double()])
-    p = dict(embedding=f32(lang.word_embedding.weight.detach()).to(device), w_ih=f32(w_ih).to(device),
+    d = lstm.hidden_size
+    dp = d if pad_to is None else int(pad_to)
+
+    def gates_kmajor(w):           # [4D, D_in] -> k-major [Dp_in][4 Dp] with gate g's columns at g Dp ...
+        w = w.detach().double()
+        out = torch.zeros((dp, 4 * dp), dtype=torch.float64)
+        for g in range(4):
+            out[:d, g * dp: g * dp + d] = w[g * d: (g + 1) * d, :].t().cpu()
+        return out
+
+    def gates_vec(b):
+        b = b.detach().double().cpu()
+        out = torch.zeros(4 * dp, dtype=torch.float64)
+        for g in range(4):
+            out[g * dp: g * dp + d] = b[g * d: (g + 1) * d]
+        return out
+
+    w_ih = torch.stack([gates_kmajor(lstm.weight_ih_l0), gates_kmajor(lstm.weight_ih_l0_reverse)])
+    w_hh = torch.stack([gates_kmajor(lstm.weight_hh_l0), gates_kmajor(lstm.weight_hh_l0_reverse)])
+    bias = torch.stack([gates_vec(lstm.bias_ih_l0) + gates_vec(lstm.bias_hh_l0),
+                        gates_vec(lstm.bias_ih_l0_reverse) + gates_vec(lstm.bias_hh_l0_reverse)])
+    emb = lang.word_embedding.weight.detach()
+    p = dict(embedding=_pad_to(f32(emb), cols=dp).to(device), w_ih=f32(w_ih).to(device),
              w_hh=f32(w_hh).to(device), bias=f32(bias).to(device))
     if x3:
         w32 = f32(w_hh)

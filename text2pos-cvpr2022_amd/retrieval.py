@@ -32,6 +32,11 @@ def retrieve_topk(cell_encodings, text_encodings, k: int, device=None, index_off
             torch.device("cuda", torch.cuda.current_device())
     c = _as_device_f32(cell_encodings, device)
     q = _as_device_f32(text_encodings, device)
+    d = c.shape[1]
+    if d not in (128, 256, 384):     # e.g. embed_dim 300: zero columns up to the kernel's width add exact zeros to every score
+        from .packing import kernel_embed_dim
+        pad = kernel_embed_dim(d) - d
+        c, q = torch.nn.functional.pad(c, (0, pad)).contiguous(), torch.nn.functional.pad(q, (0, pad)).contiguous()
     return ops.sim_topk(q, c, int(k), index_offset)
 
 
