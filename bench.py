@@ -208,7 +208,7 @@ def edge_rows(ops, torch, d_xyz, d_rgb):
 
 def executed_flops(e, e1_dedup, n_obj, n_cells, knn_edges):
     """FLOPs (2 per multiply-add) the f16x3 plan executes per step, algorithmic widths (no zero padding): layer 2 of every SA
-    edge row, the layer-1 point tables per dense point (4.1 of DESIGN.md), GA, the PointNet++ heads, the object head and the
+    edge row, the layer-1 point tables per dense point, GA, the PointNet++ heads, the object head and the
     cell graph.  SURVEY 8(d)'s F_object also counts layer 1 per EDGE, which this design removes algebraically."""
     sa2 = 2.0 * (32 * 64 * e1_dedup + 128 * 128 * e[1] + 256 * 256 * e[2])
     tables = 2.0 * n_obj * (256 * 6 * 32 + 128 * 67 * 128 + 64 * 131 * 256)

@@ -1,4 +1,4 @@
-# Timing + torch.profiler table of one coarse training step on the HIP path: python profiles/train_step_time.py [batch]
+# Timing + torch.profiler table of one coarse training step on the HIP path (docs/notebook.md 4.8): python profiles/train_step_time.py [batch]
 import sys, time, torch, numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests/golden')
 import weights as W

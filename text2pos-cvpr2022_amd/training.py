@@ -1,6 +1,6 @@
 """Host loop of the reference's coarse training (training/coarse.py:31-62, `train_epoch`) on the HIP path: same batch
 dictionary (`texts`, `objects`, `object_points` as the reference's Kitti360CoarseDataset.collate_fn yields them), same
-order of calls; the arithmetic is DESIGN.md 4.8.  The data side (datasets, augmentation, plotting) stays with the caller."""
+order of calls; the arithmetic is docs/notebook.md 4.8.  The data side (datasets, augmentation, plotting) stays with the caller."""
 from typing import Iterable, Optional
 
 import numpy as np
