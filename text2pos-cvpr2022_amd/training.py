@@ -10,8 +10,10 @@ from .losses import HardestRankingLoss, PairwiseRankingLoss
 
 
 def make_criterion(args) -> torch.nn.Module:
-    """training/coarse.py:279-284: --ranking_loss pairwise (the default, training/args.py:48) or hardest; triplet needs the
-    dataset's negative cells and is not built."""
+    """training/coarse.py:279-284: --ranking_loss pairwise (the default, training/args.py:48) or hardest.  `triplet` is not
+    built: it needs the dataset's negative cells, and the reference's own branch cannot run as written - it calls
+    `model.encode_objects(negative_cell_objects)` without the `object_points` argument the method requires
+    (training/coarse.py:48-51 against models/cell_retrieval.py:77)."""
     kind = getattr(args, "ranking_loss", "pairwise")
     margin = getattr(args, "margin", 0.35)
     if kind == "pairwise":
