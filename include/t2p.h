@@ -180,11 +180,14 @@ typedef struct t2p_cell_config {
      * others swap a kernel for one that adds the same f16x3 products in another k grouping (results agree to fp32 rounding):
      *   bit 0: keep the edge rows of repeated points in SA level 1's row lists (default: t2p_dedup_rows drops them)
      *   bit 1: f16x3 only: gather the centroid tables of all SA levels from HBM (default: built in LDS); SA levels 1 and 2
-     *          then run on the column-slice kernel of ws_sa2.hip
+     *          then run on the column-slice kernel of ws_sa2.hip (all three levels)
      *   bit 2: f16x3 only: SA level 2 on the column-slice kernel of ws_sa2.hip (default: the row-owning kernel of
      *          sa_rows.hip: a wave holds the whole 128 x 128 weight matrix and multiplies its own 32-row tiles)
      *   bit 3: f16x3 only: SA level 1 on the column-slice kernel of ws_sa2.hip (default: sa_groups.hip: independent waves,
-     *          each owning a group of 16 centroids of an object with a private LDS accumulator) */
+     *          each owning a group of 16 centroids of an object with a private LDS accumulator)
+     *   bit 4: f16x3 only: SA level 3 on sa_wide.hip (four waves of 64 columns on one SIMD each, every wave converting its own
+     *          k-quarter of the tile's rows; measured SLOWER than the default column-slice kernel of ws_sa2.hip - kept as the
+     *          measured form of that design, docs/notebook.md; ignored with bit 1) */
     int32_t tuning;
 } t2p_cell_config;
 

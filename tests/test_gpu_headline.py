@@ -646,23 +646,25 @@ def test_execution_plans_are_bit_identical(hip_model):
     """t2p_cell_config.tuning switches between equivalent plans.  Bit 0 (repeated points' rows kept / dropped) and the
     HBM / LDS form of the centroid tables must not change a single bit of any output.  Bits 1-3 also choose the kernel of SA
     levels 1 and 2: the centroid-group kernel (sa_groups.hip) / the row-owning kernel (sa_rows.hip) by default, the column-slice
-    kernel (ws_sa2.hip) otherwise - the same f16x3 products summed in another k grouping.  Plans that run the same kernels form
-    a family that is bit-identical within itself; the families agree to fp32 rounding."""
+    kernel (ws_sa2.hip) otherwise; bit 4 moves SA level 3 from ws_sa2.hip to the four-wave kernel of sa_wide.hip (LDS tables
+    only) - the same f16x3 products summed in another k grouping.  Plans that run the same kernels form a family that is
+    bit-identical within itself; the families agree to fp32 rounding."""
     from text2pos_amd import synthetic as S
     xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(77, 40)
     args = _to_dev(xyz, rgb, center, mean_rgb)
     outs = {}
     try:
-        for tuning in range(16):
+        for tuning in range(32):
             hip_model.tuning = tuning
             with torch.no_grad():
                 outs[tuning] = hip_model.encode_objects_packed(*args, cell_ptr, want_trace=("sa_out", "obj_emb"))
     finally:
         hip_model.tuning = 0
-    # (SA1 on the old kernel, SA2 on the old kernel): bit 1 moves both, bit 3 SA1, bit 2 SA2
-    family = lambda t: (bool(t & 0b1010), bool(t & 0b0110))
+    # (SA1 on the old kernel, SA2 on the old kernel, SA3 on sa_wide.hip): bit 1 moves the first two, bit 3 SA1, bit 2 SA2;
+    # bit 4 SA3 unless bit 1 is set
+    family = lambda t: (bool(t & 0b1010), bool(t & 0b0110), bool(t & 0b10000) and not (t & 0b10))
     ref = {}
-    for t in range(16):
+    for t in range(32):
         out, tr = outs[t]
         if family(t) not in ref:
             ref[family(t)] = t
@@ -671,8 +673,8 @@ def test_execution_plans_are_bit_identical(hip_model):
         assert torch.equal(out, ref_out) and torch.equal(tr["obj_emb"], ref_tr["obj_emb"]), f"tuning {t}"
         for l in range(3):
             assert torch.equal(tr["sa_out"][l], ref_tr["sa_out"][l]), f"tuning {t}: SA{l + 1} output"
-    assert len(ref) == 4
-    b_out, b_tr = outs[ref[(True, True)]]                  # all levels on ws_sa2.hip (round 2's plan)
+    assert len(ref) == 8
+    b_out, b_tr = outs[ref[(True, True, False)]]                  # all levels on ws_sa2.hip (round 2's plan)
     for fam, t in ref.items():
         a_out, a_tr = outs[t]
         if not fam[0]:

@@ -247,7 +247,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     const bool lds_btab = cfg.precision == 1 && !(cfg.tuning & 2);
     // ... and level 0 runs on the centroid-group kernel (sa_groups.hip), which builds its tables per group as well
     const bool lds_btab0 = lds_btab && !(cfg.tuning & 8);
-    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0);
+    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0) | ((cfg.tuning & 16) ? 4 : 0);
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st, guard));
     // models/object_encoder.py:86: the PointNet++ only runs when the "class" feature does not come from class_embedding
     const bool run_pointnet = cfg.use_class && !cfg.class_embed;
