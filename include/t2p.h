@@ -183,11 +183,14 @@ typedef struct t2p_cell_config {
      *          then run on the column-slice kernel of ws_sa2.hip (all three levels)
      *   bit 2: f16x3 only: SA level 2 on the column-slice kernel of ws_sa2.hip (default: the row-owning kernel of
      *          sa_rows.hip: a wave holds the whole 128 x 128 weight matrix and multiplies its own 32-row tiles)
-     *   bit 3: f16x3 only: SA level 1 on the column-slice kernel of ws_sa2.hip (default: sa_groups.hip: independent waves,
-     *          each owning a group of 16 centroids of an object with a private LDS accumulator)
+     *   bit 3: f16x3 only: SA level 1 on the column-slice kernel of ws_sa2.hip (default: sa_points.hip: independent waves,
+     *          each owning a group of 16 centroids of an object with a private LDS accumulator; BOTH layers per edge from the
+     *          object's points staged in LDS - no point table A_1, no row gathers)
      *   bit 4: f16x3 only: SA level 3 on sa_wide.hip (four waves of 64 columns on one SIMD each, every wave converting its own
      *          k-quarter of the tile's rows; measured SLOWER than the default column-slice kernel of ws_sa2.hip - kept as the
-     *          measured form of that design, docs/notebook.md; ignored with bit 1) */
+     *          measured form of that design, docs/notebook.md; ignored with bit 1)
+     *   bit 5: f16x3 only: SA level 1 on sa_groups.hip (the same wave organisation, layer 1 split algebraically: rows of the
+     *          point table A_1 gathered per edge by LDS-DMA; round 3's first form, ~1.1 ms slower + 1.0 ms of table writes) */
     int32_t tuning;
 } t2p_cell_config;
 

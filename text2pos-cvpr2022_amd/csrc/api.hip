@@ -247,7 +247,9 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     const bool lds_btab = cfg.precision == 1 && !(cfg.tuning & 2);
     // ... and level 0 runs on the centroid-group kernel (sa_groups.hip), which builds its tables per group as well
     const bool lds_btab0 = lds_btab && !(cfg.tuning & 8);
-    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0) | ((cfg.tuning & 16) ? 4 : 0);
+    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0) | ((cfg.tuning & 16) ? 4 : 0) | ((cfg.tuning & 32) ? 8 : 0);
+    // ... by default on sa_points.hip, which computes layer 1 per edge from the points themselves: no point table A_1 either
+    const bool sa1_points = lds_btab0 && !(cfg.tuning & 32) && cfg.n_pts == 256;
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st, guard));
     // models/object_encoder.py:86: the PointNet++ only runs when the "class" feature does not come from class_embedding
     const bool run_pointnet = cfg.use_class && !cfg.class_embed;
@@ -269,7 +271,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
             gt.ld_tail[l] = Geo::LD[l];
             gt.tail_col0[l] = Geo::C[l];
         }
-        gt.A1 = ws.A[0];
+        gt.A1 = sa1_points ? nullptr : ws.A[0];
         gt.w1 = W.sa_w1[0];
         gt.b1 = W.sa_b1[0];
         gt.rgb = rgb;
@@ -291,6 +293,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
             bp[l].wp = (l > 0 ? lds_btab : lds_btab0) ? W.sa_w1[l] : nullptr;   // (non-null = LDS centroid table: selects the launch shape)
             bp[l].plan = sa_plan;
         }
+        bp[0].w1 = sa1_points ? W.sa_w1[0] : nullptr;
         T2P_TRY(launch_sa_balance_levels(bp, Geo::H, Geo::C, st));
     }
 
@@ -336,6 +339,11 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.pos_src = pos_src;
         p.ld_pos = ld_pos;
         p.pos_col0 = pos_col0;
+        if (l == 0 && sa1_points) {
+            p.feat_src = rgb;
+            p.w1 = W.sa_w1[0];
+            p.b1 = W.sa_b1[0];
+        }
         p.n_dense = g.nd[l];
         p.n_cent = g.nc[l];
         p.n_obj = n;

@@ -235,6 +235,9 @@ struct SaParams {
     const uint8_t* fps_idx;  // [n_obj][n_cent]
     const float* pos_src;    // rows holding the dense positions of this level
     int ld_pos, pos_col0;
+    const float* feat_src;   // sa_points.hip (level 1 only): the points' features [n_obj*n_dense][3] (rgb), the whole layer-1
+    const float* w1;         // weight matrix [6][H] (feature rows, then position rows) and its bias [H]; nullptr: the kernels
+    const float* b1;         // that gather the point table A
     int n_dense, n_cent;
     int64_t n_obj;
     int32_t* prefix_ws;      // [n_obj+1] scratch (tile prefix sums)
@@ -243,7 +246,7 @@ struct SaParams {
     uint32_t* amax_out;      // f16x3 guard (nullable): largest output magnitude (the next dense kernel splits these rows)
     int plan;                // bit 0: SA level 2 stays on the column-slice kernel (ws_sa2.hip) instead of the row-owning one (sa_rows.hip);
                              // bit 1: SA level 1 stays on it instead of the centroid-group kernel (sa_groups.hip); bit 2: SA level 3 moves from it
-                             // to sa_wide.hip (opt-in: measured slower)
+                             // to sa_wide.hip (opt-in: measured slower); bit 3: SA level 1 on sa_groups.hip (gathered point table) instead of sa_points.hip
 };
 int launch_ws_sa(int H, int C, const SaParams& p, hipStream_t st);
 // sa_rows.hip: row-owning f16x3 kernel of SA level 2 (H = C = 128, LDS centroid table): true when launch_ws_sa routes p there
@@ -254,6 +257,10 @@ int sa_rows_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
 bool sa_groups_selected(int H, int C, const SaParams& p);
 int launch_sa_groups(int H, int C, const SaParams& p, hipStream_t st);
 int sa_groups_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
+// sa_points.hip: both layers per edge from the object's points in LDS, f16x3 kernel of SA level 1 (needs wp, w1, b1, feat_src)
+bool sa_points_selected(int H, int C, const SaParams& p);
+int launch_sa_points(int H, int C, const SaParams& p, hipStream_t st);
+int sa_points_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
 // sa_wide.hip: k-split conversion / column-split product, f16x3 kernel of SA level 3 (H = C = 256; needs wp)
 bool sa_wide_selected(int H, int C, const SaParams& p);
 int launch_sa_wide(int H, int C, const SaParams& p, hipStream_t st);
