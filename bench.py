@@ -206,16 +206,17 @@ def edge_rows(ops, torch, d_xyz, d_rgb):
     return e, e1_dedup
 
 
-def executed_flops(e, e1_dedup, n_obj, n_cells, knn_edges):
+def executed_flops(e, e1_dedup, n_obj, n_cells, knn_edges, sa1_per_edge=True):
     """FLOPs (2 per multiply-add) the f16x3 plan executes per step, algorithmic widths (no zero padding): layer 2 of every SA
-    edge row, the layer-1 point tables per dense point, GA, the PointNet++ heads, the object head and the
-    cell graph.  SURVEY 8(d)'s F_object also counts layer 1 per EDGE, which this design removes algebraically."""
-    sa2 = 2.0 * (32 * 64 * e1_dedup + 128 * 128 * e[1] + 256 * 256 * e[2])
-    tables = 2.0 * n_obj * (256 * 6 * 32 + 128 * 67 * 128 + 64 * 131 * 256)
+    edge row, layer 1 per EDGE at level 1 (6 inputs wide: sa_points.hip; `sa1_per_edge` False = the plans with a point table A_1)
+    and as point tables per dense point at levels 2 and 3, GA, the PointNet++ heads, the object head and the
+    cell graph.  SURVEY 8(d)'s F_object counts layer 1 per EDGE at every level, which this design removes algebraically there."""
+    sa2 = 2.0 * ((32 * 64 + (6 * 32 if sa1_per_edge else 0)) * e1_dedup + 128 * 128 * e[1] + 256 * 256 * e[2])
+    tables = 2.0 * n_obj * ((0 if sa1_per_edge else 256 * 6 * 32) + 128 * 67 * 128 + 64 * 131 * 256)
     ga = 2.0 * n_obj * 32 * (259 * 512 + 512 * 1024)
     heads = n_obj * (1048576.0 + 262144.0 + 590592.0)
     graph = 2.0 * n_obj * 2 * 256 * 256 + 2.0 * knn_edges * 256 * 256 + n_cells * 262144.0
-    return {"sa_layer2": sa2, "sa_layer1_tables": tables, "ga": ga, "heads": heads, "cell_graph": graph,
+    return {"sa_edge_rows": sa2, "sa_layer1_tables": tables, "ga": ga, "heads": heads, "cell_graph": graph,
             "total": sa2 + tables + ga + heads + graph}
 
 
@@ -565,9 +566,11 @@ def main():
         # the other SA levels and the whole step, same convention (algorithmic FLOPs executed / hipEvent time)
         sizes_np = np.diff(cell_ptr).astype(np.int64)
         knn_edges = int((sizes_np * np.minimum(sizes_np, 8)).sum())
-        ex = executed_flops(e_lvl, e1_dedup if not (args.tuning & 1) else e_lvl[0], n_obj, c_hi - c_lo, knn_edges)
+        sa1_per_edge = args.precision == "f16x3" and not (args.tuning & (2 | 8 | 32))     # (sa_points.hip runs level 1)
+        ex = executed_flops(e_lvl, e1_dedup if not (args.tuning & 1) else e_lvl[0], n_obj, c_hi - c_lo, knn_edges, sa1_per_edge)
         sa_levels = {}
-        for name, rows_l, hc in (("ws_edge_sa_k32_n64", e1_dedup if not (args.tuning & 1) else e_lvl[0], 32 * 64),
+        for name, rows_l, hc in (("ws_edge_sa_k32_n64", e1_dedup if not (args.tuning & 1) else e_lvl[0],
+                                  32 * 64 + (6 * 32 if sa1_per_edge else 0)),
                                  ("ws_edge_sa_k128_n128", e_lvl[1], 128 * 128), ("ws_edge_sa_k256_n256", e_lvl[2], 256 * 256)):
             ln, ms = prof.get(name, (0, 0.0))
             tf = 2.0 * hc * rows_l * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else None
@@ -576,8 +579,8 @@ def main():
                                "frac_of_f16x3_ceiling": (3.0 * tf / peak if tf else None) if args.precision == "f16x3" else None}
         whole_step = {"executed_flop_per_step": ex, "achieved_tflops": ex["total"] / (ms_per_step * 1e-3) / 1e12,
                       "frac_of_peak": ex["total"] / (ms_per_step * 1e-3) / 1e12 / peak,
-                      "note": "algorithmic FLOPs this plan executes (layer 1 of the SA MLPs per point, not per edge; SA1 rows after "
-                              "t2p_dedup_rows) over the whole timed step, text branch and ranking excluded"}
+                      "note": "algorithmic FLOPs this plan executes (layer 1 of the SA MLPs per point at levels 2 / 3, per edge at level 1; "
+                              "SA1 rows after t2p_dedup_rows) over the whole timed step, text branch and ranking excluded"}
         out = {
             "metric": "cells+queries encoded/sec and top-k retrieval QPS, 256-pt cells, 12k-cell DB",
             "value": (n_cells_total + n_q_total) / (elapsed / args.steps),
