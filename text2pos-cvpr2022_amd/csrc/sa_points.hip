@@ -13,8 +13,10 @@
 //     operand), so ReLU + fp16 split feed the 12 layer-2 MFMAs without touching LDS;
 //   * self-loop rows take their point from ANOTHER object's rows (PyG's index aliasing: row sbase + c of the flattened batch):
 //     16 such points per centroid group, fetched one group ahead into a 512-byte side table;
-//   * work distribution, group bounds, private accumulator and drain are sa_groups.hip's: 12 independent waves per CU, objects
-//     handed out through an LDS counter, no barrier, no atomics between waves.
+//   * 12 independent waves per CU, objects handed out through an LDS counter, no barrier, no atomics between waves.  The row list
+//     (sorted by centroid) streams through a 256-entry LDS ring; a wave's max-accumulator is a WINDOW of 16 centroid slots (slot =
+//     centroid & 15) in two halves: a tile takes the next 32 rows as long as they stay within the half of its first row and the
+//     next one (31.6 live rows per tile), a half is drained - relu(max + bias) -> its 8 output rows - once the list has passed it.
 // k_sample_group no longer writes the A_1 table (6.3 GB per step) and no B_1 table exists at all.
 // T2P_PABL (development only, results are wrong): 1 = no atomics, 2 = no layer-2 MFMAs, 4 = no layer-1 MFMAs, 8 = no point reads
 #ifndef T2P_PABL
@@ -46,9 +48,9 @@ struct PtsCfg {
     static constexpr int K = 32, N = 64, NC = 128, ND = 256, GS = 16;
     static constexpr int NT = 64 * NW;
     static constexpr int S16 = K / 16, NTW = N / 32;
-    static constexpr int NG = NC / GS;                   // groups per object
+    static constexpr int HS = GS / 2, NH = NC / HS;      // the accumulator window's halves: 8 centroids, 16 halves per object
     static constexpr int MAXR = NC * 33;
-    static constexpr int LPR = 64 / GS;                  // lanes per centroid row in the drain
+    static constexpr int LPR = 64 / HS;                  // lanes per centroid row in the drain (of a half)
     static constexpr int ACC_BYTES = GS * N * 4;
     static constexpr int PTS_BYTES = ND * 24;            // [r g b x y z] per point
     static constexpr int SELF_BYTES = GS * 24;           // the points the group's self-loop rows name (same record)
@@ -103,7 +105,7 @@ __device__ unsigned long long t2p_pprof_sums[16];
 template <int NW>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p) {
     using C = PtsCfg<NW>;
-    constexpr int K = C::K, N = C::N, NC = C::NC, GS = C::GS;
+    constexpr int K = C::K, N = C::N, NC = C::NC;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
     }
     constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    // drain: lane = (centroid row cr of the group, column slice cs); side tables: lanes 0 .. GS - 1 own one centroid each
+    // drain of a half: lane = (centroid row cr of the half, column slice cs)
     const int cr = lane / C::LPR, cs = lane % C::LPR;
     constexpr int NPL = N / C::LPR;
     const uint32_t bias_off = (uint32_t)(NW * C::WAVE_BYTES + 16 + cs * NPL * 4);   // (this lane's NPL bias values, shared table)
@@ -207,22 +209,19 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
         uint32_t pend = load_win(2);
         int w_loaded = 2;
 
-        // side tables of a group, fetched ahead (every lane fetches centroid lane & 15: no masked merges, no early waits):
-        // centroid position (the [xyz 0] tail of the output row) and the point its self-loop row names (row sb0 + c of the batch)
-        float qx, qy, qz, sx, sy, sz, sr, sg, sbl;
-        int jf;      // the group the registers above belong to
-        auto fetch_side = [&](int jg) {
-            const int c = jg * GS + (lane & (GS - 1));
+        // side data of a half (8 centroids), fetched ahead; every lane fetches centroid lane & 7 (no masked merges, no early
+        // waits): centroid position (the [xyz 0] tail of the output row) and the point its self-loop row names (row sb0 + c)
+        // (three 12-byte vectors: the loop-carried registers are the load's own register triples - no copy that would wait for the
+        // load on the spot)
+        typedef float f32x3 __attribute__((ext_vector_type(3)));
+        struct Side { f32x3 q, sp, sc; };      // centroid xyz | self-loop point xyz | rgb
+        auto fetch_side = [&](int hh) -> Side {
+            const int c = hh * C::HS + (lane & (C::HS - 1));
             const float* pc = p.out + ((int64_t)g * NC + c) * (int64_t)p.ldo + N;
-            qx = pc[0], qy = pc[1], qz = pc[2];
             const int64_t ai = (int64_t)sb0 + c;
-            const float* ax = p.pos_src + ai * 3;
-            const float* ac = p.feat_src + ai * 3;
-            sx = ax[0], sy = ax[1], sz = ax[2];
-            sr = ac[0], sg = ac[1], sbl = ac[2];
-            jf = jg;
+            return Side{*(const f32x3*)pc, *(const f32x3*)(p.pos_src + ai * 3), *(const f32x3*)(p.feat_src + ai * 3)};
         };
-        fetch_side(0);
+        const Side side0 = fetch_side(0), side1 = fetch_side(1);     // the first two halves are opened before the first tile
 
         // ---- the object's points -> LDS records [r g b x y z] (lane l: points 4 l .. 4 l + 3 = 96 contiguous bytes) --------------
         {
@@ -242,9 +241,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
         ring_write(1, win1);
         PPROF_MARK(1);      // points, list windows -> LDS
 
-        // drain of a group: relu(max + bias) of its GS centroids (an empty group: zeros).  The rows wait in registers and leave at
-        // the next list-window event (flush_out): vmcnt counts stores and loads alike, a store issued at the group change would
-        // sit in front of the next load the loop has to wait for
+        // The accumulator is a WINDOW of 16 centroid slots (slot = centroid & 15) in two halves of 8.  A tile may hold rows of the
+        // half of its first row and the next one, so tiles are full (32 rows) wherever the list goes on; a half is drained (relu(max
+        // + bias) -> its 8 output rows) once the list has passed it, and its slots start over for the half two further on.
+        // The drained rows wait in registers and leave at the next list-window event (flush_out): vmcnt counts stores and loads
+        // alike, a store issued here would sit in front of the next load the loop has to wait for.
         auto flush_out = [&]() {
             if (has_pout) {
 #pragma unroll
@@ -252,17 +253,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
                 has_pout = false;
             }
         };
-        auto drain = [&](int jg, bool empty) {
+        auto drain = [&](int hh, bool live) {        // live: the half's slots were initialised (else: no rows at all, zeros)
             flush_out();
-            const int c0 = jg * GS;
-            if (!empty) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            pptr = p.out + ((int64_t)g * NC + c0 + cr) * (int64_t)p.ldo + cs * NPL;
+            pptr = p.out + ((int64_t)g * NC + hh * C::HS + cr) * (int64_t)p.ldo + cs * NPL;
+            const uint32_t a0 = acc_off + (uint32_t)((((hh & 1) * C::HS + cr) * N + cs * NPL) * 4);
             int top = gtop;
 #pragma unroll
             for (int q4 = 0; q4 < NPL / 4; q4++) {
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (!empty) {
-                    const f32x4 raw = *(const f32x4*)(lds + acc_off + (cr * N + cs * NPL + q4 * 4) * 4);
+                if (live) {
+                    const f32x4 raw = *(const f32x4*)(lds + a0 + q4 * 16);
                     const f32x4 bq = *(const f32x4*)(lds + bias_off + q4 * 16);
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -277,42 +277,58 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
             has_pout = true;
             gtop = top;
         };
+        auto open_half = [&](int hh, const Side& sd) {     // slots of half hh: accumulator at -inf, side tables
+            const uint32_t s0 = (uint32_t)((hh & 1) * C::HS);
+            if (lane < C::HS) {
+                uint2* sp = (uint2*)(lds + self_off + (s0 + lane) * 24);
+                sp[0] = uint2{__float_as_uint(sd.sc[0]), __float_as_uint(sd.sc[1])};
+                sp[1] = uint2{__float_as_uint(sd.sc[2]), __float_as_uint(sd.sp[0])};
+                sp[2] = uint2{__float_as_uint(sd.sp[1]), __float_as_uint(sd.sp[2])};
+                f32x4* cp = (f32x4*)(lds + cen_off + (s0 + lane) * 32);
+                cp[0] = f32x4{0.f, 0.f, 0.f, sd.q[0]};
+                cp[1] = f32x4{sd.q[1], sd.q[2], 0.f, 0.f};
+            }
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const uint32_t a0 = acc_off + (uint32_t)(((s0 + cr) * N + cs * NPL) * 4);
+#pragma unroll
+            for (int q4 = 0; q4 < NPL / 4; q4++)
+                *(i32x4*)(lds + a0 + q4 * 16) = i32x4{(int)0xFF800000, (int)0xFF800000, (int)0xFF800000, (int)0xFF800000};
+        };
 
-        int j = -1;          // the open group
+        open_half(0, side0);
+        open_half(1, side1);
+        Side side_n = fetch_side(2);     // runs one half ahead of the window
+        int hf = 2;                      // the half `side_n` belongs to
+        int hd = 0, ho = 2;              // halves drained / opened (hd <= ho <= hd + 2)
         int r0 = 0;
         uint32_t e_cur = n > 0 ? ring_read(0) : 0u;
         while (r0 < n) {
             PPROF_COUNT(10);
-            // ---- this tile: rows r0 .. r0 + c - 1 of group jt (the list is sorted by centroid: a group is one contiguous piece) -------
+            // ---- this tile: rows r0 .. r0 + c - 1, all in halves h0 and h0 + 1 (the list is sorted by centroid) -----------------------
             const uint32_t key = r0 + rr < n ? ((e_cur >> 8) & 127u) : 255u;
-            const int jt = __builtin_amdgcn_readfirstlane((int)key) >> 4;
-            const uint32_t over = (uint32_t)__ballot(key >= (uint32_t)((jt + 1) * GS));    // (lanes 32 .. 63 repeat 0 .. 31)
+            const int h0 = __builtin_amdgcn_readfirstlane((int)key) >> 3;
+            const uint32_t over = (uint32_t)__ballot(key >= (uint32_t)((h0 + 2) * C::HS));    // (lanes 32 .. 63 repeat 0 .. 31)
             const int c = over ? (int)__builtin_ctz(over) : 32;
             const uint32_t e_nxt = ring_read(r0 + c);     // the next tile's entries (the ring always holds 64 entries past r0)
-            if (jt != j) {
-                // ---- open group jt: its side tables (fetched a group ago; the previous group's tiles no longer read them), the
-                // next group's fetch; then close the previous group and write the empty ones in between (stores go last: the
-                // next wait for a load also waits for them)
-                if (jf != jt) fetch_side(jt);
-                if (lane < GS) {
-                    uint2* sp = (uint2*)(lds + self_off + lane * 24);
-                    sp[0] = uint2{__float_as_uint(sr), __float_as_uint(sg)};
-                    sp[1] = uint2{__float_as_uint(sbl), __float_as_uint(sx)};
-                    sp[2] = uint2{__float_as_uint(sy), __float_as_uint(sz)};
-                    f32x4* cp = (f32x4*)(lds + cen_off + lane * 32);
-                    cp[0] = f32x4{0.f, 0.f, 0.f, qx};
-                    cp[1] = f32x4{qy, qz, 0.f, 0.f};
+            if (hd < h0 || ho < h0 + 2) {
+                // ---- the window moves: close the halves the list has passed, open those this tile may touch ----------------------------
+                if (hd < h0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (their atomics)
+                while (hd < h0) {
+                    drain(hd, hd < ho);
+                    hd++;
                 }
-                if (jt + 1 < C::NG) fetch_side(jt + 1);
-                if (j >= 0) drain(j, false);
-                for (int je = j + 1; je < jt; je++) drain(je, true);
-                j = jt;
-                typedef int i32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-                for (int q4 = 0; q4 < NPL / 4; q4++)
-                    *(i32x4*)(lds + acc_off + (cr * N + cs * NPL + q4 * 4) * 4) =
-                        i32x4{(int)0xFF800000, (int)0xFF800000, (int)0xFF800000, (int)0xFF800000};
-                PPROF_MARK(3);  // group change
+                if (ho < hd) ho = hd;        // (halves skipped without a row were never opened)
+                const int want = h0 + 2 < C::NH ? h0 + 2 : C::NH;
+                while (ho < want) {
+                    if (hf != ho) side_n = fetch_side(ho);
+                    open_half(ho, side_n);
+                    ho++;
+                    if (ho < C::NH) {
+                        side_n = fetch_side(ho);
+                        hf = ho;
+                    }
+                }
+                PPROF_MARK(3);  // window move
             }
             // list ring: one more window into LDS whenever less than 96 entries lie ahead (every other tile); behind its wait the
             // pending output rows leave, then the next window's load
@@ -322,12 +338,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
                 flush_out();
                 if (w_loaded < nwin) pend = load_win(w_loaded);
             }
-            const int c0 = j * GS;
             // rows past the tile's end repeat its last row (same maximum)
             const uint32_t m = rr < c ? e_cur : (uint32_t)__builtin_amdgcn_readlane((int)e_cur, c - 1);
             // ---- layer-1 input of this lane's row: [r g b dx] (half 0) / [dy dz 1 0] (half 1) --------------------------------
             const uint32_t src = m & 0xFFu, d = m >> 8;
-            const uint32_t dl = (d & 127u) - (uint32_t)c0;
+            const uint32_t dl = d & 15u;                  // slot of the row's centroid in the 16-centroid window
             const uint32_t rec = (d & 0x80u) ? self_off + dl * 24u : pts_off + src * 24u;
             const uint32_t pa0 = rec + (uint32_t)(h * 16), pa1 = h ? one_off : rec + 8u;
             f32x4 pv, cv;
@@ -407,14 +422,17 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
                             asm volatile("; %0 %1" ::"v"(ad[e]), "v"(acc[nt][e]));
                 PPROF_MARK(6);  // atomics
             }
+#if T2P_PPROF
+            pp_sum[8] += c;
+#endif
             r0 += c;
             e_cur = e_nxt;
         }
-        // ---- close the last group, write the empty ones behind it ------------------------------------------------------------
-        if (j >= 0) drain(j, false);
-        for (int je = j + 1; je < C::NG; je++) drain(je, true);
+        // ---- close what is open, write the halves behind the list's end -------------------------------------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (; hd < C::NH; hd++) drain(hd, hd < ho);
         flush_out();
-        PPROF_MARK(7);      // last drain
+        PPROF_MARK(7);      // last drains
     }
 #if T2P_PPROF
     if (blockIdx.x == 0 && wave == T2P_PPROF - 1 && lane == 0) {
