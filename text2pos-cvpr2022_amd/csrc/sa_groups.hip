@@ -112,7 +112,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_groups(SaParams p)
 #pragma unroll
     for (int e = 0; e < NPL; e++) bias_l[e] = p.bias[cs * NPL + e];
 
-    uint32_t gbits = 0;   // fp16-range guard: wave-uniform maximum (bit pattern, before out_scale) of the drained outputs
+    int gtop = 0;         // fp16-range guard: this lane's maximum (bit pattern, before out_scale) of the drained outputs; reduced over
+                          // the wave once, at the end (six ds_bpermute round trips per drain otherwise)
     const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
     // objects are handed out dynamically (an LDS counter): a wave that draws a light object comes back sooner
     int* ctr = (int*)(lds + NW * C::WAVE_BYTES);
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_groups(SaParams p)
             // ---- drain: relu(max + bias) of the group's GS centroids ---------------------------------------------------------
             {
                 float* o = p.out + ((int64_t)g * NC + c0 + cr) * (int64_t)p.ldo + cs * NPL;
-                int top = 0;
+                int top = gtop;
 #pragma unroll
                 for (int q4 = 0; q4 < NPL / 4; q4++) {
                     const f32x4 raw = *(const f32x4*)(lds + acc_off + (cr * N + cs * NPL + q4 * 4) * 4);
@@ -336,10 +337,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_groups(SaParams p)
                     }
                     *(f32x4*)(o + q4 * 4) = v;
                 }
-                guard_track_bits(gbits, top);
+                gtop = top;
             }
         }
     }
+    uint32_t gbits = 0;
+    guard_track_bits(gbits, gtop);
     if (p.amax_out != nullptr && lane == 0 && gbits != 0u)
         atomicMax(p.amax_out, __float_as_uint(__uint_as_float(gbits) * p.out_scale));
 }

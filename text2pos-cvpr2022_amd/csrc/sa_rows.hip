@@ -22,7 +22,7 @@
 //     re-indexed at load time; every fp32 accumulation runs hi.hi, hi.lo, lo.hi per step like ws_sa2.hip, with another
 //     grouping of the k's (results agree to fp32 rounding, not bit for bit).
 // T2P_RABL (development only, results are wrong): 1 = no ring DMA, 2 = no atomics, 4 = no drain stores / table build,
-// 8 = no MFMAs (first and last of a step kept)
+// 8 = no MFMAs (first and last of a step kept), 16 = no object barriers
 #ifndef T2P_RABL
 #define T2P_RABL 0
 #endif
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
     }
 
     for (int i = tid; i < NC * N; i += C::NT) acc_lds[i] = (int)0xFF800000;   // -inf
-    uint32_t gbits = 0;   // fp16-range guard: wave-uniform maximum (bit pattern, before out_scale) of the drained outputs
+    int gtop = 0;         // fp16-range guard: this lane's maximum (bit pattern, before out_scale) of the drained outputs; reduced over
+                          // the wave once, at the end (six ds_bpermute round trips per drain otherwise)
 
     const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
 
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
         // ---- per-object phases --------------------------------------------------------------------------------------------
         auto flush = [&](int g) {   // accumulator -> output rows of object g: relu(max + bias); leaves the accumulator at -inf
             float* o = p.out + (int64_t)g * NC * (int64_t)p.ldo;
-            int top = 0;
+            int top = gtop;
             static_assert(C::NT % (N / 4) == 0, "a thread keeps its column quad over the drain");
 #pragma unroll
             for (int k = 0; k < NC * N / 4 / C::NT; k++) {
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                 *(f32x4*)(o + c * (int64_t)p.ldo + c4 * 4) = v;
                 *(i32x4*)a = i32x4{(int)0xFF800000, (int)0xFF800000, (int)0xFF800000, (int)0xFF800000};
             }
-            guard_track_bits(gbits, top);
+            gtop = top;
         };
         auto build_b = [&](int g) {   // centroid table of object g from its positions (cpos buffer g & 1)
             const float* cp = (const float*)(lds + C::CPOS_OFF + (g & 1) * C::CPOS_BUF);
@@ -496,17 +497,19 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
             // the DMA pieces this wave issued for later objects (row lists, positions) are older than any ring piece a
             // counted wait has since retired - unless the wave had no tile here
             if (!did_tile) wait_all_vm();
-            lds_barrier_r();                                    // A: all atomics of object gi are in the accumulator
+            if constexpr (!(T2P_RABL & 16)) lds_barrier_r();    // A: all atomics of object gi are in the accumulator
             if constexpr (!(T2P_RABL & 4)) flush(ga + gi);
             if (gi + 1 < cnt) {
                 if constexpr (!(T2P_RABL & 4)) build_b(ga + gi + 1);
                 if (gi + 3 < cnt) dma_rows(ga + gi + 3);
                 if (gi + 2 < cnt) dma_cpos(ga + gi + 2);
             }
-            lds_barrier_r();                                    // B: accumulator cleared, next table in place
+            if constexpr (!(T2P_RABL & 16)) lds_barrier_r();    // B: accumulator cleared, next table in place
         }
     }
     wait_all_vm();
+    uint32_t gbits = 0;
+    guard_track_bits(gbits, gtop);
     if (p.amax_out != nullptr && lane == 0 && gbits != 0u)
         atomicMax(p.amax_out, __float_as_uint(__uint_as_float(gbits) * p.out_scale));
 }

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256, 1) void k_sa_wide(SaParams p) {
     }
 
     for (int i = tid; i < NC * N; i += C::NT) acc_lds[i] = (int)0xFF800000;   // -inf
-    uint32_t gbits = 0;
+    int gtop = 0;         // fp16-range guard: this lane's maximum (bit pattern, before out_scale) of the drained outputs; reduced over
+                          // the wave once, at the end (six ds_bpermute round trips per drain otherwise)
     const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
 
     auto dma16 = [&](const void* base, uint32_t voff, uint32_t lds_off) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void k_sa_wide(SaParams p) {
         };
         auto flush = [&](int g) {
             float* o = p.out + (int64_t)g * NC * (int64_t)p.ldo;
-            int top = 0;
+            int top = gtop;
 #pragma unroll
             for (int k = 0; k < NC * N / 4 / C::NT; k++) {
                 const int i = tid + k * C::NT;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void k_sa_wide(SaParams p) {
                 *(f32x4*)(o + c * (int64_t)p.ldo + c4 * 4) = v;
                 *(i32x4*)a = i32x4{(int)0xFF800000, (int)0xFF800000, (int)0xFF800000, (int)0xFF800000};
             }
-            guard_track_bits(gbits, top);
+            gtop = top;
         };
         auto build_b = [&](int g) {
             const float* cp = (const float*)(lds + C::CPOS_OFF + (g & 1) * C::CPOS_BUF);
@@ -541,6 +542,8 @@ __global__ __launch_bounds__(256, 1) void k_sa_wide(SaParams p) {
     }
 #endif
     wait_all_vm_w();
+    uint32_t gbits = 0;
+    guard_track_bits(gbits, gtop);
     if (p.amax_out != nullptr && lane == 0 && gbits != 0u)
         atomicMax(p.amax_out, __float_as_uint(__uint_as_float(gbits) * p.out_scale));
 }

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
     }
 
     for (int i = tid; i < C::ACC_BUFS * C::ACC_INTS; i += NT) acc_lds[i] = 0;
-    uint32_t gbits = 0;  // fp16-range guard: wave-uniform maximum (bit pattern, before out_scale) of the drained outputs
+    int gtop = 0;        // fp16-range guard: this lane's maximum (bit pattern, before out_scale) of the drained outputs; reduced
+                         // over the wave once, at the end
 
     const int g_begin = p.bounds_ws[blockIdx.x], g_end = p.bounds_ws[blockIdx.x + 1];
     // first of this thread's ITERS staged rows inside a batch.  K = 32: a row is 8 lanes x 8 bytes, a ds_write_b64 is served in
@@ -325,16 +326,22 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         auto flush = [&](int64_t g, int abuf) {
             int* a = acc_lds + abuf * C::ACC_INTS;
             float* o = p.out + g * nc * (int64_t)p.ldo;
-            int top = 0;  // fp16-range guard: the object's largest output (bit patterns of non-negative floats order like ints)
-            for (int i = tid; i < nc * N; i += NT) {
-                const int c = i / N, col = i % N;
-                const int bits = a[i];
-                top = bits > top ? bits : top;
-                o[c * (int64_t)p.ldo + col] = __int_as_float(bits) * p.out_scale;  // weight image scale (power of 2)
-                a[i] = 0;
+            int top = gtop;  // fp16-range guard: the largest output (bit patterns of non-negative floats order like ints)
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            for (int i = tid; i < nc * (N / 4); i += NT) {      // 16 bytes per thread and trip
+                const int c = i / (N / 4), col = (i % (N / 4)) * 4;
+                const i32x4 bits = *(const i32x4*)(a + c * N + col);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    top = bits[e] > top ? bits[e] : top;
+                    v[e] = __int_as_float(bits[e]) * p.out_scale;  // weight image scale (power of 2)
+                }
+                *(f32x4*)(o + c * (int64_t)p.ldo + col) = v;
+                *(i32x4*)(a + c * N + col) = i32x4{0, 0, 0, 0};
             }
-            // the next dense kernel splits these rows to fp16: fold the magnitude into the wave's running maximum
-            guard_track_bits(gbits, top);
+            // (the next dense kernel splits these rows to fp16: the magnitude goes into the lane's running maximum)
+            gtop = top;
         };
 
         BatchIt it_c{0, 0, (int)nr[0], sbase[0]};
@@ -565,6 +572,8 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             if (flush_g1 >= 0) flush(flush_g1, flush_buf1);
         }
     }
+    uint32_t gbits = 0;
+    guard_track_bits(gbits, gtop);
     if (p.amax_out != nullptr && lane == 0 && gbits != 0u)
         atomicMax(p.amax_out, __float_as_uint(__uint_as_float(gbits) * p.out_scale));
 }
@@ -579,6 +588,7 @@ int launch_cfg2(const SaParams& p, hipStream_t st, const char* name) {
                           "ws_sa2: the LDS centroid table needs wp and n_cent = %d (got %d)", 8192 / K, p.n_cent);
     T2P_TRY(reserve_lds((const void*)kern, C::lds_bytes(), "ws_sa2"));
     if (p.n_obj <= 0) return 0;
+    T2P_CHECK_ARG(((uintptr_t)p.out & 15) == 0 && p.ldo % 4 == 0, "ws_sa2: output rows must be 16-byte aligned (ldo = %d)", p.ldo);
     T2P_CHECK_ARG(p.n_obj < (1 << 30) && p.n_obj * p.n_dense * (int64_t)K * 4 < 0xffffffffLL &&
                       p.n_obj * p.n_cent * (int64_t)K * 4 < 0xffffffffLL,
                   "ws_sa: chunk too large for 32-bit table offsets");
