@@ -22,6 +22,9 @@
 //     the MFMA block of batch t; their VALU part and the LDS write follow it; one barrier per batch.
 //   * Column slices of one row stream (GA: N = 1024 in slices of 128) are mapped to the same XCD (block b runs on
 //     XCD b % 8), so they share the stream's A rows through that XCD's L2.
+#ifndef T2P_GABL   // development only (results wrong): 1 = GA layer 1 stores into a 4 MB window (no HBM write traffic)
+#define T2P_GABL 0
+#endif
 #ifndef T2P_GA2_V1
 #define T2P_GA2_V1 0
 #endif
@@ -324,10 +327,17 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                             if constexpr (SPLIT_IO == 2) {  // hand the activations on already split into fp16 hi / lo
                                 const fp16x2 hv = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
                                 const fp16x2 lv = __builtin_amdgcn_cvt_pkrtz((v - (float)hv[0]) * 2048.f, 0.f);
+#if T2P_GABL & 1
+                                if (FULL || r < n_rows) {      // same instructions, 4 MB footprint: no HBM write traffic
+                                    ((__fp16*)p.out_hi + (o0 & 0xFFFFF))[rr * p.ldo] = hv[0];
+                                    ((__fp16*)p.out_lo + (o0 & 0xFFFFF))[rr * p.ldo] = lv[0];
+                                }
+#else
                                 if (FULL || r < n_rows) {
                                     ((__fp16*)p.out_hi + o0)[rr * p.ldo] = hv[0];
                                     ((__fp16*)p.out_lo + o0)[rr * p.ldo] = lv[0];
                                 }
+#endif
                             } else {
                                 if (FULL || r < n_rows) (p.out + o0)[rr * p.ldo] = v;
                             }
