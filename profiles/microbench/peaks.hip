@@ -1,6 +1,9 @@
 // On-box peaks that bench.py prints next to the nominal ones ("re-measure on the box and state the values used").
 //   t2p_peak_mfma_f16:  dense v_mfma_f32_32x32x16_f16 rate, every SIMD of the chip busy (4 waves per CU-SIMD, 8 independent
 //                       accumulators per wave), TFLOP/s
+//   t2p_peak_mfma_f16_random: the same loop with eight operand pairs of pseudo-random values that rotate from MFMA to MFMA: the
+//                       chip is power-limited under matrix load, and operands that never change (or are zero) toggle fewer wires
+//                       than real data, so the constant-operand figure above is the OPTIMISTIC peak
 //   t2p_peak_copy:      float4 copy of a buffer far larger than the 256 MB Infinity Cache, GB/s (read + written bytes)
 // Built by text2pos-cvpr2022_amd/build.py into profiles/microbench/libt2p_peaks.so; measurement code, not part of the product.
 #include <hip/hip_runtime.h>
@@ -29,6 +32,33 @@ __global__ __launch_bounds__(256) void k_mfma_peak(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+template <int SAME>
+__global__ __launch_bounds__(256) void k_mfma_peak_random(float* out, int iters) {
+    // four accumulators, four A and four B operands (~100 registers: four waves per SIMD stay resident, nothing spills)
+    half8 a[4], b[4];
+    uint32_t st = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x;
+    for (int i = 0; i < 4; i++)
+        for (int e = 0; e < 8; e++) {
+            st = st * 1664525u + 1013904223u;
+            a[i][e] = SAME ? (_Float16)(0.001f * (threadIdx.x + e)) : (_Float16)(((int)(st >> 9) & 0xFFFF) * (1.0f / 32768.f) - 1.0f);
+            st = st * 1664525u + 1013904223u;
+            b[i][e] = SAME ? (_Float16)(0.002f * (threadIdx.x % 7 + e)) : (_Float16)(((int)(st >> 9) & 0xFFFF) * (1.0f / 32768.f) - 1.0f);
+        }
+    f32x16 acc[4];
+    for (int i = 0; i < 4; i++)
+        for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+    for (int it = 0; it < iters; it += 2) {      // 16 MFMAs per trip = 2 x the 8 of the constant-operand loop
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + r) & 3], b[(i + 2 * r + 1) & 3], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; i++)
+        for (int e = 0; e < 16; e++) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 __global__ __launch_bounds__(256) void k_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n) {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -39,7 +69,14 @@ static double time_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
-extern "C" int t2p_peak_mfma_f16(double* tflops) {
+static int peak_mfma(double* tflops, int mode);
+extern "C" int t2p_peak_mfma_f16(double* tflops) { return peak_mfma(tflops, 0); }
+extern "C" int t2p_peak_mfma_f16_random(double* tflops) { return peak_mfma(tflops, 1); }
+// control: the rotating-register loop of the random variant with the constant values of the first (same instruction stream,
+// other data)
+extern "C" int t2p_peak_mfma_f16_rotating_constant(double* tflops) { return peak_mfma(tflops, 2); }
+static int peak_mfma(double* tflops, int mode) {
+    auto kern = mode == 1 ? k_mfma_peak_random<0> : (mode == 2 ? k_mfma_peak_random<1> : k_mfma_peak);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -49,11 +86,11 @@ extern "C" int t2p_peak_mfma_f16(double* tflops) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, out, 1000);   // warm-up
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1000);   // warm-up
     double best = 1e30;
     for (int r = 0; r < 3; r++) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, out, iters);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         const double ms = time_ms(e0, e1);
