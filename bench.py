@@ -176,10 +176,10 @@ def measured_peaks():
     rc3 = lib.t2p_peak_mfma_f16_random(ctypes.byref(tfr)) if hasattr(lib, "t2p_peak_mfma_f16_random") else 1
     return {"mfma_f16_tflops": tf.value if rc1 == 0 else None, "copy_gbps": gb.value if rc2 == 0 else None,
             "mfma_f16_tflops_random_operands": tfr.value if rc3 == 0 else None,
-            "note": "mfma_f16_tflops: one constant operand pair for every MFMA (the most a SIMD can do); "
-                    "mfma_f16_tflops_random_operands: four A and four B register quads of random values rotating over the MFMAs "
-                    "(-14 % for the changing source registers, -8 % for the changing bits: the chip is power-limited under "
-                    "matrix load); frac_of_measured_peak uses the first, higher figure",
+            "note": "mfma_f16_tflops: one constant operand pair for every MFMA; mfma_f16_tflops_random_operands: the same loop "
+                    "(8 accumulators per wave) on four A and four B register quads of random values rotating over the MFMAs: "
+                    "-10 % - the chip is power-limited under matrix load and changing bits cost power (rotating registers with "
+                    "constant values: no loss); frac_of_measured_peak uses the first, higher figure",
             "nominal_mfma_f16_tflops": F16_MFMA_PEAK_TFLOPS, "nominal_hbm_gbps": 8000.0,
             "source": "profiles/microbench/peaks.hip (32x32x16 f16 MFMA loop, 4 waves per SIMD; float4 copy, bytes read + written)"}
 

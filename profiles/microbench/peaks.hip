@@ -32,29 +32,30 @@ __global__ __launch_bounds__(256) void k_mfma_peak(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int SAME>
+// MODE 0: random values, 1: the constant values of k_mfma_peak, 2: one operand pair for all MFMAs (= k_mfma_peak when NACC = 8)
+template <int NACC, int MODE>
 __global__ __launch_bounds__(256) void k_mfma_peak_random(float* out, int iters) {
-    // four accumulators, four A and four B operands (~100 registers: four waves per SIMD stay resident, nothing spills)
     half8 a[4], b[4];
     uint32_t st = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x;
     for (int i = 0; i < 4; i++)
         for (int e = 0; e < 8; e++) {
             st = st * 1664525u + 1013904223u;
-            a[i][e] = SAME ? (_Float16)(0.001f * (threadIdx.x + e)) : (_Float16)(((int)(st >> 9) & 0xFFFF) * (1.0f / 32768.f) - 1.0f);
+            a[i][e] = MODE ? (_Float16)(0.001f * (threadIdx.x + e)) : (_Float16)(((int)(st >> 9) & 0xFFFF) * (1.0f / 32768.f) - 1.0f);
             st = st * 1664525u + 1013904223u;
-            b[i][e] = SAME ? (_Float16)(0.002f * (threadIdx.x % 7 + e)) : (_Float16)(((int)(st >> 9) & 0xFFFF) * (1.0f / 32768.f) - 1.0f);
+            b[i][e] = MODE ? (_Float16)(0.002f * (threadIdx.x % 7 + e)) : (_Float16)(((int)(st >> 9) & 0xFFFF) * (1.0f / 32768.f) - 1.0f);
         }
-    f32x16 acc[4];
-    for (int i = 0; i < 4; i++)
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; i++)
         for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
-    for (int it = 0; it < iters; it += 2) {      // 16 MFMAs per trip = 2 x the 8 of the constant-operand loop
+    for (int it = 0; it < iters; it += 2) {      // 16 MFMAs per trip = 2 x the 8 of k_mfma_peak
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 16 / NACC; r++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + r) & 3], b[(i + 2 * r + 1) & 3], acc[i], 0, 0, 0);
+            for (int i = 0; i < NACC; i++)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[MODE == 2 ? 0 : (i + r) & 3], b[MODE == 2 ? 0 : (i / 4 + i + 2 * r + 1) & 3], acc[i], 0, 0, 0);
     }
     float s = 0.f;
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NACC; i++)
         for (int e = 0; e < 16; e++) s += acc[i][e];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
@@ -75,8 +76,10 @@ extern "C" int t2p_peak_mfma_f16_random(double* tflops) { return peak_mfma(tflop
 // control: the rotating-register loop of the random variant with the constant values of the first (same instruction stream,
 // other data)
 extern "C" int t2p_peak_mfma_f16_rotating_constant(double* tflops) { return peak_mfma(tflops, 2); }
+// control of the control: the four-accumulator loop with ONE operand pair
+extern "C" int t2p_peak_mfma_f16_four_acc(double* tflops) { return peak_mfma(tflops, 3); }
 static int peak_mfma(double* tflops, int mode) {
-    auto kern = mode == 1 ? k_mfma_peak_random<0> : (mode == 2 ? k_mfma_peak_random<1> : k_mfma_peak);
+    auto kern = mode == 1 ? k_mfma_peak_random<8, 0> : (mode == 2 ? k_mfma_peak_random<8, 1> : (mode == 3 ? k_mfma_peak_random<4, 2> : k_mfma_peak));
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -131,5 +134,36 @@ extern "C" int t2p_peak_copy(double* gbps) {
     hipEventDestroy(e1);
     hipFree(src);
     hipFree(dst);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// MFMA rate against the number of INDEPENDENT accumulator chains per wave and the waves per SIMD (one constant operand pair):
+// mode = NACC in {1, 2, 4, 8}, waves_per_simd = workgroups of 256 threads per CU
+extern "C" int t2p_peak_mfma_chains(int nacc, int waves_per_simd, double* tflops) {
+    auto kern = nacc == 1 ? k_mfma_peak_random<1, 2> : nacc == 2 ? k_mfma_peak_random<2, 2> : nacc == 4 ? k_mfma_peak_random<4, 2> : k_mfma_peak_random<8, 2>;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int blocks = cus * waves_per_simd, iters = 20000;
+    float* out = nullptr;
+    if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess) return 2;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1000);
+    double best = 1e30;
+    for (int r = 0; r < 3; r++) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        const double ms = time_ms(e0, e1);
+        best = ms < best ? ms : best;
+    }
+    const double flop = (double)blocks * 4 * iters * 8 * (2.0 * 32 * 32 * 16);
+    *tflops = flop / (best * 1e-3) / 1e12;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(out);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
