@@ -22,6 +22,9 @@
 #ifndef T2P_ABL
 #define T2P_ABL 0
 #endif
+#ifndef T2P_DEFER256   // deferred atomics at K = 256 too (the float-max form freed the bias block's registers)
+#define T2P_DEFER256 1
+#endif
 #ifndef T2P_SA1_SWIZ   // 0: K = 32 stages its rows in plain order (A/B of the bank-conflict fix)
 #define T2P_SA1_SWIZ 1
 #endif
@@ -68,11 +71,15 @@ struct Cfg2 {
     static_assert(!BL || K == N, "the staged rows address the centroid table with the accumulator's byte offsets");
     static constexpr size_t lds_bytes() {
         return (size_t)2 * 2 * PLANE * 2 + (size_t)ACC_BUFS * ACC_INTS * 4 + 4 * TR * 2 + kSub * 2 + kSub * 4 +
-               (size_t)BT_FLOATS * 4;
+               (size_t)BT_FLOATS * 4 + (size_t)N * 4;
     }
 };
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+// float max into LDS without a return value (ds_max_f32; a builtin, so that hipcc places the MFMA -> LDS-data wait states itself)
+__device__ __forceinline__ void lds_fmax(float* p, float v) {
+    (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 #if T2P_TRACE
 #define STAMP(i)                                                                                           \
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
     float* btab = (float*)(sbase + kSub);                       // BL: [n_cent + 1][K] centroid table of the current object
     float* wpl = btab + 8192 + K;                               // BL: [3][K] position rows of the layer-1 weights
     float* cposl = wpl + 3 * K;                                 // BL: [n_cent][3] centroid positions of the object being built
+    float* biasl = (float*)((char*)lds + C::lds_bytes()) - N;   // [N] bias (pre-multiplied by the weight scale), for the drain
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN, h = lane >> 5, l31 = lane & 31;
@@ -154,15 +162,12 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
                 w_lo[nt][s] = __builtin_bit_cast(half8, b);
             }
     }
-    f32x16 biasv[C::NTW];  // bias (pre-multiplied by the weight scale) broadcast over the 16 rows of a lane: the C operand
-#pragma unroll              // of every batch's first MFMA, so the accumulator needs no per-batch initialisation
-    for (int nt = 0; nt < C::NTW; nt++) {
-        const float bv = p.bias[wn * C::NTW * 32 + nt * 32 + l31];
-#pragma unroll
-        for (int e = 0; e < 16; e++) biasv[nt][e] = bv;
-    }
-
-    for (int i = tid; i < C::ACC_BUFS * C::ACC_INTS; i += NT) acc_lds[i] = 0;
+    // The bias is NOT part of the accumulation (sa_rows.hip's form): a batch's first MFMA starts from a literal 0, the LDS accumulator
+    // takes a FLOAT max of the raw products from a -inf start, and the drain forms relu(max + bias).  A bias block as the first
+    // MFMA's C operand costs 16 registers per column tile - the registers the deferred atomics need at K = 256.
+    constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < N; i += NT) biasl[i] = p.bias[i];
+    for (int i = tid; i < C::ACC_BUFS * C::ACC_INTS; i += NT) acc_lds[i] = (int)0xFF800000;   // -inf
     int gtop = 0;        // fp16-range guard: this lane's maximum (bit pattern, before out_scale) of the drained outputs; reduced
                          // over the wave once, at the end
 
@@ -330,15 +335,18 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             typedef int i32x4 __attribute__((ext_vector_type(4)));
             for (int i = tid; i < nc * (N / 4); i += NT) {      // 16 bytes per thread and trip
                 const int c = i / (N / 4), col = (i % (N / 4)) * 4;
-                const i32x4 bits = *(const i32x4*)(a + c * N + col);
+                const f32x4 raw = *(const f32x4*)(a + c * N + col);
+                const f32x4 bq = *(const f32x4*)(biasl + col);
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    top = bits[e] > top ? bits[e] : top;
-                    v[e] = __int_as_float(bits[e]) * p.out_scale;  // weight image scale (power of 2)
+                    const float r = fmaxf(raw[e] + bq[e], 0.f);     // (a centroid without rows stays at -inf: 0)
+                    const int bits = __float_as_int(r);
+                    top = bits > top ? bits : top;
+                    v[e] = r * p.out_scale;  // weight image scale (power of 2)
                 }
                 *(f32x4*)(o + c * (int64_t)p.ldo + col) = v;
-                *(i32x4*)(a + c * N + col) = i32x4{0, 0, 0, 0};
+                *(i32x4*)(a + c * N + col) = i32x4{(int)0xFF800000, (int)0xFF800000, (int)0xFF800000, (int)0xFF800000};
             }
             // (the next dense kernel splits these rows to fp16: the magnitude goes into the lane's running maximum)
             gtop = top;
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         (void)trace_n;
         // DEFER (K <= 128, registers to spare): the atomics of batch t-1 ride between the MFMAs of batch t, fed from a
         // copy of its results; one more batch passes before a finished object may be flushed.
-        constexpr bool DEFER = K <= 128;
+        constexpr bool DEFER = K <= 128 || T2P_DEFER256;
         // PINGPONG (= DEFER): two result arrays that swap roles from batch to batch - the MFMAs of batch t write one while the
         // atomics of batch t-1 read the other, the batch loop is unrolled by two - instead of one array and a 16-register copy
         // per batch (which also put an s_nop 11 behind the last MFMA): SA2 -2..3 %, SA1 -5 %.
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++)
 #pragma unroll
-                    for (int e = 0; e < 16; e++) rr[0][rt][nt][e] = rr[HALVES - 1][rt][nt][e] = 0.f;
+                    for (int e = 0; e < 16; e++) rr[0][rt][nt][e] = rr[HALVES - 1][rt][nt][e] = -__builtin_inff();   // (a no-op maximum)
         }
         // atomics e0 .. e1-1 (flattened over row tile, column tile, accumulator register) of a finished batch
         auto atomics = [&](const f32x16 (&v)[DEFER ? RT : 1][DEFER ? C::NTW : 1], const uint2 (&four)[RT][4], int abuf,
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
                 const int rt = idx / (C::NTW * 16), nt = (idx / 16) % C::NTW, e = idx % 16;
                 const uint32_t pair = (e & 2) ? four[rt][e >> 2].y : four[rt][e >> 2].x;
                 const uint32_t off = (e & 1) ? (pair >> 16) : (pair & 0xFFFFu);
-                atomicMax((int*)((char*)(accb + wn * C::NTW * 32 + nt * 32 + l31) + off), __float_as_int(v[rt][nt][e]));
+                lds_fmax((float*)((char*)(accb + wn * C::NTW * 32 + nt * 32 + l31) + off), v[rt][nt][e]);
             }
         };
         int t_end = 0;
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
                                                 // staging work (measured: -2 % at K = 256; on the third MFMA too: 0)
 #pragma unroll
                 for (int nt = 0; nt < C::NTW; nt++) {
-                    acc[rt][nt] = MFMA16(a_hi, w_hi[nt][s], s == 0 ? biasv[nt] : acc[rt][nt]);
+                    acc[rt][nt] = MFMA16(a_hi, w_hi[nt][s], s == 0 ? kZero16 : acc[rt][nt]);
                     acc[rt][nt] = MFMA16(a_hi, w_lo[nt][s], acc[rt][nt]);
                 }
                 __builtin_amdgcn_s_setprio(0);
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             } else {
                 STAMP(4);
                 load_four();
-                // max-aggregation: integer atomic max into the object's LDS accumulator (the max against +0 is the ReLU)
+                // max-aggregation: float atomic max into the object's LDS accumulator (bias + ReLU at the drain)
                 int* accb = acc_lds + abuf * C::ACC_INTS;
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
 #pragma unroll
                             for (int e = 0; e < 16; e++) {
                                 const uint32_t pair = (e & 2) ? four[rt][e >> 2].y : four[rt][e >> 2].x;
-                                atomicMax((int*)(col + ((e & 1) ? (pair >> 16) : (pair & 0xFFFFu))), __float_as_int(acc[rt][nt][e]));
+                                lds_fmax((float*)(col + ((e & 1) ? (pair >> 16) : (pair & 0xFFFFu))), acc[rt][nt][e]);
                             }
                         }
                     }
