@@ -29,13 +29,14 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 17
+#define T2P_ABI_VERSION 18
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
                                            one chunk: ~0.6 MB per object, i.e. ~38 GB at the default chunk for a batch that
                                            fills it (t2p_encode_cells_workspace_bytes gives the exact figure; a second
                                            stream's call needs its own workspace) */
+#define T2P_TUNING_MASK 0xF              /* t2p_cell_config.tuning: the bits that select a built plan */
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -186,11 +187,7 @@ typedef struct t2p_cell_config {
      *   bit 3: f16x3 only: SA level 1 on the column-slice kernel of ws_sa2.hip (default: sa_points.hip: independent waves,
      *          each owning a group of 16 centroids of an object with a private LDS accumulator; BOTH layers per edge from the
      *          object's points staged in LDS - no point table A_1, no row gathers)
-     *   bit 4: f16x3 only: SA level 3 on sa_wide.hip (four waves of 64 columns on one SIMD each, every wave converting its own
-     *          k-quarter of the tile's rows; measured SLOWER than the default column-slice kernel of ws_sa2.hip - kept as the
-     *          measured form of that design, docs/notebook.md; ignored with bit 1)
-     *   bit 5: f16x3 only: SA level 1 on sa_groups.hip (the same wave organisation, layer 1 split algebraically: rows of the
-     *          point table A_1 gathered per edge by LDS-DMA; round 3's first form, ~1.1 ms slower + 1.0 ms of table writes) */
+     * Bits outside T2P_TUNING_MASK are refused (T2P_E_ARG). */
     int32_t tuning;
 } t2p_cell_config;
 

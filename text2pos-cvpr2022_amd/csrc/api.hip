@@ -206,6 +206,7 @@ int check_cfg(const t2p_cell_config* cfg) {
     T2P_CHECK_ARG(cfg->knn_k >= 1 && cfg->knn_k <= 32, "encode_cells: knn_k=%d outside [1,32]", cfg->knn_k);
     T2P_CHECK_ARG(cfg->precision == 0 || cfg->precision == 1, "encode_cells: precision=%d (0 = fp32, 1 = f16x3)",
                   cfg->precision);
+    T2P_CHECK_ARG((cfg->tuning & ~T2P_TUNING_MASK) == 0, "encode_cells: tuning=%#x has bits outside %#x", cfg->tuning, T2P_TUNING_MASK);
     // 32-bit byte offsets into the per-chunk tables (n_obj * 128 points * 128 floats * 4 B < 2^32) and 16-bit object-local
     // indices cap a chunk at 65,535 objects; checked here, not deep inside a kernel launcher
     T2P_CHECK_ARG(cfg->chunk_objects >= 0 && cfg->chunk_objects <= T2P_MAX_CHUNK_OBJECTS,
@@ -245,11 +246,10 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     // f16x3: the SA kernels of levels 1 and 2 build their centroid tables in LDS (ws_sa2.hip, BL); the HBM tables B_2 / B_3
     // are then neither written nor read.  The fp32 kernels (ws_sa.hip) gather all three from HBM.
     const bool lds_btab = cfg.precision == 1 && !(cfg.tuning & 2);
-    // ... and level 0 runs on the centroid-group kernel (sa_groups.hip), which builds its tables per group as well
     const bool lds_btab0 = lds_btab && !(cfg.tuning & 8);
-    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0) | ((cfg.tuning & 16) ? 4 : 0) | ((cfg.tuning & 32) ? 8 : 0);
-    // ... by default on sa_points.hip, which computes layer 1 per edge from the points themselves: no point table A_1 either
-    const bool sa1_points = lds_btab0 && !(cfg.tuning & 32) && cfg.n_pts == 256;
+    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0);
+    // level 0 runs on sa_points.hip, which computes layer 1 per edge from the points themselves: no point table A_1 either
+    const bool sa1_points = lds_btab0 && cfg.n_pts == 256;
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st, guard));
     // models/object_encoder.py:86: the PointNet++ only runs when the "class" feature does not come from class_embedding
     const bool run_pointnet = cfg.use_class && !cfg.class_embed;

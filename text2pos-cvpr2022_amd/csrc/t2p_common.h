@@ -245,26 +245,17 @@ struct SaParams {
     int balanced;            // 1: bounds_ws was filled by launch_sa_balance_levels for this level's launch shape
     uint32_t* amax_out;      // f16x3 guard (nullable): largest output magnitude (the next dense kernel splits these rows)
     int plan;                // bit 0: SA level 2 stays on the column-slice kernel (ws_sa2.hip) instead of the row-owning one (sa_rows.hip);
-                             // bit 1: SA level 1 stays on it instead of the centroid-group kernel (sa_groups.hip); bit 2: SA level 3 moves from it
-                             // to sa_wide.hip (opt-in: measured slower); bit 3: SA level 1 on sa_groups.hip (gathered point table) instead of sa_points.hip
+                             // bit 1: SA level 1 stays on it instead of sa_points.hip
 };
 int launch_ws_sa(int H, int C, const SaParams& p, hipStream_t st);
 // sa_rows.hip: row-owning f16x3 kernel of SA level 2 (H = C = 128, LDS centroid table): true when launch_ws_sa routes p there
 bool sa_rows_selected(int H, int C, const SaParams& p);
 int launch_sa_rows(int H, int C, const SaParams& p, hipStream_t st);
 int sa_rows_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
-// sa_groups.hip: independent waves over centroid groups, f16x3 kernel of SA level 1 (H = 32, C = 64; needs wp)
-bool sa_groups_selected(int H, int C, const SaParams& p);
-int launch_sa_groups(int H, int C, const SaParams& p, hipStream_t st);
-int sa_groups_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
 // sa_points.hip: both layers per edge from the object's points in LDS, f16x3 kernel of SA level 1 (needs wp, w1, b1, feat_src)
 bool sa_points_selected(int H, int C, const SaParams& p);
 int launch_sa_points(int H, int C, const SaParams& p, hipStream_t st);
 int sa_points_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
-// sa_wide.hip: k-split conversion / column-split product, f16x3 kernel of SA level 3 (H = C = 256; needs wp)
-bool sa_wide_selected(int H, int C, const SaParams& p);
-int launch_sa_wide(int H, int C, const SaParams& p, hipStream_t st);
-int sa_wide_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
 // One launch that balances all three levels (their row counts are known once k_sample_group has run); fills
 // prefix_ws / bounds_ws of every p[l] for the launch shape launch_ws_sa(H[l], C[l], p[l]) will use.
 int launch_sa_balance_levels(const SaParams p[3], const int H[3], const int C[3], hipStream_t st);
