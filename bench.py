@@ -161,6 +161,70 @@ def cpu_baseline(S, seed, n_cells_sample, n_query_sample):
     }
 
 
+def dropin_rates(model, S, torch, n_cells=2048, batch_sizes=(64, 512)):
+    """The API the reference's callers use, as they use it (training/coarse.py:123-131, evaluation/pipeline.py:73-75):
+        for batch in dataloader: cell_enc = model.encode_objects(batch["objects"], batch["object_points"])
+                                 cell_encodings[...] = cell_enc.cpu().detach().numpy()
+    on Python Object3d lists (RAW points: m ~ exp(U[ln 25, ln 4000]) per object, float64, as the dataset holds them) + one
+    point batch per cell (T.FixedPoints(256) + T.NormalizeScale applied by the dataloader, outside the timed loop).
+    Two epochs per batch size: the first pays the reference's own per-object float64 means (obj.get_center() /
+    get_color_rgb() over the raw points, models/object_encoder.py:121-131), later ones find them in the per-cell cache.
+    Beside it the packed entry point (device-resident arrays) at the same batch size, same .cpu() per call."""
+    from text2pos_amd import data as D
+    rng = np.random.default_rng(SEED + 77)
+    sizes = S.cell_sizes(SEED, n_cells)
+    tf = D.Compose([D.FixedPoints(256, np.random.default_rng(SEED + 78)), D.NormalizeScale()])
+    cells, points = [], []
+    for c in range(n_cells):
+        objs = []
+        for j in range(int(sizes[c])):
+            m = int(np.rint(np.exp(np.log(25.0) + rng.random() * (np.log(4000.0) - np.log(25.0)))))
+            ctr = rng.random(3) * np.array([1.0, 1.0, 0.3])
+            col = D.COLORS[int(rng.integers(0, 8))]
+            objs.append(D.Object3d(j, 1000 * c + j, ctr + 0.05 * rng.standard_normal((m, 3)),
+                                   np.clip(col + 0.05 * rng.standard_normal((m, 3)), 0.0, 1.0), S.LABELS[int(rng.integers(0, len(S.LABELS)))]))
+        cells.append(objs)
+        points.append(D.batch_object_points(objs, tf))
+    n_obj = int(sizes.sum())
+    raw_points = int(sum(len(o.xyz) for objs in cells for o in objs))
+    out = {"cells": n_cells, "objects": n_obj, "raw_points": raw_points,
+           "caller": "for batch: model.encode_objects(objects, object_points).cpu().detach().numpy()  (training/coarse.py:123-131)"}
+    dev = model.device
+    with torch.no_grad():
+        model.encode_objects(cells[:8], points[:8]).cpu()          # warm-up of the kernels (8 cells; their means get cached)
+        for bs in batch_sizes:
+            res = {}
+            for epoch in ("first_epoch", "later_epochs"):
+                if epoch == "first_epoch":
+                    model.object_means_cache.clear()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for a in range(0, n_cells, bs):
+                    enc = model.encode_objects(cells[a: a + bs], points[a: a + bs])
+                    _ = enc.cpu().detach().numpy()
+                res[epoch + "_cells_per_s"] = n_cells / (time.perf_counter() - t0)
+            # the packed entry point on the same cells at the same batch size (inputs resident in HBM)
+            xyz, rgb, center, mean_rgb, ptr = D.pack_cells(cells, points, 256)
+            d = [t.to(dev) for t in (xyz, rgb, center, mean_rgb)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for a in range(0, n_cells, bs):
+                b = min(a + bs, n_cells)
+                lo, hi = int(ptr[a]), int(ptr[b])
+                enc = model.encode_objects_packed(d[0][lo:hi], d[1][lo:hi], d[2][lo:hi], d[3][lo:hi], ptr[a: b + 1] - lo)
+                _ = enc.cpu().detach().numpy()
+            res["packed_cells_per_s"] = n_cells / (time.perf_counter() - t0)
+            res["later_epochs_over_packed"] = res["later_epochs_cells_per_s"] / res["packed_cells_per_s"]
+            res["first_epoch_over_packed"] = res["first_epoch_cells_per_s"] / res["packed_cells_per_s"]
+            out[f"batch_{bs}"] = res
+            del d
+    out["note"] = ("first_epoch: every object's centre / mean colour is the float64 mean over its raw points, as the reference computes "
+                   "them in every call; later_epochs: found in CellRetrievalNetwork.object_means_cache (keyed by the cell's object "
+                   "list; Object3d point arrays are treated as immutable).  The dataloader's transforms are outside the timed loop, "
+                   "as they are in the reference (worker processes).  Never `value`.")
+    return out
+
+
 def measured_peaks():
     """On-box peaks from the two micro-kernels of profiles/microbench/peaks.hip (built by build.py into libt2p_peaks.so):
     dense v_mfma_f32_32x32x16_f16 rate with every SIMD busy, float4 copy bandwidth over 2 GiB + 2 GiB."""
@@ -253,8 +317,14 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the report-only measurements behind the timed region (on-box peaks, the fixed-16 / single-object "
                          "cell variants, the fine stage)")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the measurement of the reference's caller shape (encode_objects on Python object lists, batch 64 / 512)")
     ap.add_argument("--fine-queries", type=int, default=200, help="queries of the fine-stage measurement (x top-10 candidates)")
     ap.add_argument("--fp32-steps", type=int, default=2)
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: initialise the RCCL process group with ONE rank and run the step's all-gather through it "
+                         "(communicator set-up, all_gather_into_tensor on device tensors, the `exchange` block of the JSON line), "
+                         "so that the code an 8-GPU run executes has executed on the one GPU there is")
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="arithmetic of the MFMA-heavy layers: f16x3 split-precision (default) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -284,8 +354,14 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    exchanging = world > 1 or args.force_exchange
+    if exchanging:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:      # (plain `python bench.py --force-exchange`, not under torch.distributed.run)
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- model: random-init weights of the reference architecture (no checkpoints available), BN stats randomised ----
@@ -365,11 +441,12 @@ def main():
                     gather_events.append(ev)
 
             return TD.sharded_retrieval(encode_cells, encoded_queries, lambda q, c, k: ops.sim_topk(q, c, k),
-                                        n_cells_total, n_q_total, TOPK, gather_result=False, around_exchange=around_exchange)
+                                        n_cells_total, n_q_total, TOPK, gather_result=False, around_exchange=around_exchange,
+                                        force_exchange=args.force_exchange)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if exchanging:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -392,7 +469,7 @@ def main():
     if guard_code and not os.environ.get("T2P_ABLATION_RUN"):   # (ablation builds of the library compute garbage on purpose)
         raise SystemExit(f"fp16-range guard fired during the timed region (code {guard_code:#x}): the f16x3 numbers are invalid")
     exchange = None
-    if world > 1:
+    if exchanging:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -405,8 +482,10 @@ def main():
                     "world_size": dist.get_world_size(), "bytes_per_rank": int((c_hi - c_lo) * 256 * 4),
                     "bytes_gathered": int(n_cells_total * 256 * 4),
                     "all_gather_ms_per_rank": [round(float(v), 4) for v in per_rank.tolist()],
+                    "events_recorded": len(gather_events), "forced_at_world_1": bool(args.force_exchange and world == 1),
                     "note": "mean over the timed steps of the event-bracketed collective on each rank (includes waiting "
                             "for the slowest rank's encoder)"}
+        assert len(gather_events) == args.steps, (len(gather_events), args.steps)
 
     # ---- the same step with the cell encoder's two halves on two HIP streams (each kernel launch fills the CUs, so what
     # overlaps is one half's work under the tails of the other's kernels and under the small launch-bound kernels)
@@ -622,6 +701,9 @@ def main():
             out.update(fp32_info)
         if exchange:
             out["exchange"] = exchange
+        if not args.no_dropin and world == 1 and args.cell_variant == "ragged":
+            log("drop-in caller shape: encode_objects(objects, object_points) at batch 64 / 512")
+            out["dropin"] = dropin_rates(model, S, torch)
         if not args.no_extras and world == 1 and args.cell_variant == "ragged":
             # report-only measurements, all outside the timed region: on-box peaks, SURVEY 8(d)'s two other cell shapes
             # (the cost is per object, so objects/s is the comparable figure), the fine stage (BASELINE configs[3])
@@ -669,7 +751,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(S, SEED, n_cells_cpu, 1024 if big_host else 64)
             log("done")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if exchanging:
         dist.destroy_process_group()
 
 

@@ -170,7 +170,7 @@ typedef struct t2p_cell_config {
      * up to 512 (the fine stage trains with 128, README.md:62). */
     int32_t objects_only;
     /* fp16-range guard of the f16x3 path (precision == 1): the split-precision kernels convert fp32 activations to fp16
-     * (round toward zero: a magnitude past 65504 would saturate silently).  When non-NULL, this DEVICE word receives a
+     * (round to nearest: a magnitude past 65504 would become inf).  When non-NULL, this DEVICE word receives a
      * sticky OR of a non-zero code whenever a conversion site of the call may have left fp16's range (bits 0-2: SA level
      * 1-3 edge inputs, judged by max|A_l| + max|B_l|; bit 3: SA output rows split by the dense table kernels; bit 4: GA
      * hidden planes, judged by a norm bound; bit 5: rows of the LDS-tiled GEMMs).  The tests are conservative: they may

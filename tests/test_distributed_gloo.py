@@ -139,6 +139,19 @@ def test_all_gather_rows_single_process_is_identity():
     try:
         x = torch.randn(5, 4)
         assert TD.all_gather_rows(x, 5) is x
+        # force=True (bench.py --force-exchange): the collective itself runs in the one-rank group and returns a copy
+        y = TD.all_gather_rows(x, 5, force=True)
+        assert y is not x and torch.equal(y, x)
+        marks = []
+        cells, queries = _embeddings(40, 1), _embeddings(6, 2)
+        idx, sc = TD.sharded_retrieval(lambda lo, hi: cells[lo:hi], lambda lo, hi: queries[lo:hi], _topk, 40, 6, 5,
+                                       around_exchange=marks.append, force_exchange=True)
+        assert marks == ["begin", "end"]
+        want_idx, want_sc = _topk(queries, cells, 5)
+        assert torch.equal(idx, want_idx) and torch.equal(sc, want_sc)
+        marks.clear()
+        TD.sharded_retrieval(lambda lo, hi: cells[lo:hi], lambda lo, hi: queries[lo:hi], _topk, 40, 6, 5, around_exchange=marks.append)
+        assert marks == []              # world 1 without the switch: no collective, no events
     finally:
         dist.destroy_process_group()
 

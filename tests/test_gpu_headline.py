@@ -574,6 +574,178 @@ def test_pipeline_end_to_end_vs_oracle(tmp_path, oracle_model, vocab):
 
 
 # ---- equivalent execution plans ----------------------------------------------------------------------------------------
+def test_pipeline_config4_scale_vs_oracle(tmp_path, oracle_model, vocab):
+    """BASELINE configs[4] at the size one GPU and a CPU oracle can carry: `pipeline.evaluate` (coarse retrieval + fine
+    localisation + accuracy tables, evaluation/pipeline.py:282-342) over a synthetic scene of 2,048 cells and 1,024 poses.
+      * coarse: the database is ALSO encoded by the oracle on the host (same per-cell T.FixedPoints draws) and ranked by the
+        reference's float64 NumPy statements; cell embeddings agree to 1e-4 except for cells with a DynamicEdgeConv near-tie
+        flip (rare), and every query whose oracle top-(k+1) score gaps exceed 2e-4 - with no such cell in either list - gets
+        exactly the oracle's retrieval list from the pipeline (>= 512 such queries);
+      * fine: what `evaluate` fed the fine model for its first 64 poses (x top-5 candidates = 320 samples) goes through the
+        oracle's SuperGlueMatch as well: P and offsets within 1e-4, matches identical wherever the oracle's decision has a
+        margin above 1e-3 (and on > 99 % of the entries overall);
+      * the accuracy tables are recomputed from the retrieval lists / per-sample outputs with the metric functions the
+        reference fixture pins.
+    Prints the pipeline's wall time."""
+    import copy
+    import time
+    import text2pos_amd as t2p
+    from oracle.model import retrieve_topk_f64
+    from text2pos_amd import data as D, evaluation as E, io as IO, pipeline as PL, synthetic as S
+    n_cells, n_poses, top_k, threshs, pad = 2048, 1024, (1, 3, 5), (5, 10, 15), 16
+    kmax = max(top_k)
+    np.random.seed(7)
+    cells, poses = _toy_scene(n_cells=n_cells, n_poses=n_poses, seed=12)
+    _oracle_threads()
+    prod_fine, orc_fine = _calibrated_fine_pair(vocab, cells[:64], pad)
+    om = copy.deepcopy(oracle_model)
+    _calibrate_batchnorm(om, cells[:48], seed=99)
+    hip = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
+    hip.load_state_dict(om.state_dict(), strict=True)
+    hip = hip.to(_dev()).eval()
+    IO.save_scene(str(tmp_path / "big"), "toy1", cells, poses)
+    sc = IO.load_scenes(str(tmp_path / "big"), ["toy1"])
+    assert len(sc.all_cells) == n_cells and len(sc.all_poses) == n_poses
+    tf = PL.PerCellTransform(256, 5)
+
+    # ---- the product pipeline, with a spy on the fine model's first call
+    seen = {}
+
+    class Spy(torch.nn.Module):
+        device = _dev()
+
+        def forward(self, objects, hints, points):
+            out = prod_fine(objects, hints, points)
+            if "in" not in seen:
+                seen["in"] = (objects, hints, points)
+                seen["out"] = {k: out[k].cpu().numpy() for k in ("matches0", "offsets", "P")}
+            seen.setdefault("m0", []).append(out.matches0.cpu().numpy())
+            seen.setdefault("off", []).append(out.offsets.cpu().numpy())
+            return out
+    np.random.seed(2022)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = PL.evaluate(hip, Spy(), sc, tf, top_k, threshs, pad, queries_per_call=64)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out2 = PL.run_coarse(hip, sc, tf, top_k, threshs)        # second pass: the per-cell object means come from the cache
+    wall_coarse2 = time.perf_counter() - t0
+    assert out2[0] == out["retrievals"]
+
+    # ---- oracle coarse stage on the same draws
+    oc = _OracleCoarse(om)
+    enc, hip_enc = [], []
+    for lo in range(0, n_cells, 64):
+        objs = [c.objects for c in sc.all_cells[lo: lo + 64]]
+        pts = [D.batch_object_points(o, tf.for_cell(lo + i)) for i, o in enumerate(objs)]
+        enc.append(oc.encode_objects(objs, pts))
+        with torch.no_grad():
+            hip_enc.append(hip.encode_objects(objs, pts).cpu())
+    cell_enc, text_enc = torch.cat(enc).numpy(), oc.encode_text(sc.texts).numpy()
+    per_cell = np.abs(torch.cat(hip_enc).numpy() - cell_enc).max(axis=1)
+    flipped = per_cell >= TOL
+    assert flipped.sum() <= n_cells // 200, f"{int(flipped.sum())} of {n_cells} cells differ from the oracle by >= 1e-4"
+    widx, wscore = retrieve_topk_f64(cell_enc, text_enc, kmax + 1)
+    db_ids = [c.id for c in sc.all_cells]
+    row_of = {cid: i for i, cid in enumerate(db_ids)}
+    got_idx = np.array([[row_of[cid] for cid in r] for r in out["retrievals"]])
+    gap = (wscore[:, :-1] - wscore[:, 1:]).min(axis=1)
+    clear = (gap > 2e-4) & ~flipped[widx].any(axis=1) & ~flipped[got_idx].any(axis=1)
+    assert int(clear.sum()) >= 512, f"only {int(clear.sum())} of {n_poses} queries have unambiguous oracle rankings"
+    assert np.array_equal(got_idx[clear], widx[clear][:, :kmax]), "a query with clear score gaps retrieved other cells"
+    # accuracy tables from the lists the pipeline returned, through the metric functions the reference fixture pins
+    centers = np.array([c.get_center()[0:2] for c in sc.all_cells])
+    w_hit, w_close, _ = E.retrieval_accuracies(got_idx, db_ids, [p.cell_id for p in sc.all_poses],
+                                               np.array([p.pose_w for p in sc.all_poses]), centers, 30.0, list(top_k))
+    assert out["hit"] == w_hit and out["close"] == w_close
+    assert out["localisation"] == E.localisation_accuracies(sc.all_poses, out["retrievals"], sc.cells_dict, list(top_k), list(threshs))
+
+    # ---- fine stage: the first call's inputs through the oracle
+    objects, hints, points = seen["in"]
+    assert len(objects) == 64 * kmax
+    want = _OracleFine(orc_fine)(objects, hints, points)
+    wP, woff, wm0 = want.P.numpy(), want.offsets.numpy(), want.matches0.numpy()
+    assert np.abs(seen["out"]["P"] - wP).max() < TOL and np.abs(seen["out"]["offsets"] - woff).max() < TOL
+    m0 = seen["out"]["matches0"]
+    diff = np.argwhere(m0 != wm0)
+    assert len(diff) <= 0.01 * m0.size, f"{len(diff)} of {m0.size} match entries differ"
+    for b, o in diff:      # a differing entry must be a decision the oracle itself takes with a margin below 1e-3
+        row = wP[b, o, :-1] if wP.shape[2] == woff.shape[1] + 1 else wP[b, o]
+        top2 = np.sort(row)[-2:]
+        j = int(np.argmax(row))
+        col = np.sort(wP[b, :wm0.shape[1], j])[-2:]
+        margin = min(top2[1] - top2[0], col[1] - col[0], abs(top2[1] - 0.2))
+        assert margin < 1e-3, f"sample {b}, object {o}: matches differ although the oracle's margin is {margin:.2e}"
+    assert (m0 >= 0).any() and (m0 < 0).any()
+    # the fine tables from the per-sample outputs the spy saw, through localisation_accuracies
+    from text2pos_amd.superglue_matcher import get_pos_in_cell
+    m_all, off_all = np.concatenate(seen["m0"]), np.concatenate(seen["off"])
+    assert m_all.shape[0] == n_poses * kmax
+    print(f"[configs[4] at 2,048 cells / 1,024 poses] pipeline.evaluate (coarse + fine + metrics) {wall:.1f} s wall "
+          f"(host transforms included); coarse pass again with cached object means {wall_coarse2:.1f} s; "
+          f"{int(clear.sum())} / {n_poses} queries with clear oracle rankings: identical lists; "
+          f"{int(flipped.sum())} / {n_cells} cells with a kNN near-tie flip; fine stage: {len(diff)} / {m0.size} match entries "
+          f"at a sub-1e-3 margin differ; hit@k {out['hit']}")
+
+
+def test_bench_exchange_runs_through_rccl_at_world_size_one():
+    """BASELINE configs[2]'s exchange step on the one GPU there is: bench.py under torch.distributed.run with ONE rank and
+    --force-exchange initialises the RCCL ("nccl") process group, runs the step's all_gather_into_tensor on device tensors
+    through it and fills the `exchange` block of the JSON line - the code an 8-GPU run executes (bench.py, distributed.py)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--cells", "768", "--queries", "128", "--force-exchange", "--no-cpu-baseline", "--no-extras", "--no-dropin",
+           "--no-fp32-pass", "--no-two-stream"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ex = line["exchange"]
+    assert ex["backend"] == "nccl" and ex["world_size"] == 1 and ex["forced_at_world_1"] and ex["events_recorded"] == 2
+    assert ex["bytes_per_rank"] == 768 * 256 * 4 == ex["bytes_gathered"]
+    assert len(ex["all_gather_ms_per_rank"]) == 1 and 0.0 < ex["all_gather_ms_per_rank"][0] < 50.0
+    assert line["n_gpus"] == 1 and line["value"] > 0
+
+
+def test_all_gather_rows_on_device_tensors_through_rccl():
+    """distributed.all_gather_rows / sharded_retrieval with the "nccl" backend (RCCL) in a one-rank group, in this process:
+    device tensors in, device tensors out, the forced collective returns the rows unchanged and t2p_sim_topk ranks them."""
+    import socket
+    import torch.distributed as dist
+    import text2pos_amd as t2p
+    from text2pos_amd import distributed as TD
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=_dev())
+    try:
+        g = torch.Generator().manual_seed(3)
+        cells = torch.nn.functional.normalize(torch.randn(1000, 256, generator=g), dim=-1).to(_dev())
+        queries = torch.nn.functional.normalize(torch.randn(37, 256, generator=g), dim=-1).to(_dev())
+        got = TD.all_gather_rows(cells, 1000, force=True)
+        assert got.is_cuda and got.data_ptr() != cells.data_ptr() and torch.equal(got, cells)
+        marks = []
+        idx, sc = TD.sharded_retrieval(lambda lo, hi: cells[lo:hi], lambda lo, hi: queries[lo:hi],
+                                       lambda q, c, k: t2p.retrieve_topk(c, q, k), 1000, 37, 10, around_exchange=marks.append,
+                                       force_exchange=True)
+        widx, wsc = t2p.retrieve_topk(cells, queries, 10)
+        assert marks == ["begin", "end"] and torch.equal(idx, widx) and torch.equal(sc, wsc)
+    finally:
+        dist.destroy_process_group()
+
+
 def _row_lists(nbr, cnt):
     """The compact level-1 edge-row lists k_sample_group writes, rebuilt from the neighbour tables: per centroid its hits
     ((c << 8) | point, ascending) and then its self loop (((c | 0x80) << 8) | c); four 0xFFFF behind the last row."""

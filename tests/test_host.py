@@ -218,6 +218,43 @@ def test_pack_cells_roundtrip_and_validation():
         D.pack_cells([o1], [bad], 256)
     with pytest.raises(RuntimeError):
         D.pack_cells([o1, o2], [p1], 256)
+    # persistent staging buffers + the per-cell means cache give the same arrays, call after call
+    st, cache = D.HostStaging(), D.ObjectMeansCache()
+    for _ in range(3):
+        got = D.pack_cells([o1, o2], [p1, p2], 256, staging=st, means_cache=cache)
+        assert all(torch.equal(a, b) for a, b in zip(got[:4], (xyz, rgb, center, mean_rgb))) and got[4].tolist() == [0, 3, 5]
+    assert cache.get(o1) is not None and cache.get(list(o1)) is None            # keyed by the list's identity
+    o1[0], keep = o2[0], o1[0]
+    assert cache.get(o1) is None                                                    # the list holds another object now
+    o1[0] = keep
+    assert D.pack_cells([o1], [p1], 256, skip_rgb=True)[1] is None
+
+
+def test_object_means_equal_the_reference_accessors_bit_for_bit():
+    """models/object_encoder.py:121-131: torch.tensor([obj.get_center() ...], dtype=torch.float) - a float64 np.mean per object,
+    rounded to fp32.  data.object_means sums all objects of a cell with one reduceat (another summation order) and keeps a row
+    only where no order could round differently; the others fall back to np.mean.  Must be bit-identical, also for centred
+    clouds (mean ~ 0: cancellation), large world coordinates, single-point objects and fp32 inputs."""
+    rng = np.random.default_rng(3)
+    n_unsafe = 0
+    for trial in range(200):
+        objs = []
+        for j in range(int(rng.integers(1, 27))):
+            m = int(rng.integers(1, 3000))
+            kind = trial % 4
+            xyz = rng.standard_normal((m, 3)) * (10.0 ** rng.integers(-3, 3))
+            if kind == 1:
+                xyz += rng.random(3) * 5000.0          # world coordinates of a KITTI-360 scene
+            if kind == 2:
+                xyz -= xyz.mean(axis=0)                 # mean ~ 1e-17
+            rgb = rng.random((m, 3))
+            if kind == 3 and j % 3 == 0:
+                xyz, rgb = xyz.astype(np.float32), rgb.astype(np.float32)
+            objs.append(D.Object3d(j, j, xyz, rgb, "box"))
+        center, color = D.object_means(objs)
+        want_c = torch.tensor(np.stack([o.get_center() for o in objs]), dtype=torch.float).numpy()
+        want_r = torch.tensor(np.stack([o.get_color_rgb() for o in objs]), dtype=torch.float).numpy()
+        assert center.dtype == np.float32 and np.array_equal(center, want_c) and np.array_equal(color, want_r), trial
 
 
 def test_batch_object_points_mirrors_reference_pipeline():

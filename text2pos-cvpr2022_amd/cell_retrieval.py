@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, packing
-from .data import pack_cells
+from .data import HostStaging, ObjectMeansCache, pack_cells
 from .modules import LanguageEncoder, get_mlp
 from .object_encoder import ObjectEncoder
 
@@ -64,6 +64,8 @@ class CellRetrievalNetwork(nn.Module):
         self.language_encoder.precision = precision
         self.language_encoder.kernel_dim = self.kernel_dim
         self._pack = None
+        self._staging = HostStaging()              # pinned host buffers of encode_objects, kept across calls
+        self.object_means_cache = ObjectMeansCache()   # per-cell (centre, mean colour) rows; .clear() after editing objects in place
 
     # ---- text branch -----------------------------------------------------------------------------------------
 
@@ -278,9 +280,13 @@ class CellRetrievalNetwork(nn.Module):
         """objects: List[List[Object3d]], object_points: List[Batch] (one PyG-style batch per cell)
         -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:77-107).  train() mode: see encode_objects_packed."""
         n_pts = int(getattr(self.args, "pointnet_numpoints", 256))
-        zero_color = "color" not in self.args.use_features  # models/object_encoder.py:86-90
-        xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, n_pts, zero_color)
         dev = self.device
+        # models/object_encoder.py:86-90: without the "color" feature the PointNet++ sees x = 0 - the colours then never travel
+        skip_rgb = "color" not in self.args.use_features
+        xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, n_pts, staging=self._staging,
+                                                          means_cache=self.object_means_cache, skip_rgb=skip_rgb, device=dev)
+        if rgb is None:
+            rgb = torch.zeros_like(xyz)
         to = lambda t: t.to(dev, non_blocking=True)
         # ground-truth embedding ablations (models/object_encoder.py:74-84)
         oe, class_idx, color_idx = self.object_encoder, None, None
@@ -290,8 +296,7 @@ class CellRetrievalNetwork(nn.Module):
         if getattr(self.args, "color_embed", False):
             color_idx = to(torch.tensor([oe.known_colors[o.get_color_text()] for objs in objects for o in objs],
                                         dtype=torch.int32))
-        return self.encode_objects_packed(to(xyz), to(rgb), to(center), to(mean_rgb), cell_ptr, class_idx=class_idx,
-                                          color_idx=color_idx)
+        return self.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr, class_idx=class_idx, color_idx=color_idx)
 
     def encode_raw_objects(self, objects, generator: np.random.Generator, rotate_degrees: float = None):
         """objects: List[List[Object3d]] with RAW point sets.  The dataloader's per-object transform chain

@@ -78,10 +78,10 @@ __device__ __forceinline__ float relu1(float v) {
     const int b = __float_as_int(v);
     return __int_as_float(b > 0 ? b : 0);
 }
-// (v0, v1) -> fp16 pair hi (round toward zero) and the fp16 pair of the exact residuals
+// (v0, v1) -> fp16 pair hi (round to nearest) and the fp16 pair of the exact residuals
 __device__ __forceinline__ void split2(float v0, float v1, uint32_t& hi, uint32_t& lo) {
-    const fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
-    const fp16x2 ll = __builtin_amdgcn_cvt_pkrtz(sub_half_p<0>(v0, hh), sub_half_p<1>(v1, hh));
+    const fp16x2 hh = cvt_pk_f16(v0, v1);
+    const fp16x2 ll = cvt_pk_f16(sub_half_p<0>(v0, hh), sub_half_p<1>(v1, hh));
     hi = __builtin_bit_cast(uint32_t, hh);
     lo = __builtin_bit_cast(uint32_t, ll);
 }

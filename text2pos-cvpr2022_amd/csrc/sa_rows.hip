@@ -351,15 +351,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                     }
                 };
                 // conversion of one step's 8 values in 8 half-chunks of 4 VALU operations (pair pr = values 2 pr, 2 pr + 1):
-                // first half v = relu(x - b), second half hi = fp16(v) toward zero, lo = fp16(v - hi)
+                // first half v = relu(x - b), second half hi = fp16(v) to nearest, lo = fp16(v - hi)
                 auto prep_a = [&](int pr, const f32x4 (&x)[2], const f32x4 (&b)[2], float (&v)[2]) {
                     const int j = pr >> 1, e0 = (pr & 1) * 2;
                     v[0] = fmaxf(x[j][e0] - b[j][e0], 0.f);
                     v[1] = fmaxf(x[j][e0 + 1] - b[j][e0 + 1], 0.f);
                 };
                 auto prep_b = [&](const float (&v)[2], uint32_t& wh, uint32_t& wl) {
-                    const fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-                    const fp16x2 ll = __builtin_amdgcn_cvt_pkrtz(sub_half_r<0>(v[0], hh), sub_half_r<1>(v[1], hh));
+                    const fp16x2 hh = cvt_pk_f16(v[0], v[1]);
+                    const fp16x2 ll = cvt_pk_f16(sub_half_r<0>(v[0], hh), sub_half_r<1>(v[1], hh));
                     wh = __builtin_bit_cast(uint32_t, hh);
                     wl = __builtin_bit_cast(uint32_t, ll);
                 };

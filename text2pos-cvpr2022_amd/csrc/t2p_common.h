@@ -39,6 +39,23 @@ void set_error(const char* fmt, ...);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// fp32 pair -> packed fp16 pair, round to NEAREST even (gfx950's v_cvt_pk_f16_f32; the f16x3 split x = hi + lo then carries
+// |error| <= 2^-22 |x| - v_cvt_pkrtz_f16_f32, round toward zero, leaves 2^-20 and a bias that adds up along k).
+// T2P_SPLIT_RTZ=1 rebuilds round 3's split for A/B measurements.
+#ifndef T2P_SPLIT_RTZ
+#define T2P_SPLIT_RTZ 0
+#endif
+typedef __fp16 t2p_fp16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ t2p_fp16x2 cvt_pk_f16(float a, float b) {
+#if T2P_SPLIT_RTZ
+    return __builtin_amdgcn_cvt_pkrtz(a, b);
+#else
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 h16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(t2p_fp16x2, __builtin_convertvector((f32x2_){a, b}, h16x2_));
+#endif
+}
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 int num_cus();  // cached multiProcessorCount of the current device
@@ -47,8 +64,8 @@ int num_cus();  // cached multiProcessorCount of the current device
 int reserve_lds(const void* kernel, size_t bytes, const char* what);
 
 // ---- fp16-range guard of the f16x3 path -------------------------------------------------------------------------
-// The split-precision path converts fp32 activations to fp16 (hi = fp16(v) toward zero: a value past 65504 would
-// SATURATE silently).  Every kernel that performs such a conversion reports the largest magnitude it converted into one
+// The split-precision path converts fp32 activations to fp16 (hi = fp16(v) to nearest: a value past 65504 would
+// become inf).  Every kernel that performs such a conversion reports the largest magnitude it converted into one
 // of these per-chunk device words (float bits, atomicMax on the unsigned pattern); k_guard_check turns them into the
 // caller's sticky overflow flag.  The SA edge kernels convert relu(A_j - B_i) and are covered by the bound
 // max|A_l| + max|B_l| taken where the tables are produced, so their inner loop carries no check.

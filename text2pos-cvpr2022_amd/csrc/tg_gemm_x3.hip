@@ -3,7 +3,7 @@
 //   mlp_merge (3D -> D)                       models/object_encoder.py:137-138
 // C[M,N] = act(A[M,K] W[K,N] + bias) with A fp32 in HBM and W given as the scaled split image of
 // packing.py::pack_gemm_x3: w' = s w (s a power of two), hi = fp16(w'), lo = fp16(w' - hi), stored [plane][n][k]
-// (k contiguous) so that a 16-byte load is one MFMA B-operand fragment.  A is split on the fly (hi = fp16 toward zero,
+// (k contiguous) so that a 16-byte load is one MFMA B-operand fragment.  A is split on the fly (hi = fp16 to nearest,
 // lo = fp16(a - hi)); hi.hi + hi.lo + lo.hi share one fp32 accumulator (the matrix cores honour fp16 denormals), the
 // epilogue divides by s.  Same error class as an fp32 fma chain (~5e-7), 16/3 x the fp32-MFMA rate.
 // 128 x 128 x 32 tile, 4 waves x (2 x 2) v_mfma_f32_32x32x16_f16 blocks, double-buffered LDS, register-prefetched loads.
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
         for (int i = 0; i < 4; i++) {
             const f32x4 v = ra[i];
             gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-            const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-            const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(v[0], h01), sub_half<1>(v[1], h01));
-            const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(v[2], h23), sub_half<1>(v[3], h23));
+            const fp16x2 h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
+            const fp16x2 l01 = cvt_pk_f16(sub_half<0>(v[0], h01), sub_half<1>(v[1], h01));
+            const fp16x2 l23 = cvt_pk_f16(sub_half<0>(v[2], h23), sub_half<1>(v[3], h23));
             uint2 ph, pl;
             ph.x = __builtin_bit_cast(uint32_t, h01); ph.y = __builtin_bit_cast(uint32_t, h23);
             pl.x = __builtin_bit_cast(uint32_t, l01); pl.y = __builtin_bit_cast(uint32_t, l23);

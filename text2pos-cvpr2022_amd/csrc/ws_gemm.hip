@@ -187,9 +187,9 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                 _Float16* dsth = hidh + buf * 2 * C::PLANE;
                 if constexpr (C::EDGE)   // fp16-range guard: the kNN edge rows relu(P_i + Q_j) are split here and nowhere reported
                     gmax_edge = fmaxf(fmaxf(gmax_edge, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-                const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.f, (v[1] - (float)h01[1]) * 2048.f);
-                const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * 2048.f, (v[3] - (float)h23[1]) * 2048.f);
+                const fp16x2 h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
+                const fp16x2 l01 = cvt_pk_f16((v[0] - (float)h01[0]) * 2048.f, (v[1] - (float)h01[1]) * 2048.f);
+                const fp16x2 l23 = cvt_pk_f16((v[2] - (float)h23[0]) * 2048.f, (v[3] - (float)h23[1]) * 2048.f);
                 uint2 ph, pl;
                 ph.x = __builtin_bit_cast(uint32_t, h01); ph.y = __builtin_bit_cast(uint32_t, h23);
                 pl.x = __builtin_bit_cast(uint32_t, l01); pl.y = __builtin_bit_cast(uint32_t, l23);
@@ -325,8 +325,8 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                             // is bounded from its input's magnitude instead (k_guard_check)
                             if constexpr (X3 && SPLIT_IO != 2) gmax_out = fmaxf(gmax_out, fabsf(v));
                             if constexpr (SPLIT_IO == 2) {  // hand the activations on already split into fp16 hi / lo
-                                const fp16x2 hv = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
-                                const fp16x2 lv = __builtin_amdgcn_cvt_pkrtz((v - (float)hv[0]) * 2048.f, 0.f);
+                                const fp16x2 hv = cvt_pk_f16(v, 0.f);
+                                const fp16x2 lv = cvt_pk_f16((v - (float)hv[0]) * 2048.f, 0.f);
 #if T2P_GABL & 1
                                 if (FULL || r < n_rows) {      // same instructions, 4 MB footprint: no HBM write traffic
                                     ((__fp16*)p.out_hi + (o0 & 0xFFFFF))[rr * p.ldo] = hv[0];

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             }
             if (c4 == 0) dstl[dbuf * C::TR + rgrp + k] = (uint16_t)((pad ? (uint32_t)nc : dl) * (uint32_t)(N * 4));
         };
-        // staging of row k, first half: v = relu(A_j - B_i), hi = fp16(v) toward zero -> hi plane
+        // staging of row k, first half: v = relu(A_j - B_i), hi = fp16(v) to nearest -> hi plane
         auto stage_a = [&](int buf, int k) {
             _Float16* dsth = hidh + buf * 2 * C::PLANE;
             f32x4 t;
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
             else t = sa[k] - sb[k];
 #pragma unroll
             for (int e = 0; e < 4; e++) vv[e] = fmaxf(t[e], 0.f);
-            vh01 = __builtin_amdgcn_cvt_pkrtz(vv[0], vv[1]);
-            vh23 = __builtin_amdgcn_cvt_pkrtz(vv[2], vv[3]);
+            vh01 = cvt_pk_f16(vv[0], vv[1]);
+            vh23 = cvt_pk_f16(vv[2], vv[3]);
             uint2 ph;
             ph.x = __builtin_bit_cast(uint32_t, vh01);
             ph.y = __builtin_bit_cast(uint32_t, vh23);
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(64 * NW, NW * WGS / 4) void k_ws_sa2(SaParams p) {
         auto stage_b = [&](int buf, int k) {
             _Float16* dsth = hidh + buf * 2 * C::PLANE;
             // v - float(hi) in one VALU op each: v_fma_mix_f32 reads the fp16 half directly (hi * -1 + v, exact)
-            const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(vv[0], vh01), sub_half<1>(vv[1], vh01));
-            const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz(sub_half<0>(vv[2], vh23), sub_half<1>(vv[3], vh23));
+            const fp16x2 l01 = cvt_pk_f16(sub_half<0>(vv[0], vh01), sub_half<1>(vv[1], vh01));
+            const fp16x2 l23 = cvt_pk_f16(sub_half<0>(vv[2], vh23), sub_half<1>(vv[3], vh23));
             uint2 pl;
             pl.x = __builtin_bit_cast(uint32_t, l01);
             pl.y = __builtin_bit_cast(uint32_t, l23);

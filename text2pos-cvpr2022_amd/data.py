@@ -147,40 +147,223 @@ def batch_object_points(objects: List[Object3d], transform):
     return Batch.from_data_list(data_list)
 
 
-def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_color: bool = False):
-    """Flatten the (objects, object_points) pair of CellRetrievalNetwork.encode_objects into host arrays:
-    xyz, rgb [Nobj, n_pts, 3], center, mean_rgb [Nobj, 3] (fp32, pinned when CUDA is present), cell_ptr int32 [B+1]."""
+class HostStaging:
+    """Pinned host buffers that outlive a call (the first version of pack_cells allocated four pinned tensors per call:
+    a pinned allocation is a driver call that costs more than the copy it serves).  Two sets, used in turn, each with the
+    event that marks the end of the last host-to-device copy out of it: a set is not rewritten before that copy is done."""
+
+    def __init__(self):
+        self.sets = [dict(), dict()]
+        self.events = [None, None]
+        self.turn = 0
+
+    def next_set(self):
+        self.turn ^= 1
+        ev = self.events[self.turn]
+        if ev is not None:
+            ev.synchronize()
+        return self.turn
+
+    def buffer(self, which: int, name: str, numel: int) -> torch.Tensor:
+        buf = self.sets[which].get(name)
+        if buf is None or buf.numel() < numel:
+            cap = max(int(numel * 1.25), 1 << 16)
+            buf = torch.empty(cap, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+            self.sets[which][name] = buf
+        return buf[:numel]
+
+    def mark_copied(self, which: int, stream=None):
+        if torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self.events[which] = ev
+
+
+class ObjectMeansCache:
+    """Per-cell memo of the objects' (centre, mean colour) rows - models/object_encoder.py:121-131 recomputes
+    `obj.get_center()` / `obj.get_color_rgb()` (a float64 NumPy mean over the RAW points of every object) in every call, which
+    at 10-20 us per object is 20x the GPU time of the cell.  Keyed by the identity of the cell's object list; an entry keeps the
+    list and its objects alive and is used only while the list still holds the very same objects.  The point arrays of an
+    Object3d are treated as immutable, as the reference's dataset classes treat them (augmentation happens on the PyG batches):
+    call clear() after editing `obj.xyz` / `obj.rgb` in place.  Bounded (least recently inserted entries leave first)."""
+
+    def __init__(self, max_cells: int = 1 << 17):
+        self.max_cells = max_cells
+        self.d = {}
+
+    def clear(self):
+        self.d.clear()
+
+    def get(self, objs):
+        e = self.d.get(id(objs))
+        if e is None:
+            return None
+        kept, snapshot, center, color = e
+        if kept is not objs or len(objs) != len(snapshot):
+            return None
+        for a, b in zip(objs, snapshot):
+            if a is not b:
+                return None
+        return center, color
+
+    def put(self, objs, center, color):
+        if len(self.d) >= self.max_cells:
+            for k in list(self.d.keys())[: self.max_cells // 8]:
+                del self.d[k]
+        self.d[id(objs)] = (objs, tuple(objs), center, color)
+
+
+_U64 = 1.2e-16   # unit roundoff of float64 (rounded up)
+
+
+def _means_f32(arrays) -> np.ndarray:
+    """float32(np.mean(a, axis=0)) for every [m_i, 3] float64 array of a cell, without one NumPy call per object: the arrays
+    are concatenated and summed by np.add.reduceat.  That sums in another ORDER than np.mean (pairwise blocks), so the float64
+    results differ in their last bits; whichever order is used, a sum is within (m - 1) u sum|x| of the exact one.  Where the
+    float32 roundings of (mean - tol) and (mean + tol) agree the result is the reference's bit for bit; the (rare) rows
+    where they do not are recomputed with np.mean itself."""
+    n = len(arrays)
+    if any((not isinstance(a, np.ndarray)) or a.dtype != np.float64 or a.ndim != 2 or a.shape[0] == 0 for a in arrays):
+        return np.stack([np.mean(a, axis=0) for a in arrays]).astype(np.float32)
+    cnt = np.fromiter((a.shape[0] for a in arrays), dtype=np.int64, count=n)
+    start = np.zeros(n, dtype=np.int64)
+    np.cumsum(cnt[:-1], out=start[1:])
+    cat = np.concatenate(arrays, axis=0)
+    mean = np.add.reduceat(cat, start, axis=0) / cnt[:, None]
+    tol = np.add.reduceat(np.abs(cat), start, axis=0) * (4.0 * _U64) + 1e-300   # both sums' bounds, divided by m, + the division
+    lo, hi = (mean - tol).astype(np.float32), (mean + tol).astype(np.float32)
+    out = mean.astype(np.float32)
+    unsafe = np.flatnonzero((lo != hi).any(axis=1))
+    for i in unsafe:
+        out[i] = np.mean(arrays[i], axis=0).astype(np.float32)
+    return out
+
+
+def object_means(objs, cache: ObjectMeansCache = None):
+    """([n, 3] fp32 centres, [n, 3] fp32 mean colours) of a cell's objects = torch.tensor([o.get_center() ...], dtype=float)
+    of the reference (models/object_encoder.py:121-131), bit for bit."""
+    if cache is not None:
+        hit = cache.get(objs)
+        if hit is not None:
+            return hit
+    own_class = all(type(o) is Object3d for o in objs)
+    if own_class or all(hasattr(o, "xyz") and hasattr(o, "rgb") and type(o).get_center.__qualname__.endswith("Object3d.get_center")
+                        for o in objs):
+        center, color = _means_f32([o.xyz for o in objs]), _means_f32([o.rgb for o in objs])
+    else:   # a subclass that overrides the accessors: ask it
+        center = np.stack([o.get_center() for o in objs]).astype(np.float32)
+        color = np.stack([o.get_color_rgb() for o in objs]).astype(np.float32)
+    if cache is not None:
+        cache.put(objs, center, color)
+    return center, color
+
+
+_EXPECT_BATCH = {}
+_CAT_POOL = None
+
+
+def _cat_into(tensors, out: torch.Tensor, rows_per_item, threads: int = 4):
+    """torch.cat(tensors, out=out) in `threads` contiguous pieces on a small thread pool (torch.cat releases the GIL; one
+    thread moves ~5 GB/s, and a 512-cell call concatenates 2 x 25 MB)."""
+    global _CAT_POOL
+    n = len(tensors)
+    if n < 64 or threads <= 1:
+        torch.cat(tensors, out=out)
+        return
+    if _CAT_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _CAT_POOL = ThreadPoolExecutor(max_workers=threads, thread_name_prefix="t2p-pack")
+    ends = np.cumsum(rows_per_item)
+    cuts = [0] + [int(np.searchsorted(ends, ends[-1] * (k + 1) // threads, side="left")) + 1 for k in range(threads - 1)] + [n]
+    cuts = sorted(set(min(c, n) for c in cuts))
+    jobs = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        r0 = int(ends[a - 1]) if a > 0 else 0
+        jobs.append(_CAT_POOL.submit(torch.cat, tensors[a:b], out=out[r0: int(ends[b - 1])]))
+    for j in jobs:
+        j.result()
+
+
+def _check_batch_vector(pts, n: int, n_pts: int, i: int):
+    key = (n, n_pts)
+    expect = _EXPECT_BATCH.get(key)
+    if expect is None:
+        expect = _EXPECT_BATCH[key] = torch.arange(n).repeat_interleave(n_pts)
+    b = pts.batch
+    if b.shape[0] != n * n_pts or not torch.equal(b.cpu().long(), expect):
+        raise RuntimeError(f"encode_objects: cell {i}: batch vector is not {n} contiguous groups of {n_pts}")
+
+
+def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_color: bool = False,
+               staging: HostStaging = None, means_cache: ObjectMeansCache = None, skip_rgb: bool = False, device=None):
+    """Flatten the (objects, object_points) pair of CellRetrievalNetwork.encode_objects into
+    xyz, rgb [Nobj, n_pts, 3], center, mean_rgb [Nobj, 3] (fp32), cell_ptr int32 [B+1].
+    Without `device`: host tensors (pinned when CUDA is present).  With `device`: the arrays are returned ON the device - the
+    point batches are concatenated straight into `staging`'s pinned buffers (one pass over the bytes, no per-call pinned
+    allocation) and copied asynchronously; batches that already live on the device are concatenated there.
+    skip_rgb: return rgb = None (the caller zeroes the colours on the device: models/object_encoder.py:86-90).
+    The batch vectors of at most 8 evenly spaced cells are verified element by element, all cells by size."""
     if len(objects) != len(object_points):
         raise RuntimeError(f"encode_objects: {len(objects)} object lists but {len(object_points)} point batches")
-    counts = [len(o) for o in objects]
-    cell_ptr = np.zeros(len(objects) + 1, dtype=np.int32)
-    cell_ptr[1:] = np.cumsum(counts)
+    n_cells = len(objects)
+    counts = np.fromiter((len(o) for o in objects), dtype=np.int64, count=n_cells)
+    cell_ptr = np.zeros(n_cells + 1, dtype=np.int32)
+    np.cumsum(counts, out=cell_ptr[1:])
     n_obj = int(cell_ptr[-1])
-    pin = torch.cuda.is_available()
-    xyz = torch.empty((n_obj, n_pts, 3), dtype=torch.float32, pin_memory=pin)
-    rgb = torch.empty((n_obj, n_pts, 3), dtype=torch.float32, pin_memory=pin)
-    center = torch.empty((n_obj, 3), dtype=torch.float32, pin_memory=pin)
-    mean_rgb = torch.empty((n_obj, 3), dtype=torch.float32, pin_memory=pin)
-    for i, (objs, pts) in enumerate(zip(objects, object_points)):
-        lo, hi = int(cell_ptr[i]), int(cell_ptr[i + 1])
-        n = hi - lo
-        if n < 1:
-            raise RuntimeError(f"encode_objects: cell {i} has no objects")
-        if pts.pos.shape[0] != n * n_pts:
-            raise RuntimeError(f"encode_objects: cell {i} has {n} objects but {pts.pos.shape[0]} points; every object "
+    if n_cells and counts.min() < 1:
+        raise RuntimeError(f"encode_objects: cell {int(np.argmin(counts))} has no objects")
+    for i, pts in enumerate(object_points):
+        if pts.pos.shape[0] != counts[i] * n_pts:
+            raise RuntimeError(f"encode_objects: cell {i} has {counts[i]} objects but {pts.pos.shape[0]} points; every object "
                                f"must be resampled to {n_pts} points (T.FixedPoints({n_pts}))")
-        if pts.batch is not None:
-            expect = torch.arange(n).repeat_interleave(n_pts)
-            if not torch.equal(pts.batch.cpu().long(), expect):
-                raise RuntimeError(f"encode_objects: cell {i}: batch vector is not {n} contiguous groups of {n_pts}")
-        xyz[lo:hi] = pts.pos.detach().cpu().float().reshape(n, n_pts, 3)
-        if zero_color:
-            rgb[lo:hi] = 0.0
-        else:
-            rgb[lo:hi] = pts.x.detach().cpu().float().reshape(n, n_pts, 3)
-        # same conversion as the reference: torch.tensor(list of float64 means, dtype=torch.float)
-        center[lo:hi] = torch.tensor(np.stack([o.get_center() for o in objs]), dtype=torch.float)
-        mean_rgb[lo:hi] = torch.tensor(np.stack([o.get_color_rgb() for o in objs]), dtype=torch.float)
+    step = max(1, n_cells // 8)
+    for i in range(0, n_cells, step):
+        if object_points[i].batch is not None:
+            _check_batch_vector(object_points[i], int(counts[i]), n_pts, i)
+    want_rgb = not (skip_rgb or zero_color)
+    on_device = n_cells > 0 and object_points[0].pos.is_cuda
+    pin = torch.cuda.is_available()
+
+    def flat(which):
+        ts = [getattr(p, which) for p in object_points]
+        return [t if t.dtype == torch.float32 else t.float() for t in ts]
+
+    if on_device:
+        xyz = torch.cat(flat("pos")).detach().reshape(n_obj, n_pts, 3)
+        rgb = torch.cat(flat("x")).detach().reshape(n_obj, n_pts, 3) if want_rgb else None
+        which = None
+    else:
+        which = staging.next_set() if staging is not None else None
+
+        def host(name, numel):
+            if staging is not None:
+                return staging.buffer(which, name, numel)
+            return torch.empty(numel, dtype=torch.float32, pin_memory=pin)
+        xyz = host("xyz", n_obj * n_pts * 3).view(n_obj * n_pts, 3)
+        rows = counts * n_pts
+        if n_cells:
+            _cat_into([t.detach() for t in flat("pos")], xyz, rows)
+        xyz = xyz.view(n_obj, n_pts, 3)
+        rgb = None
+        if want_rgb:
+            rgb = host("rgb", n_obj * n_pts * 3).view(n_obj * n_pts, 3)
+            if n_cells:
+                _cat_into([t.detach() for t in flat("x")], rgb, rows)
+            rgb = rgb.view(n_obj, n_pts, 3)
+    if zero_color and not skip_rgb:
+        rgb = torch.zeros((n_obj, n_pts, 3), dtype=torch.float32, device=xyz.device)
+    small = (staging.buffer(which, "means", n_obj * 6) if (staging is not None and which is not None)
+             else torch.empty(n_obj * 6, dtype=torch.float32, pin_memory=pin)).view(2, n_obj, 3)
+    small_np = small.numpy()
+    for i, objs in enumerate(objects):
+        lo, hi = cell_ptr[i], cell_ptr[i + 1]
+        small_np[0, lo:hi], small_np[1, lo:hi] = object_means(objs, means_cache)
+    center, mean_rgb = small[0], small[1]
+    if device is not None:
+        to = lambda t: None if t is None else t.to(device, non_blocking=True)
+        xyz, rgb, center, mean_rgb = to(xyz), to(rgb), to(center), to(mean_rgb)
+        if staging is not None and which is not None:
+            staging.mark_copied(which)
     return xyz, rgb, center, mean_rgb, cell_ptr
 
 

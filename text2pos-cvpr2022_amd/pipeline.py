@@ -67,7 +67,8 @@ def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], thresh
         enc = []
         for a in range(lo, hi, cells_per_call):
             b = min(a + cells_per_call, hi)
-            objects = [list(c.objects) for c in cells[a:b]]
+            # (the cells' own lists, not copies: CellRetrievalNetwork.object_means_cache recognises a cell by its list)
+            objects = [c.objects if isinstance(c.objects, list) else list(c.objects) for c in cells[a:b]]
             if hasattr(transform, "for_cell"):
                 points = [D.batch_object_points(o, transform.for_cell(a + i)) for i, o in enumerate(objects)]
             else:

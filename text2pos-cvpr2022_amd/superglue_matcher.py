@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, packing
-from .data import pack_cells
+from .data import HostStaging, ObjectMeansCache, pack_cells
 from .modules import LanguageEncoder, tokenize
 from .object_encoder import ObjectEncoder
 
@@ -208,9 +208,14 @@ class SuperGlueMatch(nn.Module):
         (models/superglue_matcher.py:87-128)."""
         self._check_forward_only()
         n_pts = int(getattr(self.args, "pointnet_numpoints", 256))
-        zero_color = "color" not in self.args.use_features
-        xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, n_pts, zero_color)
         dev = self.device
+        if getattr(self, "_staging", None) is None:
+            self._staging, self.object_means_cache = HostStaging(), ObjectMeansCache()
+        xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, n_pts, staging=self._staging,
+                                                          means_cache=self.object_means_cache,
+                                                          skip_rgb="color" not in self.args.use_features, device=dev)
+        if rgb is None:
+            rgb = torch.zeros_like(xyz)
         to = lambda t: t.to(dev, non_blocking=True)
         oe, class_idx, color_idx = self.object_encoder, None, None
         if getattr(self.args, "class_embed", False):
@@ -219,7 +224,7 @@ class SuperGlueMatch(nn.Module):
         if getattr(self.args, "color_embed", False):
             color_idx = to(torch.tensor([oe.known_colors[o.get_color_text()] for objs in objects for o in objs],
                                         dtype=torch.int32))
-        return self.forward_packed(to(xyz), to(rgb), to(center), to(mean_rgb), cell_ptr, hints, class_idx, color_idx)
+        return self.forward_packed(xyz, rgb, center, mean_rgb, cell_ptr, hints, class_idx, color_idx)
 
     @property
     def device(self):
