@@ -36,7 +36,7 @@ extern "C" {
                                            one chunk: ~0.6 MB per object, i.e. ~38 GB at the default chunk for a batch that
                                            fills it (t2p_encode_cells_workspace_bytes gives the exact figure; a second
                                            stream's call needs its own workspace) */
-#define T2P_TUNING_MASK 0xF              /* t2p_cell_config.tuning: the bits that select a built plan */
+#define T2P_TUNING_MASK 0x1F             /* t2p_cell_config.tuning: the bits that select a built plan */
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -173,7 +173,8 @@ typedef struct t2p_cell_config {
      * (round to nearest: a magnitude past 65504 would become inf).  When non-NULL, this DEVICE word receives a
      * sticky OR of a non-zero code whenever a conversion site of the call may have left fp16's range (bits 0-2: SA level
      * 1-3 edge inputs, judged by max|A_l| + max|B_l|; bit 3: SA output rows split by the dense table kernels; bit 4: GA
-     * hidden planes, judged by a norm bound; bit 5: rows of the LDS-tiled GEMMs).  The tests are conservative: they may
+     * hidden planes, judged by a norm bound; bit 5: rows of the LDS-tiled GEMMs; bit 6: a NaN among the input points / colours -
+     * the float-max aggregation of the f16x3 kernels would drop it where the reference's scatter-max propagates it).  The tests are conservative: they may
      * fire for a checkpoint that would just have fitted, never the other way round.  The caller clears it, reads it after the stream has drained, and must
      * not trust the call's output when it is set (the Python host raises or re-runs with precision = 0).  NULL: no check. */
     int32_t* overflow_flag;
@@ -187,6 +188,8 @@ typedef struct t2p_cell_config {
      *   bit 3: f16x3 only: SA level 1 on the column-slice kernel of ws_sa2.hip (default: sa_points.hip: independent waves,
      *          each owning a group of 16 centroids of an object with a private LDS accumulator; BOTH layers per edge from the
      *          object's points staged in LDS - no point table A_1, no row gathers)
+     *   bit 4: f16x3 only: SA level 3 on the column-slice kernel of ws_sa2.hip (default: sa3.hip, the same data flow with
+     *          the per-row control on the scalar unit)
      * Bits outside T2P_TUNING_MASK are refused (T2P_E_ARG). */
     int32_t tuning;
 } t2p_cell_config;

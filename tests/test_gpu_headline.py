@@ -330,6 +330,24 @@ def test_f16x3_weight_out_of_range_is_refused(oracle_model, vocab):
         m.encode_objects_packed(*args, np.array([0, 6], dtype=np.int32))
 
 
+@pytest.mark.parametrize("where", ["xyz", "rgb"])
+def test_f16x3_nan_input_is_caught(hip_model, where):
+    """The f16x3 SA kernels aggregate with a float max (ds_max_f32 from -inf), which DROPS NaN operands where the reference's
+    ReLU + scatter-max propagate them: a NaN among the input points / colours would come out as a finite embedding.  The
+    guard word carries the inputs' largest |bit pattern| (a NaN is the largest of all): the call must raise."""
+    from text2pos_amd import synthetic as S
+    xyz, rgb, center, mean_rgb = S.make_objects(5, 0, 12)
+    bad = {"xyz": xyz, "rgb": rgb}[where].copy()
+    bad[7, 100, 1] = np.float32(np.nan) if where == "xyz" else -np.float32(np.nan)
+    args = _to_dev(bad if where == "xyz" else xyz, bad if where == "rgb" else rgb, center, mean_rgb)
+    ptr = np.array([0, 5, 12], dtype=np.int32)
+    with torch.no_grad(), pytest.raises(FloatingPointError, match="0x4"):
+        hip_model.encode_objects_packed(*args, ptr)
+    with torch.no_grad():                                     # the sticky word was cleared: the next (clean) call is fine
+        out = hip_model.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), ptr)
+    assert bool(torch.isfinite(out).all())
+
+
 _FEATURE_SETS = {"all": ["class", "color", "position"], "class+position": ["class", "position"], "color": ["color"],
                  "class": ["class"]}
 
@@ -826,18 +844,19 @@ def test_execution_plans_are_bit_identical(hip_model):
     args = _to_dev(xyz, rgb, center, mean_rgb)
     outs = {}
     try:
-        for tuning in range(16):
+        for tuning in range(32):
             hip_model.tuning = tuning
             with torch.no_grad():
                 outs[tuning] = hip_model.encode_objects_packed(*args, cell_ptr, want_trace=("sa_out", "obj_emb"))
     finally:
         hip_model.tuning = 0
 
-    def family(t):      # (SA1 kernel, SA2 on ws_sa2.hip): bit 1 moves levels 1 and 2 to ws_sa2.hip
+    def family(t):      # (SA1 kernel, SA2 on ws_sa2.hip): bit 1 moves levels 1 and 2 to ws_sa2.hip.  Bit 4 (SA3 on ws_sa2.hip instead of
+        # sa3.hip) does not open a family: the two kernels add the same products in the same order
         return "slice" if t & 0b1010 else "points", bool(t & 0b0110)
 
     ref = {}
-    for t in range(16):
+    for t in range(32):
         out, tr = outs[t]
         if family(t) not in ref:
             ref[family(t)] = t
@@ -886,7 +905,7 @@ def test_cold_cache_runs_are_bit_identical(hip_model):
         return [x[:, :c].clone() for x, c in zip(tr["sa_out"], (64, 128, 256))] + [out.clone()]
 
     try:
-        for tuning in (0,):
+        for tuning in (0, 16):
             ref = run(tuning, cold=False)
             for rep in range(4):
                 got = run(tuning, cold=(rep % 2 == 0))

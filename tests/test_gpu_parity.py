@@ -321,23 +321,24 @@ def test_encode_cells_embedding_ablations(vocab, class_embed, color_embed):
         assert (cls == 0).any() and (cls > 0).any()      # unknown labels hit the padding row
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
-def test_embed_dim_300_vs_oracle(vocab, precision):
+@pytest.mark.parametrize("d,precision", [(300, "f16x3"), (300, "fp32"), (64, "f16x3")])
+def test_embed_dim_300_vs_oracle(vocab, d, precision):
     """--embed_dim 300 is the reference's argparse default (training/args.py:19; its README trains with 256).  The kernels run
     multiples of 128, so the host zero-pads every embed_dim-sized axis to 384 (packing.kernel_embed_dim): padded channels stay
     exactly 0 through Linear + ReLU, the aggregations, F.normalize, the kNN distances and the LSTM cell, and are cut off again.
-    Cell branch (stage by stage), text branch and ranking against the oracle built at 300."""
+    Cell branch (stage by stage), text branch and ranking against the oracle built at 300 (and at 64 -> 128: every width runs at
+    the next multiple of 128)."""
     import weights as W
     import text2pos_amd as t2p
     from oracle import model as OM
     from oracle.model import retrieve_topk_f64
     from text2pos_amd import synthetic as S
-    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(embed_dim=300)).eval()
+    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args(embed_dim=d)).eval()
     W.fill_state_dict(om, 31)
-    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(embed_dim=300), precision=precision)
+    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(embed_dim=d), precision=precision)
     hm.load_state_dict(om.state_dict(), strict=True)
     hm = hm.to(_dev()).eval()
-    assert hm.embed_dim == 300 and hm.kernel_dim == 384
+    assert hm.embed_dim == d and hm.kernel_dim == (d + 127) // 128 * 128 and hm.language_encoder.kernel_dim == hm.kernel_dim
     xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(71, 9)
     tr = []
     want = om.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr, trace=tr)
@@ -345,7 +346,7 @@ def test_embed_dim_300_vs_oracle(vocab, precision):
     with torch.no_grad():
         got, gtr = hm.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr, want_trace=("obj_emb",))
         two = hm.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr, streams=2)
-    assert got.shape == (9, 300) and gtr["obj_emb"].shape == (xyz.shape[0], 300)
+    assert got.shape == (9, d) and gtr["obj_emb"].shape == (xyz.shape[0], d)
     assert (gtr["obj_emb"].cpu() - want_emb).abs().max().item() < TOL
     assert (got.cpu() - want).abs().max().item() < TOL
     assert torch.equal(two, got)
@@ -354,10 +355,10 @@ def test_embed_dim_300_vs_oracle(vocab, precision):
     with torch.no_grad():
         q = hm.encode_text(texts)
     want_q = om.encode_text(texts)
-    assert q.shape == (42, 300) and (q.cpu() - want_q).abs().max().item() < TOL
+    assert q.shape == (42, d) and (q.cpu() - want_q).abs().max().item() < TOL
     # ranking at D = 300 (zero columns add exact zeros to the float64 scores)
     rng = np.random.default_rng(300)
-    c = rng.standard_normal((1500, 300)).astype(np.float32)
+    c = rng.standard_normal((1500, d)).astype(np.float32)
     c /= np.linalg.norm(c, axis=1, keepdims=True)
     c[41] = c[7]
     qq = np.concatenate([q.cpu().numpy(), c[[7, 100]]], 0)
@@ -365,7 +366,7 @@ def test_embed_dim_300_vs_oracle(vocab, precision):
     widx, wscore = retrieve_topk_f64(c, qq, 10)
     assert np.array_equal(idx.cpu().numpy(), widx) and np.abs(score.cpu().numpy() - wscore).max() < 1e-12
     hm.train()
-    with pytest.raises(NotImplementedError, match="embed_dim=300"):
+    with pytest.raises(NotImplementedError, match=f"embed_dim={d}"):
         hm.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr)
 
 

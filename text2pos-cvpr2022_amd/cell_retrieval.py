@@ -179,7 +179,7 @@ class CellRetrievalNetwork(nn.Module):
             code = self.overflow_detected()
             if code:
                 msg = (f"f16x3 path: an activation left fp16's range (guard code {code:#x}: bits 0-2 = SA level 1-3 edge "
-                       "inputs, 3 = dense table rows, 4 = GA hidden planes, 5 = GEMM rows)")
+                       "inputs, 3 = dense table rows, 4 = GA hidden planes, 5 = GEMM rows, 6 = NaN among the input points / colours)")
                 if self.on_overflow != "fp32":
                     raise FloatingPointError(msg + "; construct the model with precision=\"fp32\" or on_overflow=\"fp32\"")
                 warnings.warn(msg + "; recomputing this call on the exact fp32 path", RuntimeWarning)

@@ -247,7 +247,7 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     // are then neither written nor read.  The fp32 kernels (ws_sa.hip) gather all three from HBM.
     const bool lds_btab = cfg.precision == 1 && !(cfg.tuning & 2);
     const bool lds_btab0 = lds_btab && !(cfg.tuning & 8);
-    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0);
+    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0) | ((cfg.tuning & 16) ? 4 : 0);
     // level 0 runs on sa_points.hip, which computes layer 1 per edge from the points themselves: no point table A_1 either
     const bool sa1_points = lds_btab0 && cfg.n_pts == 256;
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st, guard));

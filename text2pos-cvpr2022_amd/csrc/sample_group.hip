@@ -321,18 +321,26 @@ __global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict_
     const int lane = threadIdx.x;
     for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
         const float* src = xyz + o * (int64_t)n_pts * 3;
-        float in_max = 0.f;  // fp16-range guard: the layer-1 tables are bounded from the input magnitudes (k_guard_check)
+        // fp16-range guard: the layer-1 tables are bounded from the input magnitudes (k_guard_check).  The maximum runs over the BIT
+        // PATTERNS of |v| (they order like unsigned integers): a NaN input is the largest pattern of all and reaches the guard
+        // word - fmaxf() would drop it, and the float-max aggregation of the f16x3 SA kernels drops NaN operands too, so without
+        // this a NaN point would come out as a finite embedding (the reference's ReLU / scatter-max propagate it)
+        uint32_t in_bits = 0u;
         for (int i = lane; i < n_pts * 3; i += 64) {
             float v = src[i];
-            in_max = fmaxf(in_max, fabsf(v));
+            const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
+            in_bits = b > in_bits ? b : in_bits;
             p0[(i % 3) * kMaxPts + i / 3] = v;
         }
         if (gt.guard != nullptr) {
             if (gt.rgb != nullptr) {
                 const float* col = gt.rgb + o * (int64_t)n_pts * 3;
-                for (int i = lane; i < n_pts * 3; i += 64) in_max = fmaxf(in_max, fabsf(col[i]));
+                for (int i = lane; i < n_pts * 3; i += 64) {
+                    const uint32_t b = __float_as_uint(col[i]) & 0x7fffffffu;
+                    in_bits = b > in_bits ? b : in_bits;
+                }
             }
-            guard_publish_above(gt.guard + G_INPUT, in_max, 1.0f);   // normalised inputs stay below 1: nothing is published
+            guard_publish_bits_above(gt.guard + G_INPUT, in_bits, 0x3f800000u);   // normalised inputs stay within [-1, 1]: nothing is published
         }
         __syncthreads();
         if (gt.A1 != nullptr) {

@@ -412,12 +412,14 @@ __global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, 
 
 // fp16-range verdict of one chunk (t2p_common.h GuardSlot): bit 0..2 = SA level l may have staged relu(A_j - B_i) past
 // fp16's largest finite value, bit 3 = an SA output row (split by the next dense kernel) did, bit 4 = the GA hidden planes
-// may have (bound ||W1||_1 max(F_3, 1) + max|b1|), bit 5 = a row of the LDS-tiled GEMMs did
+// may have (bound ||W1||_1 max(F_3, 1) + max|b1|), bit 5 = a row of the LDS-tiled GEMMs did, bit 6 = NaN in the input points / colours
 __global__ void k_guard_check(const uint32_t* __restrict__ guard, int32_t* flag, GuardBounds gb) {
     if (threadIdx.x != 0) return;
     const float lim = 65504.f;
     int code = 0;
-    const float in_max = fmaxf(__uint_as_float(guard[G_INPUT]), 1.f);       // unpublished: the inputs stayed within [-1, 1]
+    const uint32_t in_bits = guard[G_INPUT];
+    if (in_bits > 0x7f800000u) code |= 64;                                  // a NaN among the input points / colours
+    const float in_max = in_bits > 0x7f800000u ? __builtin_inff() : fmaxf(__uint_as_float(in_bits), 1.f);   // unpublished: within [-1, 1]
     for (int l = 0; l < 3; l++) {
         // point table: level 0 bounded from the inputs, levels 1 and 2 reported by their dense kernels (unpublished = below
         // the floor); centroid table: ||W1p||_1 max|xyz|

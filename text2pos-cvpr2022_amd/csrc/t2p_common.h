@@ -107,6 +107,17 @@ __device__ __forceinline__ void guard_publish_above(uint32_t* slot, float m, flo
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
 }
+// The same on the bit pattern of a magnitude (|v| as an unsigned integer; NaN patterns are the largest and DO get published)
+__device__ __forceinline__ void guard_publish_bits_above(uint32_t* slot, uint32_t bits, uint32_t floor_bits) {
+    if (slot == nullptr) return;
+    if (!__any(bits > floor_bits)) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)bits, o, 64);
+        bits = other > bits ? other : bits;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, bits);
+}
 // Exact form for the persistent SA kernels: `acc` is a wave-uniform bit pattern (an SGPR) that lives across the whole
 // launch; guard_flush publishes it once per wave at the end (no floor, no contention: ~2 k atomics per launch).
 __device__ __forceinline__ void guard_track_bits(uint32_t& acc, int lane_bits /* pattern of a non-negative float */) {
@@ -262,7 +273,7 @@ struct SaParams {
     int balanced;            // 1: bounds_ws was filled by launch_sa_balance_levels for this level's launch shape
     uint32_t* amax_out;      // f16x3 guard (nullable): largest output magnitude (the next dense kernel splits these rows)
     int plan;                // bit 0: SA level 2 stays on the column-slice kernel (ws_sa2.hip) instead of the row-owning one (sa_rows.hip);
-                             // bit 1: SA level 1 stays on it instead of sa_points.hip
+                             // bit 1: SA level 1 stays on it instead of sa_points.hip; bit 2: SA level 3 stays on it instead of sa3.hip
 };
 int launch_ws_sa(int H, int C, const SaParams& p, hipStream_t st);
 // sa_rows.hip: row-owning f16x3 kernel of SA level 2 (H = C = 128, LDS centroid table): true when launch_ws_sa routes p there
@@ -273,6 +284,10 @@ int sa_rows_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
 bool sa_points_selected(int H, int C, const SaParams& p);
 int launch_sa_points(int H, int C, const SaParams& p, hipStream_t st);
 int sa_points_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
+// sa3.hip: SA level 3 (H = C = 256, LDS centroid table) with scalar per-row control; plan bit 2 keeps ws_sa2.hip's kernel
+bool sa3_selected(int H, int C, const SaParams& p);
+int launch_sa3(const SaParams& p, hipStream_t st);
+int sa3_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
 // One launch that balances all three levels (their row counts are known once k_sample_group has run); fills
 // prefix_ws / bounds_ws of every p[l] for the launch shape launch_ws_sa(H[l], C[l], p[l]) will use.
 int launch_sa_balance_levels(const SaParams p[3], const int H[3], const int C[3], hipStream_t st);

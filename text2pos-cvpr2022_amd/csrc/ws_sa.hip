@@ -372,6 +372,7 @@ int sa2_launch_shape(int H, int Cout, int64_t n_obj, int* tile_rows, int* n_wg);
 static int sa_launch_shape(int H, int Cout, const SaParams& p, int64_t n_obj, int* tile_rows, int* n_wg) {
     if (sa_rows_selected(H, Cout, p)) return sa_rows_launch_shape(n_obj, tile_rows, n_wg);
     if (sa_points_selected(H, Cout, p)) return sa_points_launch_shape(n_obj, tile_rows, n_wg);
+    if (sa3_selected(H, Cout, p)) return sa3_launch_shape(n_obj, tile_rows, n_wg);
     if (p.W_x3 != nullptr) return sa2_launch_shape(H, Cout, n_obj, tile_rows, n_wg);
     int n = num_cus();
     if (n > n_obj) n = (int)n_obj;
@@ -405,6 +406,7 @@ int launch_ws_sa(int H, int Cout, const SaParams& p, hipStream_t st) {
         T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_sa: packed f16x3 weights must be 16-byte aligned");
         if (sa_rows_selected(H, Cout, p)) return launch_sa_rows(H, Cout, p, st);
         if (sa_points_selected(H, Cout, p)) return launch_sa_points(H, Cout, p, st);
+        if (sa3_selected(H, Cout, p)) return launch_sa3(p, st);
         return launch_ws_sa2(H, Cout, p, st);
     } else {
         if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2>(p, st, "ws_edge_sa_k32_n64");

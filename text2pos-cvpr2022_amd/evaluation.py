@@ -156,7 +156,9 @@ def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Seque
         import torch.distributed as dist
         dev = getattr(model, "device", None) if dist.get_backend(group) == "nccl" else None
         def gather(a):
-            t = torch.from_numpy(np.ascontiguousarray(a[q_lo:q_hi]).reshape(q_hi - q_lo, -1))
+            # (explicit trailing size: reshape(0, -1) of an empty query block - world larger than nq - is ambiguous to NumPy, and
+            # a rank that raised here would leave the others waiting in the collective)
+            t = torch.from_numpy(np.ascontiguousarray(a[q_lo:q_hi]).reshape(q_hi - q_lo, int(np.prod(a.shape[1:]))))
             t = TD.all_gather_rows(t.to(dev) if dev is not None else t, nq, group)
             return t.cpu().numpy().reshape(a.shape)
         pos_mean, pos_off, conf = gather(pos_mean), gather(pos_off), gather(conf)

@@ -116,8 +116,19 @@ class LanguageEncoder(nn.Module):
         self.word_embedding = nn.Embedding(len(self.known_words), embedding_dim, padding_idx=0)
         self.lstm = nn.LSTM(input_size=embedding_dim, hidden_size=embedding_dim, bidirectional=True, num_layers=1)
         self.precision = "f16x3"   # arithmetic of the inference recurrence ("fp32": exact fp32 MFMA); the owning model sets it
-        self.kernel_dim = packing.kernel_embed_dim(int(embedding_dim))   # hidden width the kernel runs (zero-padded, see packing.py)
-        self._pack = None
+        self._embedding_dim = int(embedding_dim)
+        self._kernel_dim = None    # hidden width the HIP recurrence runs (zero-padded, packing.kernel_embed_dim): resolved on first use,
+        self._pack = None          # so that a width only the gradient-mode path supports can still be constructed and trained
+
+    @property
+    def kernel_dim(self):
+        if self._kernel_dim is None:
+            self._kernel_dim = packing.kernel_embed_dim(self._embedding_dim)   # raises NotImplementedError past 384
+        return self._kernel_dim
+
+    @kernel_dim.setter
+    def kernel_dim(self, value):
+        self._kernel_dim = int(value)
 
     @property
     def device(self):

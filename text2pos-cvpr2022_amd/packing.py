@@ -105,15 +105,13 @@ def pack_gemm_x3(w_kmajor: torch.Tensor, scale: float) -> torch.Tensor:
 
 
 def kernel_embed_dim(d: int) -> int:
-    """Width the kernels run an embed_dim at: 128 and 256 as they are; anything else up to 384 (the reference's argparse
-    default is 300, training/args.py:19) zero-padded to 384 - the cell head, the biLSTM and the ranking kernel are built for
-    multiples of 128.  Zero weight rows / columns and zero biases keep every padded channel EXACTLY 0 through Linear + ReLU,
+    """Width the kernels run an embed_dim at: the next multiple of 128 up to 384 (128 and 256 as they are; the reference's
+    argparse default 300, training/args.py:19, zero-padded to 384; 64 to 128) - the cell head, the biLSTM and the ranking kernel
+    are built for multiples of 128.  Zero weight rows / columns and zero biases keep every padded channel EXACTLY 0 through Linear + ReLU,
     max / mean aggregation, F.normalize, the kNN distances (they add +0) and the LSTM cell (i = f = o = 1/2, g = 0: c = h = 0),
     so the first `d` columns are the unpadded model's outputs."""
-    if d in (128, 256):
-        return d
     if 1 <= d <= 384:
-        return 384
+        return (d + 127) // 128 * 128
     raise NotImplementedError(f"embed_dim={d}: the kernels are built for 128, 256 and (zero-padded) anything up to 384")
 
 

@@ -112,7 +112,7 @@ class SuperGlueMatch(nn.Module):
         if lang is not None:
             lang.precision = value
     def _object_pack(self):
-        ver = (packing.params_version(self.object_encoder), str(self.device))
+        ver = (packing.params_version(self.object_encoder), str(self.device), self.precision)   # (a flipped precision repacks)
         if self._opack is None or self._opack[0] != ver:
             tensors = packing.pack_cell_weights(self, self.device, x3=self.precision == "f16x3")
             self._opack = (ver, tensors, ops.make_cell_weights(tensors))
@@ -129,7 +129,7 @@ class SuperGlueMatch(nn.Module):
         return code
 
     def _match_pack(self):
-        ver = (packing.params_version(self.superglue), packing.params_version(self.mlp_offsets), str(self.device))
+        ver = (packing.params_version(self.superglue), packing.params_version(self.mlp_offsets), str(self.device), self.precision)
         if self._mpack is None or self._mpack[0] != ver:
             tensors = packing.pack_match_weights(self, self.device, self.precision)
             self._mpack = (ver, tensors, ops.make_match_weights(tensors))
