@@ -306,12 +306,14 @@ def main():
     ap.add_argument("--bn", choices=["calibrated", "random"], default="calibrated",
                     help="BatchNorm running statistics of the random-init model: calibrated on 64 cells of the workload "
                          "(default) or drawn at random (SURVEY 8(d); embeddings then collapse onto one direction)")
-    ap.add_argument("--cell-streams", type=int, choices=[1, 2], default=1,
-                    help="HIP streams of the cell encoder in the timed region: 2 = the two halves of the batch run "
-                         "concurrently (own workspaces).  Default 1: an event pair around a launch then times that kernel "
-                         "alone, which is what `roofline` and the rocprofv3 summary need; the two-stream rate is measured "
-                         "right after the timed region and reported as `two_stream`")
-    ap.add_argument("--no-two-stream", action="store_true", help="skip the extra two-stream measurement")
+    ap.add_argument("--cell-streams", type=int, choices=[0, 1, 2, 3, 4], default=0,
+                    help="HIP streams of the cell encoder in the timed region.  0 (default) = the product's default "
+                         "(CellRetrievalNetwork.encode_objects_packed: two parts of the batch on two streams from 2,048 cells up); "
+                         "1 = everything on one stream: an event pair around a launch then times that kernel alone - the "
+                         "rocprofv3 evidence runs use it, and a multi-stream run measures its per-kernel times (`roofline`, "
+                         "`kernel_ms_per_step`) in a single-stream pass of the same step right after the timed region")
+    ap.add_argument("--no-two-stream", action="store_true", help="(kept for old command lines; no effect)")
+    ap.add_argument("--prof-steps", type=int, default=5, help="steps of the single-stream per-kernel timing pass")
     ap.add_argument("--tuning", type=int, default=0, help="t2p_cell_config.tuning (A/B between equivalent execution plans)")
     ap.add_argument("--no-fp32-pass", action="store_true", help="skip the extra exact-fp32 pass behind the timed region")
     ap.add_argument("--no-extras", action="store_true",
@@ -425,7 +427,7 @@ def main():
                 # the fp16-range guard accumulates in a device word during the step; it is read once after the timed region
                 return model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
                                                    chunk_objects=args.chunk_objects, check_overflow=False,
-                                                   streams=args.cell_streams)
+                                                   streams=args.cell_streams or None)
 
             def encoded_queries(lo, hi):
                 assert (lo, hi) == (q_lo, q_hi)
@@ -456,14 +458,15 @@ def main():
     barrier()
     log("timed region")
     gather_events.clear()
-    ops.profile_enable(True)
+    single = args.cell_streams == 1 or (args.cell_streams == 0 and args.cells < 2048)   # (then the timed region itself is profiled)
+    ops.profile_enable(single)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         idx, score = step()
     barrier()
     elapsed = time.perf_counter() - t0
     ops.profile_enable(False)
-    prof = ops.profile_report()
+    prof, prof_steps = (ops.profile_report(), args.steps) if single else ({}, 0)
     log(f"{args.steps} steps in {elapsed:.3f}s")
     guard_code = model.overflow_detected() if args.precision == "f16x3" else 0
     if guard_code and not os.environ.get("T2P_ABLATION_RUN"):   # (ablation builds of the library compute garbage on purpose)
@@ -487,33 +490,36 @@ def main():
                             "for the slowest rank's encoder)"}
         assert len(gather_events) == args.steps, (len(gather_events), args.steps)
 
-    # ---- the same step with the cell encoder's two halves on two HIP streams (each kernel launch fills the CUs, so what
-    # overlaps is one half's work under the tails of the other's kernels and under the small launch-bound kernels)
-    two_stream = None
-    if args.cell_streams == 1 and not args.no_two_stream:
-        saved_streams, args.cell_streams = args.cell_streams, 2
+    # ---- per-kernel times: the same step with the whole cell encoder on ONE stream (an event pair around a launch then times
+    # that kernel alone), hipEvents on the launch stream.  A multi-stream timed region cannot supply them.
+    single_stream = None
+    if not single:
+        saved_streams, args.cell_streams = args.cell_streams, 1
         try:
             step()
             barrier()
+            ops.profile_enable(True)
             t1 = time.perf_counter()
-            for _ in range(args.steps):
-                idx2, _ = step()
+            for _ in range(args.prof_steps):
+                idx1, _ = step()
             barrier()
-            e2 = time.perf_counter() - t1
+            e1 = time.perf_counter() - t1
+            ops.profile_enable(False)
+            prof, prof_steps = ops.profile_report(), args.prof_steps
         finally:
             args.cell_streams = saved_streams
         if world > 1:
-            t = torch.tensor([e2], dtype=torch.float64, device=dev)
+            t = torch.tensor([e1], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e2 = float(t.item())
-        assert torch.equal(idx2, idx), "two-stream run retrieved different cells"
-        two_stream = {"ms_per_step": e2 / args.steps * 1e3, "value": (n_cells_total + n_q_total) / (e2 / args.steps),
-                      "unit": "cells+queries/s", "steps": args.steps,
-                      "note": "same step, cell batch cut into two halves on two HIP streams (encode_objects_packed(streams=2)); "
-                              "identical top-k; not the headline because per-kernel event timings overlap in this mode"}
+            e1 = float(t.item())
+        assert torch.equal(idx1, idx), "the single-stream pass retrieved different cells"
+        single_stream = {"ms_per_step": e1 / args.prof_steps * 1e3, "value": (n_cells_total + n_q_total) / (e1 / args.prof_steps),
+                         "unit": "cells+queries/s", "steps": args.prof_steps,
+                         "note": "same step with the cell encoder on one HIP stream (encode_objects_packed(streams=1)), identical "
+                                 "top-k: the pass `kernel_ms_per_step` and `roofline` are measured in"}
         if guard_code == 0 and args.precision == "f16x3" and model.overflow_detected():
-            raise SystemExit("fp16-range guard fired in the two-stream run")
-        log(f"two streams: {two_stream['ms_per_step']:.2f} ms per step")
+            raise SystemExit("fp16-range guard fired in the single-stream pass")
+        log(f"single stream: {single_stream['ms_per_step']:.2f} ms per step")
 
     # ---- one pass of the same step on the exact fp32 MFMA path (outside the headline timing), and the precision evidence
     fp32_info = None
@@ -624,16 +630,16 @@ def main():
         e3 = e_lvl[2]
         launches, total_ms = prof.get(DOMINANT, (0, 0.0))
         flops_per_step = 2.0 * 256 * 256 * e3
-        achieved = (flops_per_step * args.steps) / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
+        achieved = (flops_per_step * prof_steps) / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
         peak = F16_MFMA_PEAK_TFLOPS if args.precision == "f16x3" else FP32_MFMA_PEAK_TFLOPS
-        phases = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        phases = {k: round(v[1] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         # FPS / ball query are scan-type (latency / issue bound); their compulsory read is the object's xyz + rgb
         # (6,168 B): report the HBM rate that corresponds to, as overhead against the encoder's MFMA bound
         sg_launches, sg_ms = prof.get("sample_group", (0, 0.0))
         if sg_ms > 0:
-            gbps = 6168.0 * n_obj * args.steps / (sg_ms * 1e-3) / 1e9
+            gbps = 6168.0 * n_obj * prof_steps / (sg_ms * 1e-3) / 1e9
             phase_rates["roofline"]["sample_group"] = {"bound": "latency / issue (scan)", "achieved_gbps": gbps, "peak_gbps": 8000.0,
-                                                       "frac": gbps / 8000.0, "ms_per_step": sg_ms / args.steps}
+                                                       "frac": gbps / 8000.0, "ms_per_step": sg_ms / prof_steps}
         # HBM traffic of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this command;
         # bench.py cannot host rocprofv3 itself): newest profiles/*_pmc_traffic.json, kernel k_ws_sa<256, 256, ...>
         traffic, traffic_source = None, None
@@ -659,8 +665,8 @@ def main():
                                   32 * 64 + (6 * 32 if sa1_per_edge else 0)),
                                  ("ws_edge_sa_k128_n128", e_lvl[1], 128 * 128), ("ws_edge_sa_k256_n256", e_lvl[2], 256 * 256)):
             ln, ms = prof.get(name, (0, 0.0))
-            tf = 2.0 * hc * rows_l * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else None
-            sa_levels[name] = {"edge_rows_per_step": rows_l, "ms_per_step": ms / args.steps, "achieved_tflops": tf,
+            tf = 2.0 * hc * rows_l * prof_steps / (ms * 1e-3) / 1e12 if ms > 0 else None
+            sa_levels[name] = {"edge_rows_per_step": rows_l, "ms_per_step": ms / prof_steps, "achieved_tflops": tf,
                                "frac_of_peak": tf / peak if tf else None,
                                "frac_of_f16x3_ceiling": (3.0 * tf / peak if tf else None) if args.precision == "f16x3" else None}
         whole_step = {"executed_flop_per_step": ex, "achieved_tflops": ex["total"] / (ms_per_step * 1e-3) / 1e12,
@@ -682,11 +688,17 @@ def main():
                                   ("calibrated by one train-mode pass over 64 cells (deviation from SURVEY 8(d), which randomises "
                                    "them: random statistics collapse every embedding onto one direction; --bn random restores it)"
                                    if args.bn == "calibrated" else "random (SURVEY 8(d))"),
+                       "cell_streams": ("product default: 2 parts of the cell batch on 2 HIP streams" if args.cell_streams == 0 and not single
+                                        else (args.cell_streams or 1)),
                        "parallelism": f"cells+queries sharded x{world}, 1 all-gather" if world > 1 else "single GPU"},
             "kernel_ms_per_step": phases, "phase_rates": phase_rates,
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_source, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
+                         "measured_in": ("the timed region (single stream)" if single_stream is None else
+                                         f"a single-stream pass of the same step right behind the timed region ({prof_steps} steps; hipEvents on "
+                                         "the launch stream): in the multi-stream timed region an event pair around one launch also spans "
+                                         "the other stream's kernels"),
                          "algorithmic_flop_per_step": flops_per_step, "sa3_edge_rows_per_step": e3,
                          "sa_levels": sa_levels, "whole_step": whole_step,
                          "note": ("algorithmic FLOPs = 2*256*256 per SA3 edge row; the f16x3 path executes 3 f16 MFMA FLOPs per "
@@ -695,8 +707,8 @@ def main():
             "host_generation_s": round(gen_s, 2),
             "fp16_range_guard": "clear" if args.precision == "f16x3" else "n/a (fp32)",
         }
-        if two_stream:
-            out["two_stream"] = two_stream
+        if single_stream:
+            out["single_stream"] = single_stream
         if fp32_info:
             out.update(fp32_info)
         if exchange:

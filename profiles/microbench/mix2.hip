@@ -146,6 +146,10 @@ int main() {
         (void)hipMemcpy(in, h, 1 << 22, hipMemcpyHostToDevice);
         free(h);
     }
+#ifdef MIX2_LONG   // power probe (profiles/power_probe.sh): the bare MFMA loop, back to back, for several seconds
+    for (int rep = 0; rep < 1500; rep++) run<512, 2, 1, 1, 0, 0, 0, 0, 0, 0>(in, out, "MFMA only (long)");
+    return 0;
+#endif
     BOTH(512, 2, 1, 0, 0, 0, 0, 0, 0, "MFMA only");
     BOTH(512, 2, 1, 6, 0, 0, 0, 0, 0, "+ 6 v_fma");
     BOTH(512, 2, 1, 15, 0, 0, 0, 0, 0, "+ 15 v_fma");
@@ -162,5 +166,9 @@ int main() {
     BOTH(256, 1, 1, 0, 0, 0, 0, 0, 0, "1 wave/SIMD, MFMA only");
     BOTH(256, 1, 1, 15, 0, 0, 0, 0, 0, "1 wave/SIMD + 15 v_fma");
     BOTH(256, 1, 1, 6, 0, 6, 2, 1, 1, "1 wave/SIMD scalarised mix");
+    // the same bare MFMA loop on ALL-ZERO operands: if the chip were not power-limited the operand values would not matter
+    (void)hipMemset(in, 0, 1 << 22);
+    BOTH(512, 2, 1, 0, 0, 0, 0, 0, 0, "MFMA only, ZERO operands");
+    BOTH(256, 1, 1, 0, 0, 0, 0, 0, 0, "1 wave/SIMD, MFMA only, ZERO operands");
     return 0;
 }

@@ -148,7 +148,7 @@ class CellRetrievalNetwork(nn.Module):
                                       "torch.no_grad(), or put the model in train() for the training-mode path")
 
     def encode_objects_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, cell_ptr_dev=None, want_trace=False,
-                              chunk_objects=0, class_idx=None, color_idx=None, check_overflow=True, streams=1):
+                              chunk_objects=0, class_idx=None, color_idx=None, check_overflow=True, streams=None):
         """Device-resident packed inputs: xyz/rgb [Nobj, P, 3], center/mean_rgb [Nobj, 3] (fp32, on self.device),
         cell_ptr int32 [B+1] on the host.  Returns [B, D] L2-normalised.  In train() mode (training/coarse.py:32) the
         batch-statistics path of train_cell.py runs instead of the folded inference kernels and the result carries a
@@ -156,9 +156,12 @@ class CellRetrievalNetwork(nn.Module):
         check_overflow (f16x3 only): read the fp16-range guard word after the launch (one host synchronisation; the
         reference's callers move the result to the host right away, training/coarse.py:115) and act as `on_overflow` says.
         Pipelined callers pass False and call overflow_detected() once their stream has drained.
-        streams=2: the batch is cut into two halves (whole cells) that run on the current stream and on a second HIP
-        stream with its own workspace; the kernels of a call fill every CU, so the gain is the other half's work under each
-        kernel's tail (measured 1.8 %, profiles/microbench/two_stream_overlap.py).  Cells are independent: same result."""
+        streams = n > 1: the batch is cut into n parts (whole cells, equal object counts) that run on the current stream and
+        on n - 1 further HIP streams, each with its own workspace: the latency- and store-bound kernels of one part (FPS / ball
+        query, the layer-1 tables) then run under the matrix-bound kernels of another - the chip is power-limited under matrix
+        load, so what runs beside an MFMA kernel's tail or on its idle issue slots is nearly free (-2.5 % per step with two).
+        Cells are independent: same result, bit for bit.  None (default): 2 from 2,048 cells up, else 1; 1 = everything on
+        the current stream (what per-kernel event timings and the rocprofv3 evidence runs need)."""
         if self.training and not want_trace:
             if self.kernel_dim != self.embed_dim:
                 raise NotImplementedError(f"training-mode path at embed_dim={self.embed_dim}: built for 128 and 256")
@@ -170,9 +173,11 @@ class CellRetrievalNetwork(nn.Module):
             cell_ptr_dev = torch.from_numpy(cp).to(self.device)
         if "color" not in self.args.use_features and not getattr(self.args, "class_embed", False):
             rgb = torch.zeros_like(rgb)   # models/object_encoder.py:86-90: the PointNet++ then sees x = 0
-        if streams == 2 and not want_trace and cp.shape[0] > 2 and self.precision in ("f16x3", "fp32"):
-            return self._trim(self._encode_two_streams(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx,
-                                                       color_idx, check_overflow))
+        if streams is None:
+            streams = 2 if cp.shape[0] - 1 >= 2048 else 1
+        if streams > 1 and not want_trace and cp.shape[0] - 1 >= streams:
+            return self._trim(self._encode_multi_stream(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx,
+                                                        color_idx, check_overflow, int(streams)))
         cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx)
         out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
         if check_overflow and self.precision == "f16x3" and cp.shape[0] > 1:
@@ -187,21 +192,30 @@ class CellRetrievalNetwork(nn.Module):
                 out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
         return self._trim(out)
 
-    def _encode_two_streams(self, xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx, color_idx,
-                            check_overflow):
+    def _encode_multi_stream(self, xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx, color_idx,
+                             check_overflow, n_streams):
         dev = self.device
         n_cells = cp.shape[0] - 1
-        half = int(np.searchsorted(cp, cp[-1] // 2))          # first cell whose start lies past half of the objects
-        half = min(max(half, 1), n_cells - 1)
+        # part boundaries: first cell whose start lies past k / n of the objects (whole cells, at least one per part)
+        cuts = [0]
+        for k in range(1, n_streams):
+            c = int(np.searchsorted(cp, cp[-1] * k // n_streams))
+            cuts.append(min(max(c, cuts[-1] + 1), n_cells - (n_streams - k)))
+        cuts.append(n_cells)
         main = torch.cuda.current_stream(dev)
-        if getattr(self, "_aux_stream", None) is None:
-            self._aux_stream = torch.cuda.Stream(device=dev)
-        aux = self._aux_stream
+        aux = getattr(self, "_aux_streams", None) or []
+        while len(aux) < n_streams - 1:
+            aux.append(torch.cuda.Stream(device=dev))
+        self._aux_streams = aux
         out = torch.empty((n_cells, self.kernel_dim), dtype=torch.float32, device=dev)
-        out.record_stream(aux)
         pack = self._cell_pack()
-        aux.wait_stream(main)
-        for (c0, c1), st, tag in (((half, n_cells), aux, "encode_cells#2"), ((0, half), main, "encode_cells")):
+        for st in aux[: n_streams - 1]:
+            st.wait_stream(main)
+            out.record_stream(st)
+        # the side streams' parts are launched first, the current stream's part (part 0) last
+        for part in list(range(1, n_streams)) + [0]:
+            c0, c1 = cuts[part], cuts[part + 1]
+            st = main if part == 0 else aux[part - 1]
             o0, o1 = int(cp[c0]), int(cp[c1])
             with torch.cuda.stream(st):
                 sub = [t[o0:o1] for t in (xyz, rgb, center, mean_rgb)]
@@ -209,11 +223,13 @@ class CellRetrievalNetwork(nn.Module):
                 co = None if color_idx is None else color_idx[o0:o1].contiguous()
                 cfg = self._cell_config(xyz.shape[1], chunk_objects, ci, co)
                 cpd = cell_ptr_dev[c0: c1 + 1] - o0 if o0 else cell_ptr_dev[c0: c1 + 1]
-                out[c0:c1] = ops.encode_cells(*sub, cp[c0: c1 + 1] - o0, cpd.contiguous(), pack, cfg, False, ws_tag=tag)
-                if st is aux:
+                out[c0:c1] = ops.encode_cells(*sub, cp[c0: c1 + 1] - o0, cpd.contiguous(), pack, cfg, False,
+                                              ws_tag="encode_cells" if part == 0 else f"encode_cells#{part + 1}")
+                if st is not main:
                     for t in (xyz, rgb, center, mean_rgb, cell_ptr_dev):
-                        t.record_stream(aux)
-        main.wait_stream(aux)
+                        t.record_stream(st)
+        for st in aux[: n_streams - 1]:
+            main.wait_stream(st)
         if check_overflow and self.precision == "f16x3" and self.overflow_detected():
             if self.on_overflow != "fp32":
                 raise FloatingPointError("f16x3 path: an activation left fp16's range; construct the model with "
@@ -221,8 +237,8 @@ class CellRetrievalNetwork(nn.Module):
             warnings.warn("f16x3 path: an activation left fp16's range; recomputing on the exact fp32 path", RuntimeWarning)
             saved, self.precision = self.precision, "fp32"
             try:
-                return self._encode_two_streams(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx,
-                                                color_idx, False)
+                return self._encode_multi_stream(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx,
+                                                 color_idx, False, n_streams)
             finally:
                 self.precision = saved
         return out
@@ -280,6 +296,30 @@ class CellRetrievalNetwork(nn.Module):
         """objects: List[List[Object3d]], object_points: List[Batch] (one PyG-style batch per cell)
         -> [B, D] fp32, L2-normalised (models/cell_retrieval.py:77-107).  train() mode: see encode_objects_packed."""
         n_pts = int(getattr(self.args, "pointnet_numpoints", 256))
+        n_cells = len(objects)
+        if n_cells >= 256 and not self.training and len(object_points) == n_cells:
+            # two halves: the kernels of the first half run while the host packs the second (packing a 512-cell batch - two
+            # 25 MB concatenations into pinned memory plus the per-cell bookkeeping - takes about as long as encoding it)
+            half = n_cells // 2
+            outs = [self._encode_objects_once(objects[a:b], object_points[a:b], n_pts, check_overflow=False)
+                    for a, b in ((0, half), (half, n_cells))]
+            out = torch.cat(outs)
+            if self.precision == "f16x3":
+                code = self.overflow_detected()
+                if code:
+                    if self.on_overflow != "fp32":
+                        raise FloatingPointError(f"f16x3 path: an activation left fp16's range (guard code {code:#x}); construct "
+                                                 "the model with precision=\"fp32\" or on_overflow=\"fp32\"")
+                    warnings.warn("f16x3 path: an activation left fp16's range; recomputing on the exact fp32 path", RuntimeWarning)
+                    saved, self.precision = self.precision, "fp32"
+                    try:
+                        return self.encode_objects(objects, object_points)
+                    finally:
+                        self.precision = saved
+            return out
+        return self._encode_objects_once(objects, object_points, n_pts)
+
+    def _encode_objects_once(self, objects, object_points, n_pts, check_overflow=True):
         dev = self.device
         # models/object_encoder.py:86-90: without the "color" feature the PointNet++ sees x = 0 - the colours then never travel
         skip_rgb = "color" not in self.args.use_features
@@ -296,7 +336,8 @@ class CellRetrievalNetwork(nn.Module):
         if getattr(self.args, "color_embed", False):
             color_idx = to(torch.tensor([oe.known_colors[o.get_color_text()] for objs in objects for o in objs],
                                         dtype=torch.int32))
-        return self.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr, class_idx=class_idx, color_idx=color_idx)
+        return self.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr, class_idx=class_idx, color_idx=color_idx,
+                                          check_overflow=check_overflow)
 
     def encode_raw_objects(self, objects, generator: np.random.Generator, rotate_degrees: float = None):
         """objects: List[List[Object3d]] with RAW point sets.  The dataloader's per-object transform chain

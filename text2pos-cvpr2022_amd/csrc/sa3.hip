@@ -18,7 +18,10 @@
 // VALU instruction next to the MFMA stream costs issue time on the same SIMD (profiles/microbench/mix2.hip), scalar ones do not.
 #include "t2p_common.h"
 
-#ifndef T2P_SA3_ABL   // development only (results wrong): 1 = no atomics
+// T2P_SA3_ABL, development only (results wrong, timing valid): 1 = no atomics, 2 = no row gathers, 4 = no staging stores to LDS,
+// 8 = no operand reads inside the MFMA loop, 16 = no third MFMA, 32 = no per-batch barrier, 64 = no staging arithmetic,
+// 128 = no per-object phases (drain, centroid table)
+#ifndef T2P_SA3_ABL
 #define T2P_SA3_ABL 0
 #endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
@@ -212,7 +215,11 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
         const uint32_t g = (uint32_t)(valid(it) ? it.g : g_end - 1);
         const uint32_t srow = (d & 0x80u) ? ((uint32_t)it.sb + src) : (g * (uint32_t)ND + src);
         const float* rowp = p.A + (size_t)srow * K;                       // scalar 64-bit row base
-        sa[k] = *(const f32x4*)((const char*)rowp + lane16);
+        if constexpr (T2P_SA3_ABL & 2) {
+            const float f = __uint_as_float(((uint32_t)(uintptr_t)rowp & 0xFFFFu) | 0x3f000000u);
+            sa[k] = f32x4{f, f, f, f};
+        } else
+            sa[k] = *(const f32x4*)((const char*)rowp + lane16);
         boff[k] = dl * (uint32_t)(K * 4);
         const uint32_t dv = dl * (uint32_t)(N * 4);
         if (k == 0) dpack_lo = dv;
@@ -223,24 +230,37 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
     auto load_b = [&](int k) { bq = *(const f32x4*)((const char*)btab + boff[k] + lane16); };
     auto stage_a = [&](int buf, int k) {         // v = relu(A_j - B_i), hi = fp16(v) -> hi plane
         _Float16* dsth = tile + buf * 2 * PLANE;
-        const f32x4 t = sa[k] - bq;
-#pragma unroll
-        for (int e = 0; e < 4; e++) vv[e] = fmaxf(t[e], 0.f);
-        vh01 = cvt_pk_f16(vv[0], vv[1]);
-        vh23 = cvt_pk_f16(vv[2], vv[3]);
         uint2 ph;
-        ph.x = __builtin_bit_cast(uint32_t, vh01);
-        ph.y = __builtin_bit_cast(uint32_t, vh23);
-        *(uint2*)(dsth + (4 * wave + k) * LDHH + c4 * 4) = ph;
+        if constexpr (T2P_SA3_ABL & 64) {
+            ph.x = __float_as_uint(sa[k][0]) ^ __float_as_uint(bq[0]);
+            ph.y = __float_as_uint(sa[k][1]) ^ __float_as_uint(bq[1]);
+            vv = sa[k];
+        } else {
+            const f32x4 t = sa[k] - bq;
+#pragma unroll
+            for (int e = 0; e < 4; e++) vv[e] = fmaxf(t[e], 0.f);
+            vh01 = cvt_pk_f16(vv[0], vv[1]);
+            vh23 = cvt_pk_f16(vv[2], vv[3]);
+            ph.x = __builtin_bit_cast(uint32_t, vh01);
+            ph.y = __builtin_bit_cast(uint32_t, vh23);
+        }
+        if constexpr (T2P_SA3_ABL & 4) asm volatile("" ::"v"(ph.x), "v"(ph.y));
+        else *(uint2*)(dsth + (4 * wave + k) * LDHH + c4 * 4) = ph;
     };
     auto stage_b = [&](int buf, int k) {         // lo = fp16(v - hi) -> lo plane
         _Float16* dsth = tile + buf * 2 * PLANE;
-        const fp16x2 l01 = cvt_pk_f16(sub_half<0>(vv[0], vh01), sub_half<1>(vv[1], vh01));
-        const fp16x2 l23 = cvt_pk_f16(sub_half<0>(vv[2], vh23), sub_half<1>(vv[3], vh23));
         uint2 pl;
-        pl.x = __builtin_bit_cast(uint32_t, l01);
-        pl.y = __builtin_bit_cast(uint32_t, l23);
-        *(uint2*)(dsth + PLANE + (4 * wave + k) * LDHH + c4 * 4) = pl;
+        if constexpr (T2P_SA3_ABL & 64) {
+            pl.x = __float_as_uint(vv[2]);
+            pl.y = __float_as_uint(vv[3]);
+        } else {
+            const fp16x2 l01 = cvt_pk_f16(sub_half<0>(vv[0], vh01), sub_half<1>(vv[1], vh01));
+            const fp16x2 l23 = cvt_pk_f16(sub_half<0>(vv[2], vh23), sub_half<1>(vv[3], vh23));
+            pl.x = __builtin_bit_cast(uint32_t, l01);
+            pl.y = __builtin_bit_cast(uint32_t, l23);
+        }
+        if constexpr (T2P_SA3_ABL & 4) asm volatile("" ::"v"(pl.x), "v"(pl.y));
+        else *(uint2*)(dsth + PLANE + (4 * wave + k) * LDHH + c4 * 4) = pl;
     };
     auto put_dst = [&](int slot, uint32_t lo, uint32_t hi) {
         if (lane == 0) *(uint2*)(dstl + slot * TR + 4 * wave) = uint2{lo, hi};
@@ -294,12 +314,12 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
             if (half > 0 && !valid(it_c)) break;
             {
                 bool fence = false;
-                if (flush_g >= 0) {                     // the object whose last atomics ran in the previous batch drains
+                if (flush_g >= 0 && !(T2P_SA3_ABL & 128)) {     // the object whose last atomics ran in the previous batch drains
                     flush(flush_g);
                     flush_g = -1;
                     fence = true;                       // the next object's atomics (inside this batch) must not overtake the drain
                 }
-                if (valid(it_s) && it_s.r0 == 0) {      // batch t+1 opens a new object: its centroid table replaces the current one
+                if (valid(it_s) && it_s.r0 == 0 && !(T2P_SA3_ABL & 128)) {   // batch t+1 opens a new object: its centroid table replaces the current one
                     build_b(it_s.g);
                     fence = false;
                 }
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
 #pragma unroll
             for (int j = 0; j < S16; j++) {
                 SB();
-                if (j + 1 < S16) {
+                if (j + 1 < S16 && !(T2P_SA3_ABL & 8)) {
                     n_hi = *(const half8*)(hrow + (j + 1) * 8);
                     n_lo = *(const half8*)(hrow + PLANE + (j + 1) * 8);
                 }
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
                     lds_fmax((float*)((char*)acc_col + off), prev[e]);
                 }
                 SB();
-                acc = MFMA16(a_lo, w_hi[j], acc);
+                if constexpr (!(T2P_SA3_ABL & 16)) acc = MFMA16(a_lo, w_hi[j], acc);
                 a_hi = n_hi;
                 a_lo = n_lo;
                 if (j == S16 / 2 - 1) it_n = advance(it_m);
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
             it_s = it_g;
             it_g = it_m;
             it_m = it_n;
-            __syncthreads();
+            if constexpr (!(T2P_SA3_ABL & 32)) __syncthreads();
         }
     }
     if (flush_g >= 0) {

@@ -199,11 +199,9 @@ class ObjectMeansCache:
         if e is None:
             return None
         kept, snapshot, center, color = e
-        if kept is not objs or len(objs) != len(snapshot):
+        # (tuple comparison short-cuts on identity; Object3d defines no __eq__, so equal means the very same objects)
+        if kept is not objs or tuple(objs) != snapshot:
             return None
-        for a, b in zip(objs, snapshot):
-            if a is not b:
-                return None
         return center, color
 
     def put(self, objs, center, color):
@@ -262,24 +260,29 @@ _EXPECT_BATCH = {}
 _CAT_POOL = None
 
 
+def _pack_pool():
+    global _CAT_POOL
+    if _CAT_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _CAT_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="t2p-pack")
+    return _CAT_POOL
+
+
 def _cat_into(tensors, out: torch.Tensor, rows_per_item, threads: int = 4):
     """torch.cat(tensors, out=out) in `threads` contiguous pieces on a small thread pool (torch.cat releases the GIL; one
     thread moves ~5 GB/s, and a 512-cell call concatenates 2 x 25 MB)."""
-    global _CAT_POOL
     n = len(tensors)
     if n < 64 or threads <= 1:
         torch.cat(tensors, out=out)
         return
-    if _CAT_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _CAT_POOL = ThreadPoolExecutor(max_workers=threads, thread_name_prefix="t2p-pack")
+    pool = _pack_pool()
     ends = np.cumsum(rows_per_item)
     cuts = [0] + [int(np.searchsorted(ends, ends[-1] * (k + 1) // threads, side="left")) + 1 for k in range(threads - 1)] + [n]
     cuts = sorted(set(min(c, n) for c in cuts))
     jobs = []
     for a, b in zip(cuts[:-1], cuts[1:]):
         r0 = int(ends[a - 1]) if a > 0 else 0
-        jobs.append(_CAT_POOL.submit(torch.cat, tensors[a:b], out=out[r0: int(ends[b - 1])]))
+        jobs.append(pool.submit(torch.cat, tensors[a:b], out=out[r0: int(ends[b - 1])]))
     for j in jobs:
         j.result()
 
@@ -326,11 +329,11 @@ def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_co
 
     def flat(which):
         ts = [getattr(p, which) for p in object_points]
-        return [t if t.dtype == torch.float32 else t.float() for t in ts]
+        return [(t if t.dtype == torch.float32 else t.float()) if not t.requires_grad else t.detach().float() for t in ts]
 
     if on_device:
-        xyz = torch.cat(flat("pos")).detach().reshape(n_obj, n_pts, 3)
-        rgb = torch.cat(flat("x")).detach().reshape(n_obj, n_pts, 3) if want_rgb else None
+        xyz = torch.cat(flat("pos")).reshape(n_obj, n_pts, 3)
+        rgb = torch.cat(flat("x")).reshape(n_obj, n_pts, 3) if want_rgb else None
         which = None
     else:
         which = staging.next_set() if staging is not None else None
@@ -342,22 +345,23 @@ def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_co
         xyz = host("xyz", n_obj * n_pts * 3).view(n_obj * n_pts, 3)
         rows = counts * n_pts
         if n_cells:
-            _cat_into([t.detach() for t in flat("pos")], xyz, rows)
+            _cat_into(flat("pos"), xyz, rows)
         xyz = xyz.view(n_obj, n_pts, 3)
         rgb = None
         if want_rgb:
             rgb = host("rgb", n_obj * n_pts * 3).view(n_obj * n_pts, 3)
             if n_cells:
-                _cat_into([t.detach() for t in flat("x")], rgb, rows)
+                _cat_into(flat("x"), rgb, rows)
             rgb = rgb.view(n_obj, n_pts, 3)
     if zero_color and not skip_rgb:
         rgb = torch.zeros((n_obj, n_pts, 3), dtype=torch.float32, device=xyz.device)
     small = (staging.buffer(which, "means", n_obj * 6) if (staging is not None and which is not None)
              else torch.empty(n_obj * 6, dtype=torch.float32, pin_memory=pin)).view(2, n_obj, 3)
     small_np = small.numpy()
-    for i, objs in enumerate(objects):
-        lo, hi = cell_ptr[i], cell_ptr[i + 1]
-        small_np[0, lo:hi], small_np[1, lo:hi] = object_means(objs, means_cache)
+    if n_cells:     # (one concatenation per array: a NumPy slice assignment per cell costs more than the cache lookup it follows)
+        rows = [object_means(objs, means_cache) for objs in objects]   # (threads do not help here: the per-cell work is GIL-bound)
+        np.concatenate([r[0] for r in rows], axis=0, out=small_np[0])
+        np.concatenate([r[1] for r in rows], axis=0, out=small_np[1])
     center, mean_rgb = small[0], small[1]
     if device is not None:
         to = lambda t: None if t is None else t.to(device, non_blocking=True)
