@@ -68,6 +68,20 @@ def _calibrate_batchnorm_packed(om, xyz, rgb, center, mean_rgb, cell_ptr):
         m.momentum = 0.1
 
 
+def _global_knn(knn, cell_ptr):
+    """t2p_cell_trace.knn_idx rows are local to the library's internal chunk (whole cells, at most DEFAULT_CHUNK_OBJECTS
+    objects): add each object's chunk start, keep -1."""
+    from text2pos_amd.ops import DEFAULT_CHUNK_OBJECTS
+    knn = np.asarray(knn).astype(np.int64)
+    chunk0 = np.zeros(knn.shape[0], dtype=np.int64)
+    lo = 0
+    for c in range(len(cell_ptr) - 1):
+        if cell_ptr[c + 1] - lo > DEFAULT_CHUNK_OBJECTS:
+            lo = cell_ptr[c]
+        chunk0[cell_ptr[c]: cell_ptr[c + 1]] = lo
+    return np.where(knn >= 0, knn + chunk0[:, None], -1)
+
+
 def _knn_flips(knn_a, knn_b, embn64, cell_ptr):
     """Objects whose DynamicEdgeConv neighbour lists differ between two runs, and the evidence that every such difference
     is a near-tie: the squared distances (float64, from one run's normalised object embeddings) of the neighbours that
@@ -130,39 +144,39 @@ def test_headline_config_full_size_parity(oracle_model, vocab, checkpoint):
     d_obj = (tr3["obj_emb"] - tr32["obj_emb"]).abs().max().item()
     assert d_obj < TOL, f"object embeddings, f16x3 vs fp32 over {xyz.shape[0]} objects: {d_obj:.3e}"
     embn64 = torch.nn.functional.normalize(tr32["obj_emb"].double(), dim=-1).cpu().numpy()
-    # (knn_idx rows are local to the internal chunk; both runs chunk alike, and the distances only need the members)
-    chunk0 = np.zeros(xyz.shape[0], dtype=np.int64)
-    lo = 0
-    from text2pos_amd.ops import DEFAULT_CHUNK_OBJECTS
-    for c in range(n_cells):                                            # chunk starts: whole cells, <= the default chunk
-        if cell_ptr[c + 1] - lo > DEFAULT_CHUNK_OBJECTS:
-            lo = cell_ptr[c]
-        chunk0[cell_ptr[c]: cell_ptr[c + 1]] = lo
-    ka, kb = tr3["knn_idx"].cpu().numpy().astype(np.int64), tr32["knn_idx"].cpu().numpy().astype(np.int64)
-    ka, kb = np.where(ka >= 0, ka + chunk0[:, None], -1), np.where(kb >= 0, kb + chunk0[:, None], -1)
+    ka, kb = _global_knn(tr3["knn_idx"].cpu().numpy(), cell_ptr), _global_knn(tr32["knn_idx"].cpu().numpy(), cell_ptr)
     cell_of = np.repeat(np.arange(n_cells), np.diff(cell_ptr))
     assert (cell_of[np.maximum(ka, 0)] == cell_of[:, None])[ka >= 0].all()       # neighbours stay inside their cell
     flip_cells, worst = _knn_flips(ka, kb, embn64, cell_ptr)
     assert worst < 1e-4, f"a neighbour-list difference that is not a near-tie (distance gap {worst:.2e})"
-    assert len(flip_cells) <= n_cells // 200, f"{len(flip_cells)} cells with kNN tie flips"
+    # observed with the round-to-nearest split: 6 of 12,000 (round 3's toward-zero split: 13); the bar is ~3 x that
+    assert len(flip_cells) <= 20, f"{len(flip_cells)} cells with kNN tie flips between the two arithmetic paths"
+    print(f"[headline gate, {checkpoint}] f16x3 vs fp32 over 12,000 cells: object embeddings {d_obj:.2e}, {len(flip_cells)} cells with "
+          f"a kNN near-tie flip")
     same = np.ones(n_cells, dtype=bool)
     same[flip_cells] = False
     per_cell = (x3 - f32).abs().max(dim=1).values.cpu().numpy()
     d = float(per_cell[same].max())
     assert d < TOL, f"f16x3 vs fp32 over the {int(same.sum())} cells with identical graphs: max|delta| = {d:.3e}"
-    # (b) both against the oracle on >= 128 drawn cells + the extreme sizes the generator produces (n = 6 and n = 26),
-    #     stage by stage: the sub-batch is its own call (cells do not depend on their neighbours in a batch: bit-identical)
+    # (b) both against the oracle on drawn cells (4,096 with the calibrated checkpoint, 128 with the golden one) + the extreme
+    #     sizes the generator produces (n = 6 and n = 26), stage by stage: the sub-batch is its own call (cells do not depend
+    #     on their neighbours in a batch: bit-identical)
     sizes = cell_ptr[1:] - cell_ptr[:-1]
     assert sizes.min() == 6 and sizes.max() == 26
     rng = np.random.default_rng(7)
-    pick = set(rng.choice(n_cells, 128, replace=False).tolist())
+    pick = set(rng.choice(n_cells, 4096 if checkpoint == "calibrated" else 128, replace=False).tolist())
     pick |= set(np.flatnonzero(sizes == 6)[:8].tolist()) | set(np.flatnonzero(sizes == 26)[:8].tolist())
     pick = sorted(pick)
     sel = torch.tensor(pick)
     sub, sub_ptr = _sub_batch((xyz, rgb, center, mean_rgb), cell_ptr, pick)
-    otr = []
-    want = oracle_model.encode_objects_packed(*sub, sub_ptr, trace=otr)
-    want_emb = [t for t in otr if "object_embeddings" in t][0]["object_embeddings"]
+    want_parts, emb_parts = [], []
+    for lo in range(0, len(pick), 256):          # (the oracle's stage trace of 256 cells is ~0.4 GB: kept per slice only)
+        part, part_ptr = _sub_batch((xyz, rgb, center, mean_rgb), cell_ptr, pick[lo: lo + 256])
+        otr = []
+        want_parts.append(oracle_model.encode_objects_packed(*part, part_ptr, trace=otr))
+        emb_parts.append([t for t in otr if "object_embeddings" in t][0]["object_embeddings"])
+        del otr
+    want, want_emb = torch.cat(want_parts), torch.cat(emb_parts)
     want_embn = np.ascontiguousarray(torch.nn.functional.normalize(want_emb, dim=-1).numpy())
     want_knn = np.zeros((want_embn.shape[0], 8), np.int32)
     fp = lambda a_, t_: a_.ctypes.data_as(C.POINTER(t_))
@@ -174,13 +188,16 @@ def test_headline_config_full_size_parity(oracle_model, vocab, checkpoint):
         assert torch.equal(got, full[sel.to(full.device)]), f"{name}: a cell's embedding depends on its batch"
         e_obj = (gtr["obj_emb"].cpu() - want_emb).abs().max().item()
         assert e_obj < TOL, f"{name} object embeddings vs oracle: {e_obj:.3e}"
-        flips, worst = _knn_flips(gtr["knn_idx"].cpu().numpy().astype(np.int64), want_knn.astype(np.int64),
+        flips, worst = _knn_flips(_global_knn(gtr["knn_idx"].cpu().numpy(), sub_ptr), want_knn.astype(np.int64),
                                   want_embn.astype(np.float64), sub_ptr)
-        assert worst < 1e-4 and len(flips) <= max(1, len(pick) // 50), (name, worst, len(flips))
+        # observed against the oracle: ~1 cell in 1,000 (round-to-nearest split); the bar is 3 x that
+        assert worst < 1e-4 and len(flips) <= max(2, 3 * len(pick) // 1000), (name, worst, len(flips))
         ok = np.ones(len(pick), dtype=bool)
         ok[flips] = False
         err = (got.cpu() - want).abs().max(dim=1).values.numpy()[ok].max()
         assert err < TOL, f"{name} vs oracle on {int(ok.sum())} of the 12,000 cells: {err:.3e}"
+        print(f"[headline gate, {checkpoint}] {name} vs oracle on {len(pick)} cells: object embeddings {e_obj:.2e}, "
+              f"{len(flips)} cells with a kNN near-tie flip (worst distance gap {worst:.1e}), other cells {err:.2e}")
     # (c) retrieval of the ENCODED queries over the ENCODED cells: bit-exact indices against the reference's float64 NumPy
     texts = S.make_texts(SEED, 0, n_q)
     with torch.no_grad():

@@ -366,8 +366,8 @@ def test_embed_dim_300_vs_oracle(vocab, d, precision):
     widx, wscore = retrieve_topk_f64(c, qq, 10)
     assert np.array_equal(idx.cpu().numpy(), widx) and np.abs(score.cpu().numpy() - wscore).max() < 1e-12
     hm.train()
-    with pytest.raises(NotImplementedError, match=f"embed_dim={d}"):
-        hm.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr)
+    out_t = hm.encode_objects_packed(*_to_dev(xyz, rgb, center, mean_rgb), cell_ptr)      # train() mode runs at any width
+    assert out_t.shape == (9, d) and out_t.requires_grad
 
 
 def test_pack_objects_matches_host_transform_chain(hip_model, oracle_model):
@@ -816,7 +816,8 @@ def _oracle_threads_then_restore():
     torch.set_num_threads(n)
 
 
-@pytest.mark.parametrize("kw,self_loops", [({}, True), (dict(use_features=["class", "position"], pointnet_features=1), False)])
+@pytest.mark.parametrize("kw,self_loops", [({}, True), (dict(use_features=["class", "position"], pointnet_features=1), False),
+                                           (dict(embed_dim=300), True)])
 def test_training_step_at_the_reference_batch_size(vocab, kw, self_loops, _oracle_threads_then_restore):
     """BASELINE configs[0]: one training step of training/coarse.py:31-62 at the reference's batch size - 64 cells (6-26
     objects each) + 64 descriptions, model.train(), anchor = encode_text, positive = encode_objects, PairwiseRankingLoss(0.35),
@@ -826,7 +827,10 @@ def test_training_step_at_the_reference_batch_size(vocab, kw, self_loops, _oracl
     of a parameter's largest entry in a handful of layers.  The bar is therefore two-sided: every HIP gradient is within 5e-3
     of the float64 one (relative to the parameter's largest gradient entry, floor 1 % of the step's gradient scale) OR no
     further from it than 1.5 x the fp32 oracle's own deviation; at least 85 % of the parameters meet the 5e-3 bar outright
-    (measured: 55 of 58, against 36 of 58 for the fp32 oracle; without the colour feature 43 of 50 against 3 of 50)."""
+    (measured: 55 of 58, against 36 of 58 for the fp32 oracle; without the colour feature 43 of 50 against 3 of 50).  On top of
+    that an ABSOLUTE cap: no HIP gradient further than 5e-2 from the float64 one, however ill-conditioned the fp32 oracle is.
+    Third case: --embed_dim 300, the reference's argparse default (training/args.py:19) - the training path runs every width
+    (Linear layers zero-pad their output columns to the GEMM's granule of 8)."""
     import weights as W
     import text2pos_amd as t2p
     from oracle import model as OM
@@ -888,7 +892,7 @@ def test_training_step_at_the_reference_batch_size(vocab, kw, self_loops, _oracl
         scale = max(1e-2 * g_all, g.abs().max().item())
         e32 = (r32[name].grad.double() - g).abs().max().item() / scale
         eh = (p.grad.cpu().double() - g).abs().max().item() / scale
-        assert eh < max(5e-3, 1.5 * e32), (name, eh, e32)
+        assert eh < max(5e-3, 1.5 * e32) and eh < 5e-2, (name, eh, e32)
         rows.append((eh, e32, name))
     assert len(rows) >= 45 and sum(r[0] < 5e-3 for r in rows) >= 0.85 * len(rows), sorted(rows, reverse=True)[:6]
     assert any(n.startswith("language_encoder.") for _, _, n in rows) and any(n.startswith("graph1.") for _, _, n in rows)

@@ -163,8 +163,6 @@ class CellRetrievalNetwork(nn.Module):
         Cells are independent: same result, bit for bit.  None (default): 2 from 2,048 cells up, else 1; 1 = everything on
         the current stream (what per-kernel event timings and the rocprofv3 evidence runs need)."""
         if self.training and not want_trace:
-            if self.kernel_dim != self.embed_dim:
-                raise NotImplementedError(f"training-mode path at embed_dim={self.embed_dim}: built for 128 and 256")
             from .train_cell import encode_objects_train
             return encode_objects_train(self, xyz, rgb, center, mean_rgb, cell_ptr, class_idx, color_idx)
         self._check_forward_only()

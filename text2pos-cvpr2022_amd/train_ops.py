@@ -215,14 +215,20 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        k = x.shape[1]
+        k, n = x.shape[1], weight.shape[0]
         pad = (-k) % 8                                     # the GEMM wants K % 4 == 0 and N % 8 == 0: zero columns
         xp = torch.nn.functional.pad(x.detach(), (0, pad)).contiguous() if pad else x.detach().contiguous()
         wp = torch.nn.functional.pad(weight.detach(), (0, pad)).contiguous() if pad else weight.detach().contiguous()
         ctx.save_for_backward(xp, wp)
         ctx.k = k
         ctx.has_bias = bias is not None
-        return ops.gemm(xp, wp.t().contiguous(), bias.detach().contiguous() if bias is not None else None)
+        b = bias.detach().contiguous() if bias is not None else None
+        pad_n = (-n) % 8                                   # e.g. --embed_dim 300 (training/args.py:19): zero output columns, cut off
+        if pad_n:
+            wt = torch.nn.functional.pad(wp, (0, 0, 0, pad_n)).t().contiguous()
+            bp = torch.nn.functional.pad(b, (0, pad_n)).contiguous() if b is not None else None
+            return ops.gemm(xp, wt, bp)[:, :n].contiguous()
+        return ops.gemm(xp, wp.t().contiguous(), b)
 
     @staticmethod
     def backward(ctx, dy):
