@@ -696,7 +696,7 @@ def main():
         # the other SA levels and the whole step, same convention (algorithmic FLOPs executed / hipEvent time)
         sizes_np = np.diff(cell_ptr).astype(np.int64)
         knn_edges = int((sizes_np * np.minimum(sizes_np, 8)).sum())
-        sa1_per_edge = args.precision == "f16x3" and not (args.tuning & (2 | 8))     # (sa_points.hip runs level 1)
+        sa1_per_edge = args.precision == "f16x3"     # (sa_points.hip runs level 1: both layers per edge)
         ex = executed_flops(e_lvl, e1_dedup if not (args.tuning & 1) else e_lvl[0], n_obj, c_hi - c_lo, knn_edges, sa1_per_edge)
         sa_levels = {}
         for name, rows_l, hc in (("ws_edge_sa_k32_n64", e1_dedup if not (args.tuning & 1) else e_lvl[0],

@@ -29,14 +29,14 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 18
+#define T2P_ABI_VERSION 19
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
                                            one chunk: ~0.6 MB per object, i.e. ~38 GB at the default chunk for a batch that
                                            fills it (t2p_encode_cells_workspace_bytes gives the exact figure; a second
                                            stream's call needs its own workspace) */
-#define T2P_TUNING_MASK 0x1F             /* t2p_cell_config.tuning: the bits that select a built plan */
+#define T2P_TUNING_MASK 0x1              /* t2p_cell_config.tuning: the bits that select a built plan */
 #define T2P_E_ARG (-1)
 #define T2P_E_WORKSPACE (-2)
 #define T2P_E_UNSUPPORTED (-3)
@@ -178,19 +178,11 @@ typedef struct t2p_cell_config {
      * fire for a checkpoint that would just have fitted, never the other way round.  The caller clears it, reads it after the stream has drained, and must
      * not trust the call's output when it is set (the Python host raises or re-runs with precision = 0).  NULL: no check. */
     int32_t* overflow_flag;
-    /* A/B switches between equivalent execution plans (0 = the default plan).  Bit 0 leaves every output bit unchanged; the
-     * others swap a kernel for one that adds the same f16x3 products in another k grouping (results agree to fp32 rounding):
-     *   bit 0: keep the edge rows of repeated points in SA level 1's row lists (default: t2p_dedup_rows drops them)
-     *   bit 1: f16x3 only: gather the centroid tables of all SA levels from HBM (default: built in LDS); SA levels 1 and 2
-     *          then run on the column-slice kernel of ws_sa2.hip (all three levels)
-     *   bit 2: f16x3 only: SA level 2 on the column-slice kernel of ws_sa2.hip (default: the row-owning kernel of
-     *          sa_rows.hip: a wave holds the whole 128 x 128 weight matrix and multiplies its own 32-row tiles)
-     *   bit 3: f16x3 only: SA level 1 on the column-slice kernel of ws_sa2.hip (default: sa_points.hip: independent waves,
-     *          each owning a group of 16 centroids of an object with a private LDS accumulator; BOTH layers per edge from the
-     *          object's points staged in LDS - no point table A_1, no row gathers)
-     *   bit 4: f16x3 only: SA level 3 on the column-slice kernel of ws_sa2.hip (default: sa3.hip, the same data flow with
-     *          the per-row control on the scalar unit)
-     * Bits outside T2P_TUNING_MASK are refused (T2P_E_ARG). */
+    /* A/B switch between equivalent execution plans (0 = the default plan):
+     *   bit 0: keep the edge rows of repeated points in SA level 1's row lists (default: t2p_dedup_rows drops them; every
+     *          output bit is the same either way)
+     * Bits outside T2P_TUNING_MASK are refused (T2P_E_ARG).  (Rounds 1-3 kept alternative SA kernels behind further bits; the
+     * measured record is docs/notebook.md, the code is in the git history.) */
     int32_t tuning;
 } t2p_cell_config;
 

@@ -243,11 +243,10 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
     gbounds.a1_bmax = W.sa_b1_absmax;
     gbounds.ga1_l1 = W.ga_w1_l1;
     gbounds.ga1_bmax = W.ga_b1_absmax;
-    // f16x3: the SA kernels of levels 1 and 2 build their centroid tables in LDS (ws_sa2.hip, BL); the HBM tables B_2 / B_3
-    // are then neither written nor read.  The fp32 kernels (ws_sa.hip) gather all three from HBM.
-    const bool lds_btab = cfg.precision == 1 && !(cfg.tuning & 2);
-    const bool lds_btab0 = lds_btab && !(cfg.tuning & 8);
-    const int sa_plan = ((cfg.tuning & 4) ? 1 : 0) | ((cfg.tuning & 8) ? 2 : 0) | ((cfg.tuning & 16) ? 4 : 0);
+    // f16x3: the SA kernels build their centroid tables B_i = W1p pos_i in LDS (sa_points.hip, sa_rows.hip, sa3.hip); the HBM
+    // tables B_l are then neither written nor read.  The fp32 kernels (ws_sa.hip) gather all three from HBM.
+    const bool lds_btab = cfg.precision == 1;
+    const bool lds_btab0 = lds_btab;
     // level 0 runs on sa_points.hip, which computes layer 1 per edge from the points themselves: no point table A_1 either
     const bool sa1_points = lds_btab0 && cfg.n_pts == 256;
     T2P_TRY(launch_cell_index(cell_ptr_dev, (int)nb, o_lo, ws.seg_ptr, ws.first, st, guard));
@@ -291,7 +290,6 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
             bp[l].bounds_ws = ws.bounds[l];
             bp[l].W_x3 = cfg.precision == 1 ? W.sa_w2_x3[l] : nullptr;
             bp[l].wp = (l > 0 ? lds_btab : lds_btab0) ? W.sa_w1[l] : nullptr;   // (non-null = LDS centroid table: selects the launch shape)
-            bp[l].plan = sa_plan;
         }
         bp[0].w1 = sa1_points ? W.sa_w1[0] : nullptr;
         T2P_TRY(launch_sa_balance_levels(bp, Geo::H, Geo::C, st));
@@ -351,7 +349,6 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.bounds_ws = ws.bounds[l];
         p.balanced = 1;
         p.amax_out = gslot(G_F1 + l);
-        p.plan = sa_plan;
         T2P_TRY(launch_ws_sa(H, C, p, st));
     }
     // ---- global abstraction: [x | pos] -> 512 -> 1024, max over the object's 32 points ------------------------

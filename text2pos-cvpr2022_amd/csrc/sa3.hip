@@ -20,7 +20,7 @@
 
 // T2P_SA3_ABL, development only (results wrong, timing valid): 1 = no atomics, 2 = no row gathers, 4 = no staging stores to LDS,
 // 8 = no operand reads inside the MFMA loop, 16 = no third MFMA, 32 = no per-batch barrier, 64 = no staging arithmetic,
-// 128 = no per-object phases (drain, centroid table)
+// 128 = no per-object phases (drain, centroid table); 256 = no s_setprio around the MFMA pairs (results stay right)
 #ifndef T2P_SA3_ABL
 #define T2P_SA3_ABL 0
 #endif
@@ -348,10 +348,10 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
                     n_hi = *(const half8*)(hrow + (j + 1) * 8);
                     n_lo = *(const half8*)(hrow + PLANE + (j + 1) * 8);
                 }
-                __builtin_amdgcn_s_setprio(1);
+                if constexpr (!(T2P_SA3_ABL & 256)) __builtin_amdgcn_s_setprio(1);
                 acc = MFMA16(a_hi, w_hi[j], j == 0 ? kZero16 : acc);
                 acc = MFMA16(a_hi, w_lo[j], acc);
-                __builtin_amdgcn_s_setprio(0);
+                if constexpr (!(T2P_SA3_ABL & 256)) __builtin_amdgcn_s_setprio(0);
                 SB();
                 if (j == 0) meta_m = load_meta(it_m);          // M(t+3)
                 // 12 staging chunks over the 16 MFMA groups: row k = (stage_a | stage_b | issue + next centroid read)
@@ -366,11 +366,12 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
                         else put_dst(dslot, dlo, dhi);
                     }
                 }
-                if constexpr (!(T2P_SA3_ABL & 1)) {             // one deferred atomic per group
+                {                                               // one deferred atomic per group
                     const int e = j;
                     const uint32_t pair = (e & 2) ? four[e >> 2].y : four[e >> 2].x;
                     const uint32_t off = (e & 1) ? (pair >> 16) : (pair & 0xFFFFu);
-                    lds_fmax((float*)((char*)acc_col + off), prev[e]);
+                    if constexpr (T2P_SA3_ABL & 1) asm volatile("" ::"v"(prev[e]), "v"(off));   // (keeps the MFMA results alive)
+                    else lds_fmax((float*)((char*)acc_col + off), prev[e]);
                 }
                 SB();
                 if constexpr (!(T2P_SA3_ABL & 16)) acc = MFMA16(a_lo, w_hi[j], acc);
@@ -401,13 +402,12 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
 #pragma unroll
         for (int q = 0; q < 4; q++) four[q] = *(const uint2*)(dl + 8 * q + 4 * h);
         const f32x16& last = rr[newest];
-        if constexpr (!(T2P_SA3_ABL & 1)) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const uint32_t pair = (e & 2) ? four[e >> 2].y : four[e >> 2].x;
-                const uint32_t off = (e & 1) ? (pair >> 16) : (pair & 0xFFFFu);
-                lds_fmax((float*)((char*)acc_col + off), last[e]);
-            }
+        for (int e = 0; e < 16; e++) {
+            const uint32_t pair = (e & 2) ? four[e >> 2].y : four[e >> 2].x;
+            const uint32_t off = (e & 1) ? (pair >> 16) : (pair & 0xFFFFu);
+            if constexpr (T2P_SA3_ABL & 1) asm volatile("" ::"v"(last[e]), "v"(off));
+            else lds_fmax((float*)((char*)acc_col + off), last[e]);
         }
         __syncthreads();
         if (flush_g1 >= 0) flush(flush_g1);
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
 }  // namespace
 
 bool sa3_selected(int H, int C, const SaParams& p) {
-    return H == 256 && C == 256 && p.W_x3 != nullptr && p.wp != nullptr && !(p.plan & 4);
+    return H == 256 && C == 256 && p.W_x3 != nullptr && p.wp != nullptr;
 }
 
 int sa3_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg) {

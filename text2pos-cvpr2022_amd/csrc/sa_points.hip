@@ -454,7 +454,7 @@ constexpr int kPtsWaves = T2P_PTS_WAVES;
 }  // namespace
 
 bool sa_points_selected(int H, int Cout, const SaParams& p) {
-    return H == 32 && Cout == 64 && p.W_x3 != nullptr && p.wp != nullptr && p.w1 != nullptr && !(p.plan & 2);
+    return H == 32 && Cout == 64 && p.W_x3 != nullptr && p.wp != nullptr && p.w1 != nullptr;
 }
 
 // (tile rows, workgroups) for the range balancing: one 12-wave workgroup per CU, cost = rows

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
 }  // namespace
 
 bool sa_rows_selected(int H, int Cout, const SaParams& p) {
-    return H == 128 && Cout == 128 && p.W_x3 != nullptr && p.wp != nullptr && !(p.plan & 1);
+    return H == 128 && Cout == 128 && p.W_x3 != nullptr && p.wp != nullptr;
 }
 
 // (tile rows, workgroups) for the range balancing: four waves share an object, a round of the workgroup covers 128 rows

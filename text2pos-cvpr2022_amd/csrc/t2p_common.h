@@ -272,8 +272,6 @@ struct SaParams {
     int32_t* bounds_ws;      // [n_workgroups+1] scratch (balanced contiguous object ranges)
     int balanced;            // 1: bounds_ws was filled by launch_sa_balance_levels for this level's launch shape
     uint32_t* amax_out;      // f16x3 guard (nullable): largest output magnitude (the next dense kernel splits these rows)
-    int plan;                // bit 0: SA level 2 stays on the column-slice kernel (ws_sa2.hip) instead of the row-owning one (sa_rows.hip);
-                             // bit 1: SA level 1 stays on it instead of sa_points.hip; bit 2: SA level 3 stays on it instead of sa3.hip
 };
 int launch_ws_sa(int H, int C, const SaParams& p, hipStream_t st);
 // sa_rows.hip: row-owning f16x3 kernel of SA level 2 (H = C = 128, LDS centroid table): true when launch_ws_sa routes p there
@@ -284,7 +282,7 @@ int sa_rows_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
 bool sa_points_selected(int H, int C, const SaParams& p);
 int launch_sa_points(int H, int C, const SaParams& p, hipStream_t st);
 int sa_points_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
-// sa3.hip: SA level 3 (H = C = 256, LDS centroid table) with scalar per-row control; plan bit 2 keeps ws_sa2.hip's kernel
+// sa3.hip: SA level 3 (H = C = 256, LDS centroid table), column-slice waves with scalar per-row control
 bool sa3_selected(int H, int C, const SaParams& p);
 int launch_sa3(const SaParams& p, hipStream_t st);
 int sa3_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);

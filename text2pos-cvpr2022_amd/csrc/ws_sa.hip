@@ -1,5 +1,5 @@
 // Set-abstraction edge kernel, exact-fp32 path (precision = "fp32": v_mfma_f32_32x32x2_f32 fma chains): per-edge
-// ReLU(A_j - B_i) -> layer-2 GEMM -> max per centroid, for sa1/sa2/sa3.  The default f16x3 path is ws_sa2.hip.
+// ReLU(A_j - B_i) -> layer-2 GEMM -> max per centroid, for sa1/sa2/sa3.  The f16x3 path runs on sa_points.hip / sa_rows.hip / sa3.hip (levels 1 / 2 / 3); this file keeps the exact fp32 MFMA kernels and the range balancing.
 // (reference: gnn.PointConv(local_nn)(x, (pos, pos[idx]), edge_index), models/pointcloud/pointnet2.py:31-35).
 //
 // Same arithmetic and register-resident weights as ws_gemm.hip (see the design notes there); this variant removes
@@ -356,7 +356,6 @@ int launch_sa_cfg(const SaParams& p_in, hipStream_t st, const char* name) {
 
 }  // namespace
 
-int launch_ws_sa2(int H, int Cout, const SaParams& p, hipStream_t st);  // ws_sa2.hip
 
 int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st) {
     ProfScope ps_("sa_balance", st);
@@ -366,14 +365,16 @@ int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st
     return 0;
 }
 
-int sa2_launch_shape(int H, int Cout, int64_t n_obj, int* tile_rows, int* n_wg);  // ws_sa2.hip
 
 // tile rows / workgroup count of the kernel launch_ws_sa will pick for (H, Cout)
 static int sa_launch_shape(int H, int Cout, const SaParams& p, int64_t n_obj, int* tile_rows, int* n_wg) {
     if (sa_rows_selected(H, Cout, p)) return sa_rows_launch_shape(n_obj, tile_rows, n_wg);
     if (sa_points_selected(H, Cout, p)) return sa_points_launch_shape(n_obj, tile_rows, n_wg);
     if (sa3_selected(H, Cout, p)) return sa3_launch_shape(n_obj, tile_rows, n_wg);
-    if (p.W_x3 != nullptr) return sa2_launch_shape(H, Cout, n_obj, tile_rows, n_wg);
+    if (p.W_x3 != nullptr) {
+        set_error("ws_sa: no f16x3 kernel for H=%d C=%d (built: 32/64 over 256 points, 128/128, 256/256, each with the LDS centroid table)", H, Cout);
+        return T2P_E_UNSUPPORTED;
+    }
     int n = num_cus();
     if (n > n_obj) n = (int)n_obj;
     *n_wg = n;
@@ -402,12 +403,13 @@ int launch_sa_balance_levels(const SaParams p[3], const int H[3], const int C[3]
 
 int launch_ws_sa(int H, int Cout, const SaParams& p, hipStream_t st) {
     T2P_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.Bc) & 15) == 0, "ws_sa: tables must be 16-byte aligned");
-    if (p.W_x3 != nullptr) {  // f16x3 split-precision path: the interleaved kernel (ws_sa2.hip)
+    if (p.W_x3 != nullptr) {  // f16x3 split-precision path: one kernel per level
         T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_sa: packed f16x3 weights must be 16-byte aligned");
         if (sa_rows_selected(H, Cout, p)) return launch_sa_rows(H, Cout, p, st);
         if (sa_points_selected(H, Cout, p)) return launch_sa_points(H, Cout, p, st);
         if (sa3_selected(H, Cout, p)) return launch_sa3(p, st);
-        return launch_ws_sa2(H, Cout, p, st);
+        set_error("ws_sa: no f16x3 kernel for H=%d C=%d (built: 32/64 over 256 points, 128/128, 256/256, each with the LDS centroid table)", H, Cout);
+        return T2P_E_UNSUPPORTED;
     } else {
         if (H == 32 && Cout == 64) return launch_sa_cfg<32, 64, 2, 2>(p, st, "ws_edge_sa_k32_n64");
         if (H == 128 && Cout == 128) return launch_sa_cfg<128, 128, 4, 1>(p, st, "ws_edge_sa_k128_n128");

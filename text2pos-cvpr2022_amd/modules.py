@@ -88,7 +88,7 @@ class _LstmTrainFn(torch.autograd.Function):
                 dc_new, carry_new = torch.empty_like(dc), torch.empty_like(dc)
                 ops.lstm_cell_backward(dh_gemm, dh_carry, dc, gates[dr, s], cs[dr, s], cs[dr, s + 1], lengths, s, d_pre[s],
                                        dc_new, carry_new)
-                dh_gemm = ops.gemm(d_pre[s], whh_t) if s > 0 else None
+                dh_gemm = ops.matmul(d_pre[s], whh_t) if s > 0 else None     # (matmul: pads N = D to the GEMM's granule of 8, e.g. D = 300)
                 dc, dh_carry = dc_new, carry_new
             flat = d_pre.reshape(t * b, 4 * d)
             d_whh_k = ops.gemm_tn(hs[dr, :t].reshape(t * b, d), flat)                     # [D, 4D] = H^T dPre

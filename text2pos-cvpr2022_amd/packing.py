@@ -77,7 +77,7 @@ def f16x3_scale(w: torch.Tensor) -> float:
 
 
 def pack_f16x3_scaled(w_kmajor: torch.Tensor, scale: float) -> torch.Tensor:
-    """Single-accumulator form used by the SA edge kernel (csrc/ws_sa2.hip): w' = scale * w (a power of two: exact),
+    """Single-accumulator form used by the SA edge kernel (csrc/sa3.hip, sa_rows.hip, sa_points.hip): w' = scale * w (a power of two: exact),
     hi = fp16(w'), lo = fp16(w' - hi) WITHOUT the 2048 factor (the matrix cores honour fp16 denormals, and w' uses fp16's
     range, so lo keeps 11 significant bits).  Same register-order layout as pack_f16x3."""
     k, n = w_kmajor.shape
