@@ -412,6 +412,8 @@ def main():
     if os.environ.get("T2P_ABLATION_RUN"):   # development: T2P_ABL builds of the library compute garbage on purpose
         model.overflow_detected = lambda: 0
     model.tuning = args.tuning
+    if args.cell_streams:      # every cell-encoder call of this run (phase rates, PCIe-inclusive rate, variants), not only the step
+        model.cell_streams = args.cell_streams
 
     # ---- inputs -> HBM (outside the timed region) ---------------------------------------------------------------------
     d_xyz, d_rgb, d_center, d_mean = (torch.from_numpy(a).to(dev) for a in (xyz, rgb, center, mean_rgb))

@@ -32,10 +32,13 @@ def main():
         ns[k] += t
         if t > 200000:           # dispatches of at least 0.2 ms: the ratio of a short one is dominated by its ramp
             best = max(best, v / t)
-    print(f"# GRBM_GUI_ACTIVE per ns of dispatch time; largest ratio of any dispatch >= 0.2 ms: {best:.3f} (= 1.00 below)")
+    light = [k for k in ns if k.startswith("k_dedup_rows")]
+    if light:      # a light streaming kernel of this library as the yardstick (tiny torch kernels read high: ramp effects)
+        best = cyc[light[0]] / ns[light[0]]
+    print(f"# GRBM_GUI_ACTIVE per ns of dispatch time; reference = {'k_dedup_rows (a light streaming kernel)' if light else 'largest ratio of a dispatch >= 0.2 ms'}: {best:.3f} (= 1.00 below)")
     for k in sorted(ns, key=lambda k: -ns[k])[:top]:
         r = cyc[k] / ns[k]
-        print(f"{k:34s} ms={ns[k] / 1e6:8.2f}  cycles/ns={r:7.3f}  relative clock={r / best if best else 0:5.2f}  (~{2.4 * r / best if best else 0:4.2f} GHz if the fastest kernel runs at 2.4)")
+        print(f"{k:34s} ms={ns[k] / 1e6:8.2f}  cycles/ns={r:7.3f}  relative clock={r / best if best else 0:5.2f}")
 
 
 if __name__ == "__main__":

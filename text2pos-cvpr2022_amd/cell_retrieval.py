@@ -53,6 +53,7 @@ class CellRetrievalNetwork(nn.Module):
             raise ValueError("on_overflow must be 'raise' or 'fp32'")
         self.on_overflow = on_overflow
         self._overflow = None
+        self.cell_streams = None   # default of encode_objects_packed(streams=None): None = 2 parts from 2,048 cells up, else 1
         self.tuning = 0          # t2p_cell_config.tuning: A/B switches between equivalent execution plans (include/t2p.h)
         d = self.embed_dim
         assert args.variation in (0, 1)
@@ -161,7 +162,8 @@ class CellRetrievalNetwork(nn.Module):
         query, the layer-1 tables) then run under the matrix-bound kernels of another - the chip is power-limited under matrix
         load, so what runs beside an MFMA kernel's tail or on its idle issue slots is nearly free (-2.5 % per step with two).
         Cells are independent: same result, bit for bit.  None (default): 2 from 2,048 cells up, else 1; 1 = everything on
-        the current stream (what per-kernel event timings and the rocprofv3 evidence runs need)."""
+        the current stream (what per-kernel event timings and the rocprofv3 evidence runs need); `self.cell_streams`
+        overrides the default for every call of this model."""
         if self.training and not want_trace:
             from .train_cell import encode_objects_train
             return encode_objects_train(self, xyz, rgb, center, mean_rgb, cell_ptr, class_idx, color_idx)
@@ -172,7 +174,7 @@ class CellRetrievalNetwork(nn.Module):
         if "color" not in self.args.use_features and not getattr(self.args, "class_embed", False):
             rgb = torch.zeros_like(rgb)   # models/object_encoder.py:86-90: the PointNet++ then sees x = 0
         if streams is None:
-            streams = 2 if cp.shape[0] - 1 >= 2048 else 1
+            streams = self.cell_streams if self.cell_streams else (2 if cp.shape[0] - 1 >= 2048 else 1)
         if streams > 1 and not want_trace and cp.shape[0] - 1 >= streams:
             return self._trim(self._encode_multi_stream(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx,
                                                         color_idx, check_overflow, int(streams)))
