@@ -355,10 +355,12 @@ def main():
                     help="skip the measurement of the reference's caller shape (encode_objects on Python object lists, batch 64 / 512)")
     ap.add_argument("--fine-queries", type=int, default=200, help="queries of the fine-stage measurement (x top-10 candidates)")
     ap.add_argument("--fp32-steps", type=int, default=2)
-    ap.add_argument("--force-exchange", action="store_true",
-                    help="N = 1 only: initialise the RCCL process group with ONE rank and run the step's all-gather through it "
+    ap.add_argument("--force-exchange", action="store_true", default=True,
+                    help="N = 1 (default ON): initialise the RCCL process group with ONE rank and run the step's all-gather through it "
                          "(communicator set-up, all_gather_into_tensor on device tensors, the `exchange` block of the JSON line), "
-                         "so that the code an 8-GPU run executes has executed on the one GPU there is")
+                         "so that the step a 1-GPU line times is the step an 8-GPU run executes.  0.1 ms of the step")
+    ap.add_argument("--no-force-exchange", dest="force_exchange", action="store_false",
+                    help="N = 1: no process group, no collective (the plain single-GPU path of distributed.sharded_retrieval)")
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="arithmetic of the MFMA-heavy layers: f16x3 split-precision (default) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -389,14 +391,22 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     exchanging = world > 1 or args.force_exchange
+    exchange_error = None
     if exchanging:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:      # (plain `python bench.py --force-exchange`, not under torch.distributed.run)
+        if "MASTER_PORT" not in os.environ:      # (plain `python bench.py`, not under torch.distributed.run)
             import socket
             with socket.socket() as s_:
                 s_.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        except Exception as e:      # a 1-GPU line must not die of the optional one-rank group (N > 1 cannot run without it)
+            if world > 1:
+                raise
+            exchange_error = f"{type(e).__name__}: {e}"
+            log(f"RCCL process group at world size 1 failed ({exchange_error}): running without the forced exchange")
+            exchanging = args.force_exchange = False
 
     # ---- model: random-init weights of the reference architecture (no checkpoints available); BatchNorm statistics: random
     # here, then (default --bn calibrated) replaced below by one train-mode pass over 64 cells of the workload ----
@@ -747,6 +757,8 @@ def main():
             "host_generation_s": round(gen_s, 2),
             "fp16_range_guard": "clear" if args.precision == "f16x3" else "n/a (fp32)",
         }
+        if exchange_error:
+            out["exchange"] = {"error": exchange_error, "note": "the one-rank RCCL group could not be initialised; no collective in the step"}
         if single_stream:
             out["single_stream"] = single_stream
         if fp32_info:

@@ -11,7 +11,7 @@ sample() {  # $1 = tag, $2 = seconds
 /opt/rocm/bin/rocm-smi --showsclkrange --showmclkrange 2>/dev/null | grep -vE "^=|^$" > $out/ranges.txt
 /opt/rocm/bin/rocm-smi -M 2>/dev/null | grep -iE "power|cap" >> $out/ranges.txt
 sample idle 2
-python bench.py --steps 150 --warmup 5 --no-cpu-baseline --no-extras --no-fp32-pass --no-two-stream --no-dropin > $out/bench_loop.json 2> $out/bench_loop.err &
+python bench.py --steps 150 --warmup 5 --no-cpu-baseline --no-extras --no-fp32-pass --no-dropin --no-force-exchange > $out/bench_loop.json 2> $out/bench_loop.err &
 sleep 9; sample bench 8; wait
 hipcc --offload-arch=gfx950 -O3 -DMIX2_LONG=1 -o /tmp/mix2_long profiles/microbench/mix2.hip 2>/dev/null
 /tmp/mix2_long > $out/mix2_long.txt 2>&1 &
