@@ -36,6 +36,15 @@ DOMINANT = "ws_edge_sa_k256_n256"
 _T0 = time.perf_counter()
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def log(msg):
     if os.environ.get("RANK", "0") == "0":
         print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -497,6 +506,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if exchanging:
+        barrier()
+        _flush_c_stdio()     # (RCCL's banner leaves libc's buffer now, on every rank, far in front of the JSON line)
     log("inputs resident in HBM; warm-up")
     for _ in range(args.warmup):
         step()
@@ -825,9 +837,15 @@ def main():
                     "oracle (each one a DynamicEdgeConv near-tie that fell the other way; tests/test_gpu_headline.py proves the ties) "
                     "and the largest difference over all other cells"))
             log("done")
-        print(json.dumps(out), flush=True)
+    # The JSON line must be the LAST line of stdout.  RCCL writes a version banner to the C-level stdout when the communicator is
+    # created; with stdout redirected it sits in libc's buffer until the process exits - i.e. behind anything Python printed.
+    # So: tear the group down first, flush libc's buffers on every rank, then rank 0 prints.
     if exchanging:
+        dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
