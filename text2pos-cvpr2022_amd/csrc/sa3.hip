@@ -91,7 +91,10 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: everything derived from it stays on the scalar unit
     const int h = lane >> 5, l31 = lane & 31;
 
-    const AS4 uint32_t* const n_rows_c = as_const((const uint32_t*)p.n_rows);   // u16 entries, read as the dword that holds them
+    // (constant address space = scalar loads: legal because earlier KERNELS wrote these tables - the scalar cache is invalidated at
+    // kernel start - and this kernel never writes them.  n_rows holds u16 entries, read as the dword that holds them: the last
+    // dword of an odd-length array reaches 2 bytes into the workspace's 256-byte alignment gap behind it)
+    const AS4 uint32_t* const n_rows_c = as_const((const uint32_t*)p.n_rows);
     const AS4 int32_t* const first_c = as_const(p.first);
     const AS4 uint32_t* const rows_c = as_const((const uint32_t*)p.rows);
     const AS4 int32_t* const bounds_c = as_const(p.bounds_ws);

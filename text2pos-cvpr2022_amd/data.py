@@ -315,21 +315,25 @@ def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_co
     n_obj = int(cell_ptr[-1])
     if n_cells and counts.min() < 1:
         raise RuntimeError(f"encode_objects: cell {int(np.argmin(counts))} has no objects")
-    for i, pts in enumerate(object_points):
-        if pts.pos.shape[0] != counts[i] * n_pts:
-            raise RuntimeError(f"encode_objects: cell {i} has {counts[i]} objects but {pts.pos.shape[0]} points; every object "
-                               f"must be resampled to {n_pts} points (T.FixedPoints({n_pts}))")
+    pos_list = [p.pos for p in object_points]
+    n_rows = np.fromiter((t.shape[0] for t in pos_list), dtype=np.int64, count=n_cells)
+    if n_cells and (n_rows != counts * n_pts).any():
+        i = int(np.flatnonzero(n_rows != counts * n_pts)[0])
+        raise RuntimeError(f"encode_objects: cell {i} has {counts[i]} objects but {n_rows[i]} points; every object "
+                           f"must be resampled to {n_pts} points (T.FixedPoints({n_pts}))")
     step = max(1, n_cells // 8)
     for i in range(0, n_cells, step):
         if object_points[i].batch is not None:
             _check_batch_vector(object_points[i], int(counts[i]), n_pts, i)
     want_rgb = not (skip_rgb or zero_color)
-    on_device = n_cells > 0 and object_points[0].pos.is_cuda
+    on_device = n_cells > 0 and pos_list[0].is_cuda
     pin = torch.cuda.is_available()
 
-    def flat(which):
-        ts = [getattr(p, which) for p in object_points]
-        return [(t if t.dtype == torch.float32 else t.float()) if not t.requires_grad else t.detach().float() for t in ts]
+    def flat(which):      # float32 tensors without a grad_fn pass as they are (the common case: one cheap scan)
+        ts = pos_list if which == "pos" else [p.x for p in object_points]
+        if any(t.dtype is not torch.float32 or t.requires_grad for t in ts):
+            ts = [(t.detach() if t.requires_grad else t).float() for t in ts]
+        return ts
 
     if on_device:
         xyz = torch.cat(flat("pos")).reshape(n_obj, n_pts, 3)
@@ -359,7 +363,15 @@ def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_co
              else torch.empty(n_obj * 6, dtype=torch.float32, pin_memory=pin)).view(2, n_obj, 3)
     small_np = small.numpy()
     if n_cells:     # (one concatenation per array: a NumPy slice assignment per cell costs more than the cache lookup it follows)
-        rows = [object_means(objs, means_cache) for objs in objects]   # (threads do not help here: the per-cell work is GIL-bound)
+        # (inlined ObjectMeansCache.get: a function call per cell costs as much as the look-up; threads do not help, GIL-bound)
+        memo = means_cache.d if means_cache is not None else {}
+        rows = []
+        for objs in objects:
+            e = memo.get(id(objs))
+            if e is not None and e[0] is objs and tuple(objs) == e[1]:
+                rows.append((e[2], e[3]))
+            else:
+                rows.append(object_means(objs, means_cache))
         np.concatenate([r[0] for r in rows], axis=0, out=small_np[0])
         np.concatenate([r[1] for r in rows], axis=0, out=small_np[1])
     center, mean_rgb = small[0], small[1]
