@@ -39,6 +39,16 @@ def tokenize(descriptions: List[str], known_words: dict):
     return padded, lengths
 
 
+_LSTM_SIDE = {}
+
+
+def _lstm_side_stream(dev):
+    key = str(dev)
+    if key not in _LSTM_SIDE:
+        _LSTM_SIDE[key] = torch.cuda.Stream(device=dev)
+    return _LSTM_SIDE[key]
+
+
 class _LstmTrainFn(torch.autograd.Function):
     """Training-mode text branch (first part): Embedding -> packed biLSTM -> mean of the two final
     hidden states (models/modules.py:77-90) with a backward pass, for `anchor = model.encode_text(...); loss.backward()`
@@ -76,32 +86,48 @@ class _LstmTrainFn(torch.autograd.Function):
         steps = torch.arange(t, device=dev, dtype=torch.int64)[:, None]                   # [T, 1]
         ln = lengths.to(torch.int64)[None, :]                                             # [1, B]
         active = steps < ln                                                               # [T, B]
-        d_emb = torch.zeros_like(emb_c)
-        grads = []
+        # The two directions are independent until their gradients are added: their (tiny, latency-bound) per-step kernels are
+        # issued alternately on two HIP streams and overlap on the GPU (9.2 -> ~5 ms at 64 texts; the forward loop is bound by
+        # the host's launch rate and stays on one stream).
+        main = torch.cuda.current_stream(dev)
+        side = _lstm_side_stream(dev)
+        streams = (main, side)
+        side.wait_stream(main)
+        whh_t = [whh0.t().contiguous(), whh1.t().contiguous()]                            # [4D, D]: d_pre -> dh_{s-1}
+        d_pre = [torch.empty((t, b, 4 * d), dtype=torch.float32, device=dev) for _ in range(2)]
+        dh_carry, dc, dh_gemm = [None, None], [None, None], [None, None]
+        for dr in (0, 1):
+            with torch.cuda.stream(streams[dr]):
+                dh_carry[dr] = (0.5 * dout).contiguous()
+                dc[dr] = torch.zeros((b, d), dtype=torch.float32, device=dev)
+        for s in range(t - 1, -1, -1):
+            for dr in (0, 1):
+                with torch.cuda.stream(streams[dr]):
+                    dc_new, carry_new = torch.empty_like(dc[dr]), torch.empty_like(dc[dr])
+                    ops.lstm_cell_backward(dh_gemm[dr], dh_carry[dr], dc[dr], gates[dr, s], cs[dr, s], cs[dr, s + 1], lengths, s,
+                                           d_pre[dr][s], dc_new, carry_new)
+                    # (matmul: pads N = D to the GEMM's granule of 8, e.g. D = 300)
+                    dh_gemm[dr] = ops.matmul(d_pre[dr][s], whh_t[dr]) if s > 0 else None
+                    dc[dr], dh_carry[dr] = dc_new, carry_new
+        d_emb_parts, grads = [], []
         for dr, (wih_k, whh_k) in enumerate(((wih0, whh0), (wih1, whh1))):
-            whh_t = whh_k.t().contiguous()                                                # [4D, D]: d_pre -> dh_{s-1}
-            d_pre = torch.empty((t, b, 4 * d), dtype=torch.float32, device=dev)
-            dh_carry = (0.5 * dout).contiguous()
-            dc = torch.zeros((b, d), dtype=torch.float32, device=dev)
-            dh_gemm = None
-            for s in range(t - 1, -1, -1):
-                dc_new, carry_new = torch.empty_like(dc), torch.empty_like(dc)
-                ops.lstm_cell_backward(dh_gemm, dh_carry, dc, gates[dr, s], cs[dr, s], cs[dr, s + 1], lengths, s, d_pre[s],
-                                       dc_new, carry_new)
-                dh_gemm = ops.matmul(d_pre[s], whh_t) if s > 0 else None     # (matmul: pads N = D to the GEMM's granule of 8, e.g. D = 300)
-                dc, dh_carry = dc_new, carry_new
-            flat = d_pre.reshape(t * b, 4 * d)
-            d_whh_k = ops.gemm_tn(hs[dr, :t].reshape(t * b, d), flat)                     # [D, 4D] = H^T dPre
-            # gate-table gradient: rows of d_pre summed per token (one-hot product: deterministic, V is ~40)
-            pos = steps if dr == 0 else (ln - 1 - steps).clamp(min=0)                     # token position of (step, sequence)
-            tok = torch.gather(tokens.to(torch.int64).t(), 0, pos.expand(t, b))           # [T, B]
-            onehot_t = torch.zeros((t * b, v), dtype=torch.float32, device=dev)
-            onehot_t.scatter_(1, tok.reshape(t * b, 1), active.reshape(t * b, 1).to(torch.float32))
-            d_table = ops.gemm_tn(onehot_t, flat)                                         # [V, 4D]: one-hot^T dPre
-            d_bias = d_table.sum(0)
-            d_wih_k = ops.gemm_tn(emb_c, d_table)                                         # [D, 4D] = E^T dTable
-            d_emb += ops.matmul(d_table, wih_k.t().contiguous())
-            grads += [d_wih_k.t().contiguous(), d_whh_k.t().contiguous(), d_bias, d_bias.clone()]
+            with torch.cuda.stream(streams[dr]):
+                flat = d_pre[dr].reshape(t * b, 4 * d)
+                d_whh_k = ops.gemm_tn(hs[dr, :t].reshape(t * b, d), flat)                 # [D, 4D] = H^T dPre
+                # gate-table gradient: rows of d_pre summed per token (one-hot product: deterministic, V is ~40)
+                pos = steps if dr == 0 else (ln - 1 - steps).clamp(min=0)                 # token position of (step, sequence)
+                tok = torch.gather(tokens.to(torch.int64).t(), 0, pos.expand(t, b))       # [T, B]
+                onehot_t = torch.zeros((t * b, v), dtype=torch.float32, device=dev)
+                onehot_t.scatter_(1, tok.reshape(t * b, 1), active.reshape(t * b, 1).to(torch.float32))
+                d_table = ops.gemm_tn(onehot_t, flat)                                     # [V, 4D]: one-hot^T dPre
+                d_bias = d_table.sum(0)
+                d_wih_k = ops.gemm_tn(emb_c, d_table)                                     # [D, 4D] = E^T dTable
+                d_emb_parts.append(ops.matmul(d_table, wih_k.t().contiguous()))
+                grads += [d_wih_k.t().contiguous(), d_whh_k.t().contiguous(), d_bias, d_bias.clone()]
+        main.wait_stream(side)
+        for tns in grads[4:] + [d_emb_parts[1]] + d_pre:      # produced on the side stream, consumed (and later freed) on the main one
+            tns.record_stream(main)
+        d_emb = d_emb_parts[0] + d_emb_parts[1]                                           # (fixed order: forward direction first)
         d_emb[0].zero_()                                                                  # nn.Embedding(padding_idx=0)
         return (None, None, d_emb) + tuple(grads)
 
