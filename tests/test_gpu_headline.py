@@ -770,6 +770,8 @@ def test_all_gather_rows_on_device_tensors_through_rccl():
         cells = torch.nn.functional.normalize(torch.randn(1000, 256, generator=g), dim=-1).to(_dev())
         queries = torch.nn.functional.normalize(torch.randn(37, 256, generator=g), dim=-1).to(_dev())
         got = TD.all_gather_rows(cells, 1000, force=True)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL's version banner (C-level stdout) leaves libc's buffer here, not behind pytest's summary
         assert got.is_cuda and got.data_ptr() != cells.data_ptr() and torch.equal(got, cells)
         marks = []
         idx, sc = TD.sharded_retrieval(lambda lo, hi: cells[lo:hi], lambda lo, hi: queries[lo:hi],
