@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 19
+#define T2P_ABI_VERSION 20
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
@@ -319,6 +319,17 @@ int t2p_profile_report(char* buf, size_t buf_bytes);
  *             gradient of the step's gate pre-activations (zero for finished sequences, whose dh / dc pass through
  *             dh_carry_out / dc_out).
  * ---------------------------------------------------------------------------------------------------------- */
+/* The whole recurrence of ONE direction with the time loop inside the library (one call instead of 2 T: the per-step kernels are
+ * tiny and the Python loop around them was bound by the host's launch rate).  Layouts as modules._LstmTrainFn keeps them:
+ * gates [T][B][4D], cs / hs [T+1][B][D] with slice 0 = the initial state (zeros), w_hh_k [D][4D] = W_hh^T, pre_ws [B][4D] scratch.
+ * backward: dh_last [B][D] = the gradient of the final hidden state, w_hh_t [4D][D] = W_hh, d_pre [T][B][4D] (out),
+ * ws [5][B][D] scratch.  embed_dim must be a multiple of 4 (else T2P_E_UNSUPPORTED: the host falls back to the per-step calls).
+ * The recurrent products run on a few-rows kernel (tg_gemm.hip::k_gemm_skinny): fp32 sums in another order than t2p_gemm's. */
+int t2p_lstm_train_forward(const float* gate_table, const float* w_hh_k, const int32_t* tokens, const int32_t* lengths,
+                           int64_t batch, int32_t max_len, int32_t embed_dim, int32_t reverse, float* gates, float* cs, float* hs,
+                           float* pre_ws, t2p_stream_t stream);
+int t2p_lstm_train_backward(const float* dh_last, const float* w_hh_t, const float* gates, const float* cs, const int32_t* lengths,
+                            int64_t batch, int32_t max_len, int32_t embed_dim, float* d_pre, float* ws, t2p_stream_t stream);
 int t2p_lstm_cell_forward(const float* pre, const float* gate_table, const int32_t* tokens, const int32_t* lengths,
                           int64_t batch, int32_t max_len, int32_t embed_dim, int32_t step, int32_t reverse, const float* c_prev,
                           const float* h_prev, float* gates, float* c, float* h, t2p_stream_t stream);

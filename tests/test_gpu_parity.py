@@ -585,6 +585,56 @@ def test_encode_text_training_step_matches_autograd(hip_model, oracle_model):
         p.requires_grad_(r)
 
 
+@pytest.mark.parametrize("b,d,t", [(70, 300, 19), (5, 128, 7), (33, 64, 54), (64, 256, 54), (130, 100, 3)])
+def test_lstm_train_loops_match_autograd(b, d, t):
+    """The in-library time loops of the training-mode text branch (t2p_lstm_train_forward / _backward, products on the
+    few-rows kernel) at batch sizes around its 64-row tiles and widths around its granules, against torch.autograd through
+    nn.Embedding + pack_padded_sequence + nn.LSTM (models/modules.py:77-90) on the CPU: the mean of the two final hidden
+    states within 1e-5, every parameter gradient within 1e-4 of its largest entry."""
+    from text2pos_amd import modules as M, ops
+    assert ops.lstm_train_loops_supported(d)
+    g = torch.Generator().manual_seed(1000 * b + d)
+    v = 23
+    emb = torch.nn.Embedding(v, d, padding_idx=0)
+    lstm = torch.nn.LSTM(input_size=d, hidden_size=d, bidirectional=True, num_layers=1)
+    with torch.no_grad():
+        for prm in list(emb.parameters()) + list(lstm.parameters()):
+            prm.copy_(torch.randn(prm.shape, generator=g) * (0.5 if prm.ndim == 1 else 1.5 / d ** 0.5))
+        emb.weight[0].zero_()
+    lengths = torch.randint(1, t + 1, (b,), generator=g, dtype=torch.int32)
+    lengths[0] = t
+    tokens = torch.randint(0, v, (b, t), generator=g, dtype=torch.int32)      # 0 = an unknown word inside a sentence
+    for i in range(b):
+        tokens[i, int(lengths[i]):] = 0
+    coef = torch.randn(b, d, generator=g)
+    # reference (the statements of LanguageEncoder.forward)
+    x = emb(tokens.long())
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lengths.long(), batch_first=True, enforce_sorted=False)
+    _, (h, _c) = lstm(packed)
+    want = torch.mean(h, dim=0)
+    (want * coef).sum().backward()
+    ref = [emb.weight.grad] + [getattr(lstm, n).grad for n in
+                               ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+                                "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse")]
+    dev = _dev()
+    prm = [emb.weight] + [getattr(lstm, n) for n in
+                          ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+                           "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse")]
+    prm_d = [q.detach().to(dev).requires_grad_(True) for q in prm]
+    got = M._LstmTrainFn.apply(tokens.to(dev), lengths.to(dev), *prm_d)
+    (got * coef.to(dev)).sum().backward()
+    assert (got.detach().cpu() - want.detach()).abs().max().item() < 1e-5
+    for q, r in zip(prm_d, ref):
+        err = (q.grad.cpu() - r).abs().max().item()
+        assert err < 1e-4 * max(1.0, r.abs().max().item()), (tuple(r.shape), err, r.abs().max().item())
+    assert float(prm_d[0].grad[0].abs().max()) == 0.0
+    # determinism: the partial sums of the few-rows kernel are added in a fixed order
+    prm_e = [q.detach().clone().requires_grad_(True) for q in prm_d]
+    again = M._LstmTrainFn.apply(tokens.to(dev), lengths.to(dev), *prm_e)
+    (again * coef.to(dev)).sum().backward()
+    assert torch.equal(again, got) and all(torch.equal(x1.grad, x2.grad) for x1, x2 in zip(prm_d, prm_e))
+
+
 @pytest.mark.parametrize("b", [1, 7, 64, 300])
 def test_pairwise_ranking_loss_matches_reference_formula(b):
     """PairwiseRankingLoss forward value and both input gradients against the reference's statements

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -76,6 +76,10 @@ SYMBOLS = {
                                c_void, C.c_size_t, c_void]),
     "t2p_lstm_cell_forward": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         c_void, c_void, c_void, c_void, c_void, c_void]),
+    "t2p_lstm_train_forward": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_void, c_void,
+                                        c_void, c_void, c_void]),
+    "t2p_lstm_train_backward": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, C.c_int32, c_void, c_void,
+                                         c_void]),
     "t2p_lstm_cell_backward": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int32,
                                          C.c_int32, c_void, c_void, c_void, c_void]),
     "t2p_bn_train_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

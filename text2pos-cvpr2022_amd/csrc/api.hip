@@ -689,6 +689,59 @@ int t2p_lstm_cell_backward(const float* dh_gemm, const float* dh_carry_in, const
                                 dh_carry_out, (hipStream_t)stream);
 }
 
+int t2p_lstm_train_forward(const float* gate_table, const float* w_hh_k, const int32_t* tokens, const int32_t* lengths,
+                           int64_t batch, int32_t max_len, int32_t embed_dim, int32_t reverse, float* gates, float* cs, float* hs,
+                           float* pre_ws, t2p_stream_t stream) {
+    T2P_CHECK_ARG(gate_table && w_hh_k && tokens && lengths && gates && cs && hs && pre_ws, "lstm_train_forward: NULL argument");
+    T2P_CHECK_ARG(batch >= 0 && max_len >= 1 && embed_dim >= 1, "lstm_train_forward: bad sizes");
+    if (embed_dim % 4 != 0) {
+        set_error("lstm_train_forward: embed_dim=%d is not a multiple of 4", embed_dim);
+        return T2P_E_UNSUPPORTED;
+    }
+    if (batch == 0) return 0;
+    const int D = embed_dim;
+    const size_t bd = (size_t)batch * D;
+    hipStream_t st = (hipStream_t)stream;
+    for (int s = 0; s < max_len; s++) {       // the time loop of modules._LstmTrainFn.forward, one launch pair per step
+        T2P_TRY(launch_gemm_skinny(hs + s * bd, D, w_hh_k, pre_ws, 4 * D, batch, D, 4 * D, st));
+        T2P_TRY(launch_lstm_cell_fwd(pre_ws, gate_table, tokens, lengths, batch, max_len, D, s, reverse, cs + s * bd, hs + s * bd,
+                                     gates + (size_t)s * batch * 4 * D, cs + (s + 1) * bd, hs + (s + 1) * bd, st));
+    }
+    return 0;
+}
+
+int t2p_lstm_train_backward(const float* dh_last, const float* w_hh_t, const float* gates, const float* cs, const int32_t* lengths,
+                            int64_t batch, int32_t max_len, int32_t embed_dim, float* d_pre, float* ws, t2p_stream_t stream) {
+    T2P_CHECK_ARG(dh_last && w_hh_t && gates && cs && lengths && d_pre && ws, "lstm_train_backward: NULL argument");
+    T2P_CHECK_ARG(batch >= 0 && max_len >= 1 && embed_dim >= 1, "lstm_train_backward: bad sizes");
+    if (embed_dim % 4 != 0) {
+        set_error("lstm_train_backward: embed_dim=%d is not a multiple of 4", embed_dim);
+        return T2P_E_UNSUPPORTED;
+    }
+    if (batch == 0) return 0;
+    const int D = embed_dim;
+    const size_t bd = (size_t)batch * D;
+    hipStream_t st = (hipStream_t)stream;
+    float* dc[2] = {ws, ws + bd};              // ws: [5][B][D] = dc ping-pong | dh_carry ping-pong | dh_gemm
+    float* carry[2] = {ws + 2 * bd, ws + 3 * bd};
+    float* dh_gemm = ws + 4 * bd;
+    hipError_t e = hipMemsetAsync(dc[0], 0, bd * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(carry[0], dh_last, bd * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        set_error("lstm_train_backward: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    int cur = 0;
+    for (int s = max_len - 1; s >= 0; s--) {
+        T2P_TRY(launch_lstm_cell_bwd(s == max_len - 1 ? nullptr : dh_gemm, carry[cur], dc[cur], gates + (size_t)s * batch * 4 * D,
+                                     cs + s * bd, cs + (s + 1) * bd, lengths, batch, D, s, d_pre + (size_t)s * batch * 4 * D,
+                                     dc[cur ^ 1], carry[cur ^ 1], st));
+        if (s > 0) T2P_TRY(launch_gemm_skinny(d_pre + (size_t)s * batch * 4 * D, 4 * D, w_hh_t, dh_gemm, D, batch, 4 * D, D, st));
+        cur ^= 1;
+    }
+    return 0;
+}
+
 int t2p_pairwise_ranking(const float* scores, int32_t batch, float margin, float* row_loss, float* d_scores, float* row_count,
                          t2p_stream_t stream) {
     T2P_CHECK_ARG(scores && row_loss && d_scores && row_count, "pairwise_ranking: NULL argument");

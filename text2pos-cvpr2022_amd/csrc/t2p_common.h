@@ -204,6 +204,8 @@ int launch_cell_index(const int32_t* cell_ptr, int n_cells, int32_t o_lo, int32_
 // C[M, N] (ldc, column offset c0) = act(A[M, K] (lda) * W[K, N] (row-major, ldw = N) + bias[N])
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int c0, int64_t M,
                 int K, int N, int relu, hipStream_t st, const float* resid = nullptr, int ldr = 0);
+// few rows x long K, no epilogue (tg_gemm.hip): the per-step products of the training-mode LSTM; K a multiple of 4, any N
+int launch_gemm_skinny(const float* A, int lda, const float* W, float* C, int ldc, int64_t M, int K, int N, hipStream_t st);
 // tg_gemm_x3.hip: the same contract on the f16x3 matrix path (W as the image of packing.py::pack_gemm_x3)
 int launch_gemm_x3(const float* A, int lda, const void* Wx, float scale, const float* bias, float* C, int ldc, int c0,
                    int64_t M, int K, int N, int relu, hipStream_t st, const float* resid = nullptr, int ldr = 0,

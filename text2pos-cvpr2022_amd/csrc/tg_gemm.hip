@@ -99,7 +99,79 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     }
 }
 
+// ---- skinny product: few rows, long K -------------------------------------------------------------------------------------
+// The per-step products of the training-mode LSTM (h_{s-1} W_hh^T: 64 x 256 x 1024; d_pre W_hh: 64 x 1024 x 256) put 2-8
+// workgroups of the tiled kernel above on the chip, each walking its whole K alone behind two barriers per 16 k: 31-47 us per
+// launch, 2 x T launches per direction.  Here a workgroup of 16 waves owns 64 rows x 32 columns: wave (rt, ks) multiplies row
+// tile rt by the ks-th eighth of K straight from global memory (no LDS staging: every operand is used once per wave), the eight
+// partial tiles are added in a fixed order through LDS by the ks = 0 waves.  k is permuted inside groups of 8 (lane half h owns
+// k0 + 4 h .. + 3, so that A arrives in 16-byte loads): fp32 sums in another order than k_gemm, deterministic.
+__global__ __launch_bounds__(1024) void k_gemm_skinny(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                       float* __restrict__ C, int ldc, int64_t M, int K, int N) {
+    __shared__ float part[14 * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int rt = wave & 1, ks = wave >> 1;
+    const int col = blockIdx.x * 32 + l31;
+    const int64_t m0 = (int64_t)blockIdx.y * 64 + rt * 32;
+    const int64_t row = m0 + l31;
+    const int per = (((K + 7) / 8 + 7) / 8) * 8;
+    const int k_begin = ks * per < K ? ks * per : K;
+    const int k_end = k_begin + per < K ? k_begin + per : K;
+    const bool row_ok = row < M, col_ok = col < N;
+    const float* ap = A + (row_ok ? row : 0) * (int64_t)lda + 4 * h;
+    const float* wp = W + (int64_t)(4 * h) * N + (col_ok ? col : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    if (m0 < M) {
+#pragma unroll 4
+        for (int k = k_begin; k < k_end; k += 8) {
+            const bool k_ok = k + 4 * h < K;          // (K = 8 i + 4: the upper half of the last group is past the end)
+            const int ks_ = k_ok ? k : 0;
+            f32x4 a = *(const f32x4*)(ap + ks_);
+            float b[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = wp[(int64_t)(ks_ + j) * N];
+            const bool a_ok = row_ok && k_ok, b_ok = col_ok && k_ok;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ok ? a[j] : 0.f, b_ok ? b[j] : 0.f, acc, 0, 0, 0);
+        }
+    }
+    if (ks > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) part[(((ks - 1) * 2 + rt) * 16 + e) * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+    if (ks == 0 && m0 < M) {
+#pragma unroll
+        for (int s = 1; s < 8; s++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] += part[(((s - 1) * 2 + rt) * 16 + e) * 64 + lane];
+        if (col_ok) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int64_t r = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (r < M) C[r * (int64_t)ldc + col] = acc[e];
+            }
+        }
+    }
+}
+
 }  // namespace
+
+int launch_gemm_skinny(const float* A, int lda, const float* W, float* C, int ldc, int64_t M, int K, int N, hipStream_t st) {
+    T2P_CHECK_ARG(K % 4 == 0 && lda % 4 == 0 && (((uintptr_t)A) & 15) == 0, "gemm_skinny: K=%d and lda=%d must be multiples of 4, A 16-byte aligned",
+                  K, lda);
+    if (M == 0 || N == 0) return 0;
+    ProfScope ps_("tg_gemm_skinny", st);
+    hipLaunchKernelGGL(k_gemm_skinny, dim3((unsigned)((N + 31) / 32), (unsigned)((M + 63) / 64)), dim3(1024), 0, st, A, lda, W, C, ldc,
+                       M, K, N);
+    T2P_CHECK_LAUNCH("gemm_skinny");
+    return 0;
+}
 
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int c0, int64_t M,
                 int K, int N, int relu, hipStream_t st, const float* resid, int ldr) {

@@ -52,8 +52,9 @@ def _lstm_side_stream(dev):
 class _LstmTrainFn(torch.autograd.Function):
     """Training-mode text branch (first part): Embedding -> packed biLSTM -> mean of the two final
     hidden states (models/modules.py:77-90) with a backward pass, for `anchor = model.encode_text(...); loss.backward()`
-    (training/coarse.py:44-58).  The recurrence runs step by step on the HIP kernels t2p_lstm_cell_forward / _backward and
-    t2p_gemm (the persistent inference kernel keeps no activations); the weight-gradient reductions at the end are plain
+    (training/coarse.py:44-58).  The recurrence runs on the HIP kernels behind t2p_lstm_cell_forward / _backward and
+    t2p_gemm, the time loop inside the library (t2p_lstm_train_forward / _backward) when the width allows, else step by step from
+    here (the persistent inference kernel keeps no activations); the weight-gradient reductions at the end are plain
     library GEMMs over the stored activations.  Parameters come in nn.LSTM's own layout (weight_* [4D, D], gates i f g o)."""
 
     @staticmethod
@@ -68,12 +69,24 @@ class _LstmTrainFn(torch.autograd.Function):
         gates = torch.empty((2, t, b, 4 * d), dtype=torch.float32, device=dev)
         cs = torch.zeros((2, t + 1, b, d), dtype=torch.float32, device=dev)
         hs = torch.zeros((2, t + 1, b, d), dtype=torch.float32, device=dev)
+        # the time loops run inside the library where the width allows: 1 call per direction instead of 2 T
+        in_library = dev.type == "cuda" and ops.lstm_train_loops_supported(d)
+        if in_library:
+            main, side = torch.cuda.current_stream(dev), _lstm_side_stream(dev)
+            side.wait_stream(main)
         for dr in (0, 1):
+            if in_library:                                  # the two directions overlap on two HIP streams
+                with torch.cuda.stream((main, side)[dr]):
+                    table = ops.gemm(emb_c, wih_k[dr], bias[dr])
+                    ops.lstm_train_forward(table, whh_k[dr], tokens, lengths, dr == 1, gates[dr], cs[dr], hs[dr])
+                continue
             table = ops.gemm(emb_c, wih_k[dr], bias[dr])                                 # [V, 4D] = E W_ih^T + b_ih + b_hh
             for s in range(t):
                 pre = ops.gemm(hs[dr, s], whh_k[dr])
                 ops.lstm_cell_forward(pre, table, tokens, lengths, s, dr == 1, cs[dr, s], hs[dr, s], gates[dr, s],
                                       cs[dr, s + 1], hs[dr, s + 1])
+        if in_library:
+            main.wait_stream(side)
         ctx.save_for_backward(tokens, lengths, emb_c, wih_k[0], wih_k[1], whh_k[0], whh_k[1], gates, cs, hs)
         return 0.5 * (hs[0, t] + hs[1, t])
 
@@ -92,15 +105,19 @@ class _LstmTrainFn(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         side = _lstm_side_stream(dev)
         streams = (main, side)
-        side.wait_stream(main)
         whh_t = [whh0.t().contiguous(), whh1.t().contiguous()]                            # [4D, D]: d_pre -> dh_{s-1}
+        side.wait_stream(main)
         d_pre = [torch.empty((t, b, 4 * d), dtype=torch.float32, device=dev) for _ in range(2)]
         dh_carry, dc, dh_gemm = [None, None], [None, None], [None, None]
+        in_library = ops.lstm_train_loops_supported(d)
         for dr in (0, 1):
             with torch.cuda.stream(streams[dr]):
                 dh_carry[dr] = (0.5 * dout).contiguous()
-                dc[dr] = torch.zeros((b, d), dtype=torch.float32, device=dev)
-        for s in range(t - 1, -1, -1):
+                if in_library:
+                    ops.lstm_train_backward(dh_carry[dr], whh_t[dr], gates[dr], cs[dr], lengths, d_pre[dr])
+                else:
+                    dc[dr] = torch.zeros((b, d), dtype=torch.float32, device=dev)
+        for s in (range(t - 1, -1, -1) if not in_library else ()):
             for dr in (0, 1):
                 with torch.cuda.stream(streams[dr]):
                     dc_new, carry_new = torch.empty_like(dc[dr]), torch.empty_like(dc[dr])

@@ -493,6 +493,51 @@ def lstm_cell_forward(pre, table, tokens, lengths, step: int, reverse: bool, c_p
                                           _ptr(h), _stream(dev)), "t2p_lstm_cell_forward")
 
 
+def lstm_train_loops_supported(d: int) -> bool:
+    """Widths the in-library time loops take (16-byte loads of the state rows)."""
+    return d % 4 == 0
+
+
+def lstm_train_forward(table, w_hh_k, tokens, lengths, reverse: bool, gates, cs, hs):
+    """All T steps of one direction in ONE call (t2p_lstm_train_forward): table [V,4D], w_hh_k [D,4D]; fills gates [T,B,4D],
+    cs / hs [T+1,B,D] (slice 0 = the initial state, left as given)."""
+    dev = table.device
+    _need(table, "table", torch.float32, 2, dev)
+    _need(w_hh_k, "w_hh_k", torch.float32, 2, dev)
+    _need(tokens, "tokens", torch.int32, 2, dev)
+    _need(lengths, "lengths", torch.int32, 1, dev)
+    for name, t in (("gates", gates), ("cs", cs), ("hs", hs)):
+        _need(t, name, torch.float32, 3, dev)
+    b, t_len = tokens.shape
+    d = w_hh_k.shape[0]
+    if (tuple(w_hh_k.shape) != (d, 4 * d) or table.shape[1] != 4 * d or tuple(gates.shape) != (t_len, b, 4 * d)
+            or tuple(cs.shape) != (t_len + 1, b, d) or tuple(hs.shape) != (t_len + 1, b, d) or lengths.shape[0] != b):
+        raise RuntimeError("lstm_train_forward: inconsistent shapes")
+    pre = torch.empty((b, 4 * d), dtype=torch.float32, device=dev)
+    L.check(L.lib().t2p_lstm_train_forward(_ptr(table), _ptr(w_hh_k), _ptr(tokens), _ptr(lengths), b, t_len, d,
+                                           int(bool(reverse)), _ptr(gates), _ptr(cs), _ptr(hs), _ptr(pre), _stream(dev)),
+            "t2p_lstm_train_forward")
+
+
+def lstm_train_backward(dh_last, w_hh_t, gates, cs, lengths, d_pre):
+    """The whole backward recurrence of one direction in ONE call (t2p_lstm_train_backward): dh_last [B,D] = gradient of the
+    final hidden state, w_hh_t [4D,D]; fills d_pre [T,B,4D]."""
+    dev = gates.device
+    _need(dh_last, "dh_last", torch.float32, 2, dev)
+    _need(w_hh_t, "w_hh_t", torch.float32, 2, dev)
+    _need(lengths, "lengths", torch.int32, 1, dev)
+    for name, t in (("gates", gates), ("cs", cs), ("d_pre", d_pre)):
+        _need(t, name, torch.float32, 3, dev)
+    t_len, b, d4 = gates.shape
+    d = d4 // 4
+    if (tuple(dh_last.shape) != (b, d) or tuple(w_hh_t.shape) != (4 * d, d) or tuple(cs.shape) != (t_len + 1, b, d)
+            or tuple(d_pre.shape) != (t_len, b, 4 * d) or lengths.shape[0] != b):
+        raise RuntimeError("lstm_train_backward: inconsistent shapes")
+    ws = torch.empty((5, b, d), dtype=torch.float32, device=dev)
+    L.check(L.lib().t2p_lstm_train_backward(_ptr(dh_last), _ptr(w_hh_t), _ptr(gates), _ptr(cs), _ptr(lengths), b, t_len, d,
+                                            _ptr(d_pre), _ptr(ws), _stream(dev)), "t2p_lstm_train_backward")
+
+
 def lstm_cell_backward(dh_gemm, dh_carry_in, dc_in, gates, c_prev, c, lengths, step: int, d_pre, dc_out, dh_carry_out):
     """Backward of one training-mode LSTM step (t2p_lstm_cell_backward); dh_gemm may be None (last step)."""
     dev = gates.device
