@@ -4,7 +4,8 @@
 tag=${1:-r01_j}
 cd /root/repo; export TMPDIR=/tmp
 mkdir -p gpurun_out/$tag
-timeout 2400 python -m pytest tests -q -m gpu --durations=8 2>&1 | tail -16 > gpurun_out/$tag/pytest.txt
+# SKIP_PYTEST=1: the GPU suite of the same tree ran in its own call (its tail is copied to profiles/<tag>_pytest.txt by hand)
+[ -n "$SKIP_PYTEST" ] || timeout 2400 python -m pytest tests -q -m gpu --durations=8 2>&1 | tail -16 > gpurun_out/$tag/pytest.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/stats -o s -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-pass --cell-streams 1 --no-extras --no-dropin --no-force-exchange > gpurun_out/$tag/stats.log 2>&1
 trace=$(find gpurun_out/$tag/stats -name "s_kernel_trace.csv" | head -1)
 python profiles/summarize.py $trace gpurun_out/$tag/kernel_stats.md "$tag: python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-pass --cell-streams 1 --no-extras --no-dropin --no-force-exchange (12k cells + 1k queries, 1 x MI355X)" > /dev/null
@@ -25,4 +26,4 @@ timeout 600 python bench_fine.py 2> gpurun_out/$tag/bench_fine.err | tail -1 > g
 # keep the merge small: drop the raw traces
 cp $trace gpurun_out/$tag/kernel_trace.csv 2>/dev/null   # (kept for re-summarising; not committed)
 find gpurun_out/$tag -name "*.db" -delete; find gpurun_out/$tag -mindepth 2 -name "*.csv" -delete
-cat gpurun_out/$tag/pytest.txt; cut -c1-400 gpurun_out/$tag/bench.json; head -12 gpurun_out/$tag/kernel_stats.md
+cat gpurun_out/$tag/pytest.txt 2>/dev/null; cut -c1-400 gpurun_out/$tag/bench.json; head -12 gpurun_out/$tag/kernel_stats.md

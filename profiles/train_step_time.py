@@ -19,3 +19,4 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     opt.zero_grad(); loss = crit(model.encode_text(texts), model.encode_objects_packed(*cells, cell_ptr)); loss.backward(); torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=18, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=25, max_name_column_width=60))

@@ -257,6 +257,51 @@ def test_object_means_equal_the_reference_accessors_bit_for_bit():
         assert center.dtype == np.float32 and np.array_equal(center, want_c) and np.array_equal(color, want_r), trial
 
 
+def test_object_means_many_through_the_c_helper_bit_for_bit():
+    """data.object_means_many: a whole call's cells in one pass of the CPython helper _t2p_host (csrc/host_ext.c; four
+    interleaved partial sums per column, a few threads).  Same contract as above - bit-identical to the reference's per-object
+    np.mean rounded to fp32 - including the routes around the helper: float32 arrays, a tuple instead of a list, a subclass
+    that overrides an accessor, and the cache it fills."""
+    assert D.host_ext() is not None, "the host helper is built by __graft_entry__.build() / build.py"
+    rng = np.random.default_rng(11)
+
+    class Shifted(D.Object3d):
+        def get_center(self):
+            return np.mean(self.xyz, axis=0) + 1.0
+
+    def want(objs):
+        return (torch.tensor(np.stack([o.get_center() for o in objs]), dtype=torch.float).numpy(),
+                torch.tensor(np.stack([o.get_color_rgb() for o in objs]), dtype=torch.float).numpy())
+
+    cells = []
+    for c in range(120):
+        objs = []
+        for j in range(int(rng.integers(1, 27))):
+            m = int(rng.integers(1, 6000))
+            xyz = rng.standard_normal((m, 3)) * (10.0 ** rng.integers(-3, 3))
+            if c % 4 == 1:
+                xyz += rng.random(3) * 5000.0
+            if c % 4 == 2:
+                xyz -= xyz.mean(axis=0)
+            objs.append(D.Object3d(j, j, xyz, rng.random((m, 3)), "box"))
+        cells.append(objs)
+    cells[7][0].xyz = cells[7][0].xyz.astype(np.float32)              # not float64: the NumPy route takes the call
+    cells[9] = tuple(cells[9])                                         # not a list
+    cells[11][0] = Shifted(0, 0, cells[11][0].xyz, cells[11][0].rgb, "box")
+    cells[13][0].xyz = np.asfortranarray(cells[13][0].xyz)            # not C-contiguous
+    for threads in (1, 4):
+        for part in (cells[:7], cells[:8], cells[8:10], cells[10:12], cells[12:14], cells[14:]):
+            cache = D.ObjectMeansCache()
+            got = D.object_means_many(list(part), cache, threads=threads)
+            assert len(got) == len(part)
+            for objs, (center, color) in zip(part, got):
+                wc, wr = want(objs)
+                assert center.dtype == np.float32 and np.array_equal(center, wc) and np.array_equal(color, wr)
+                hit = cache.get(objs)
+                assert hit is not None and hit[0] is not None and np.array_equal(hit[0], wc)
+    assert D.object_means_many([], None) == []
+
+
 def test_batch_object_points_mirrors_reference_pipeline():
     rng = np.random.default_rng(0)
     objs = [D.Object3d(i, i, rng.random((40 + i, 3)) * 5, rng.random((40 + i, 3)), "box") for i in range(4)]

@@ -85,6 +85,21 @@ def build_peaks() -> str:
     return os.path.abspath(lib)
 
 
+def build_host_ext() -> str:
+    """_t2p_host: the CPython helper of the drop-in entry point (csrc/host_ext.c: per-object float64 column sums of a whole
+    encode_objects call in C, GIL released).  Plain C, built with the host compiler against this interpreter's headers."""
+    import sysconfig
+    src = os.path.join(CSRC, "host_ext.c")
+    lib = os.path.join(HERE, "_t2p_host" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if _stale(lib, [src]):
+        cc = os.environ.get("CC") or "gcc"
+        r = subprocess.run([cc, "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], "-o", lib, src,
+                            "-lpthread", "-lm"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building _t2p_host failed:\n" + r.stderr)
+    return lib
+
+
 if __name__ == "__main__":
     if "--variant" in sys.argv:  # python build.py --variant NAME DEF1 DEF2 ...
         i = sys.argv.index("--variant")
@@ -92,3 +107,4 @@ if __name__ == "__main__":
     else:
         print(build_hip(force="--force" in sys.argv, verbose=True))
         print(build_peaks())
+        print(build_host_ext())

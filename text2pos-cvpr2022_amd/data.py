@@ -237,6 +237,77 @@ def _means_f32(arrays) -> np.ndarray:
     return out
 
 
+_HOST_EXT = None
+
+
+def host_ext():
+    """The CPython helper _t2p_host (csrc/host_ext.c, built by build.py::build_host_ext), or None when it has not been built:
+    the callers then take the NumPy route - the same host arithmetic, one cell at a time."""
+    global _HOST_EXT
+    if _HOST_EXT is None:
+        import glob
+        import importlib.util
+        import os
+        _HOST_EXT = False
+        for path in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_t2p_host*.so")):
+            try:
+                spec = importlib.util.spec_from_file_location("_t2p_host", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _HOST_EXT = mod
+                break
+            except ImportError:
+                continue
+    return _HOST_EXT or None
+
+
+def _plain_objects(objs) -> bool:
+    """True if the centre / mean colour of every object is np.mean over its .xyz / .rgb (Object3d, or a class that inherits
+    the reference's accessors unchanged)."""
+    return all(type(o) is Object3d for o in objs) or all(
+        hasattr(o, "xyz") and hasattr(o, "rgb") and type(o).get_center.__qualname__.endswith("Object3d.get_center")
+        and type(o).get_color_rgb.__qualname__.endswith("Object3d.get_color_rgb") for o in objs)
+
+
+def _means_from_sums(sums, abs_sums, rows, arrays_of):
+    """float32 means from the helper's column sums: the same proof as _means_f32 (any summation order is within
+    (m - 1) u sum|x| of the exact sum), np.mean itself for the rows where it does not decide the float32 rounding."""
+    cnt = rows[:, None].astype(np.float64)
+    mean = sums / cnt
+    tol = abs_sums * (4.0 * _U64) + 1e-300
+    lo, hi = (mean - tol).astype(np.float32), (mean + tol).astype(np.float32)
+    out = mean.astype(np.float32)
+    for i in np.flatnonzero((lo != hi).any(axis=1)):
+        out[i] = np.mean(arrays_of(int(i)), axis=0).astype(np.float32)
+    return out
+
+
+def object_means_many(cells, cache: ObjectMeansCache = None, threads: int = 8):
+    """object_means for a list of cells in ONE pass of the C helper (cells that are not in the cache: the first epoch, or
+    evaluation.pipeline's single pass over the database).  Returns a list of (centre [n, 3], colour [n, 3]) fp32 pairs."""
+    ext = host_ext()
+    if ext is None or not cells or not all(type(objs) is list and _plain_objects(objs) for objs in cells):
+        return [object_means(objs, cache) for objs in cells]
+    n = sum(len(objs) for objs in cells)
+    sums, asums = np.empty((2, n, 3), dtype=np.float64), np.empty((2, n, 3), dtype=np.float64)
+    rows = np.empty((2, n), dtype=np.int64)
+    for k, attr in enumerate(("xyz", "rgb")):
+        if ext.column_sums(cells, attr, sums[k], asums[k], rows[k], int(threads)) != n:
+            return [object_means(objs, cache) for objs in cells]    # some array is not float64 [m, 3]: the NumPy route decides
+    flat = [o for objs in cells for o in objs]
+    center = _means_from_sums(sums[0], asums[0], rows[0], lambda i: flat[i].xyz)
+    color = _means_from_sums(sums[1], asums[1], rows[1], lambda i: flat[i].rgb)
+    out, a = [], 0
+    for objs in cells:
+        b = a + len(objs)
+        pair = (center[a:b], color[a:b])
+        if cache is not None:
+            cache.put(objs, pair[0], pair[1])
+        out.append(pair)
+        a = b
+    return out
+
+
 def object_means(objs, cache: ObjectMeansCache = None):
     """([n, 3] fp32 centres, [n, 3] fp32 mean colours) of a cell's objects = torch.tensor([o.get_center() ...], dtype=float)
     of the reference (models/object_encoder.py:121-131), bit for bit."""
@@ -244,9 +315,7 @@ def object_means(objs, cache: ObjectMeansCache = None):
         hit = cache.get(objs)
         if hit is not None:
             return hit
-    own_class = all(type(o) is Object3d for o in objs)
-    if own_class or all(hasattr(o, "xyz") and hasattr(o, "rgb") and type(o).get_center.__qualname__.endswith("Object3d.get_center")
-                        for o in objs):
+    if _plain_objects(objs):
         center, color = _means_f32([o.xyz for o in objs]), _means_f32([o.rgb for o in objs])
     else:   # a subclass that overrides the accessors: ask it
         center = np.stack([o.get_center() for o in objs]).astype(np.float32)
@@ -365,13 +434,17 @@ def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_co
     if n_cells:     # (one concatenation per array: a NumPy slice assignment per cell costs more than the cache lookup it follows)
         # (inlined ObjectMeansCache.get: a function call per cell costs as much as the look-up; threads do not help, GIL-bound)
         memo = means_cache.d if means_cache is not None else {}
-        rows = []
-        for objs in objects:
+        rows, miss = [], []
+        for i, objs in enumerate(objects):
             e = memo.get(id(objs))
             if e is not None and e[0] is objs and tuple(objs) == e[1]:
                 rows.append((e[2], e[3]))
             else:
-                rows.append(object_means(objs, means_cache))
+                rows.append(None)
+                miss.append(i)
+        if miss:    # (first epoch / a single evaluation pass: all of them at once through the C helper)
+            for i, pair in zip(miss, object_means_many([objects[i] for i in miss], means_cache)):
+                rows[i] = pair
         np.concatenate([r[0] for r in rows], axis=0, out=small_np[0])
         np.concatenate([r[1] for r in rows], axis=0, out=small_np[1])
     center, mean_rgb = small[0], small[1]
