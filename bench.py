@@ -254,8 +254,9 @@ def dropin_rates(model, S, torch, n_cells=2048, batch_sizes=(64, 512)):
             res["first_epoch_over_packed"] = res["first_epoch_cells_per_s"] / res["packed_cells_per_s"]
             out[f"batch_{bs}"] = res
             del d
+    out["host_helper"] = "csrc/host_ext.c (_t2p_host)" if D.host_ext() is not None else "not built: NumPy route"
     out["note"] = ("first_epoch: every object's centre / mean colour is the float64 mean over its raw points, as the reference computes "
-                   "them in every call; later_epochs: found in CellRetrievalNetwork.object_means_cache (keyed by the cell's object "
+                   "them in every call (here: one C pass over a call's objects, bit-identical to np.mean); later_epochs: found in CellRetrievalNetwork.object_means_cache (keyed by the cell's object "
                    "list; Object3d point arrays are treated as immutable).  The dataloader's transforms are outside the timed loop, "
                    "as they are in the reference (worker processes).  Never `value`.")
     return out

@@ -1053,6 +1053,18 @@ def test_train_epoch_through_the_reference_signatures(vocab):
         last, _ = T.train_epoch(model, loader, opt, crit)
     assert last < 0.9 * first, (first, last)
     assert T.train_epoch(model, loader, opt, crit, max_batches=1)[1] == loader[:1]
+    # the text branch on its own stream (the default) changes nothing but the schedule: same parameters, bit for bit
+    results = []
+    for overlap in (True, False):
+        m2 = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
+        W.fill_state_dict(m2, 37)
+        m2 = m2.to(_dev())
+        o2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+        losses = [T.train_epoch(m2, loader, o2, crit, overlap_text=overlap)[0] for _ in range(2)]
+        torch.cuda.synchronize()
+        results.append((losses, {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}))
+    assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+    assert all(torch.equal(results[0][1][k], results[1][1][k]) for k in results[0][1])
 
 
 # ---------------------------------------------------------------------------------------------------------------

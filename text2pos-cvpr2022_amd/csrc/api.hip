@@ -33,6 +33,18 @@ int num_cus() {
     return cached;
 }
 
+// Workgroups of the three persistent matrix kernels (k_sa3, k_sa_rows, k_ga2: one workgroup fills a CU).  Development switch
+// T2P_MATRIX_WGS=<n>: fewer than one per CU leaves whole CUs to the kernels of the other HIP stream (notebook, round 4).
+int matrix_wgs() {
+    static int cached = 0;
+    if (cached == 0) {
+        cached = num_cus();
+        const char* e = getenv("T2P_MATRIX_WGS");
+        if (e != nullptr && atoi(e) >= 8 && atoi(e) <= cached) cached = atoi(e) / 8 * 8;
+    }
+    return cached;
+}
+
 int reserve_lds(const void* kernel, size_t bytes, const char* what) {
     static std::mutex mu;
     static std::set<std::pair<int, const void*>> done;

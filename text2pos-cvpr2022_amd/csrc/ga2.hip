@@ -156,7 +156,7 @@ int launch_ga2(const WsParams& p_in, hipStream_t st) {
     p.n_groups = p.M / 32;
     if (p.n_groups <= 0) return 0;
     const int n_slices = 1024 / NW;
-    int64_t streams = num_cus() / n_slices;
+    int64_t streams = matrix_wgs() / n_slices;
     if (streams < 1) streams = 1;
     if (streams > p.n_groups) streams = p.n_groups;
     if (streams >= 8) streams -= streams % 8;

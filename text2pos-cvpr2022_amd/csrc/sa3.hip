@@ -428,7 +428,7 @@ bool sa3_selected(int H, int C, const SaParams& p) {
 }
 
 int sa3_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg) {
-    int n = num_cus();
+    int n = matrix_wgs();
     if (n > 1024) n = 1024;
     if (n > n_obj) n = (int)n_obj;
     *tile_rows = TR;

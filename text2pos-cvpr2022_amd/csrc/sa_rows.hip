@@ -522,7 +522,7 @@ bool sa_rows_selected(int H, int Cout, const SaParams& p) {
 
 // (tile rows, workgroups) for the range balancing: four waves share an object, a round of the workgroup covers 128 rows
 int sa_rows_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg) {
-    int n = num_cus();
+    int n = matrix_wgs();
     if (n > 1024) n = 1024;
     if (n > n_obj) n = (int)n_obj;
     *tile_rows = 4 * 32;

@@ -59,6 +59,7 @@ __device__ __forceinline__ t2p_fp16x2 cvt_pk_f16(float a, float b) {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 int num_cus();  // cached multiProcessorCount of the current device
+int matrix_wgs(); // workgroups of the persistent matrix kernels (= num_cus() unless T2P_MATRIX_WGS says otherwise)
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: set once per (device, kernel), under a
 // lock; returns 0 or the hipError_t (message kept for t2p_last_error)
 int reserve_lds(const void* kernel, size_t bytes, const char* what);

@@ -23,16 +23,32 @@ def make_criterion(args) -> torch.nn.Module:
     raise NotImplementedError(f"ranking_loss={kind!r}: 'pairwise' and 'hardest' are built")
 
 
-def train_epoch(model, dataloader: Iterable[dict], optimizer, criterion, max_batches: Optional[int] = None):
-    """One pass over `dataloader` (training/coarse.py:31-62).  Returns (mean loss, the batches seen)."""
+def train_epoch(model, dataloader: Iterable[dict], optimizer, criterion, max_batches: Optional[int] = None,
+                overlap_text: bool = True):
+    """One pass over `dataloader` (training/coarse.py:31-62).  Returns (mean loss, the batches seen).
+    overlap_text: the text branch runs on a second HIP stream beside the cell branch - the two meet only in the loss, and autograd
+    runs a node's backward on the stream of its forward, so the biLSTM's step-by-step recurrence (latency-bound, ~3 ms of a
+    64 + 64 step forward + backward) hides under the cell branch's matrix kernels in both directions.  Same kernels in the same
+    order per stream: the parameters after an epoch are bit-identical to overlap_text=False."""
     model.train()
     epoch_losses, batches = [], []
+    dev = model.device
+    side = torch.cuda.Stream(device=dev) if (overlap_text and dev.type == "cuda") else None
     for i_batch, batch in enumerate(dataloader):
         if max_batches is not None and i_batch >= max_batches:
             break
         optimizer.zero_grad()
-        anchor = model.encode_text(batch["texts"])
-        positive = model.encode_objects(batch["objects"], batch["object_points"])
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)                       # zero_grad / the previous optimizer step
+            with torch.cuda.stream(side):
+                anchor = model.encode_text(batch["texts"])
+            positive = model.encode_objects(batch["objects"], batch["object_points"])
+            main.wait_stream(side)
+            anchor.record_stream(main)                   # allocated on the side stream's pool, consumed by the loss on the main one
+        else:
+            anchor = model.encode_text(batch["texts"])
+            positive = model.encode_objects(batch["objects"], batch["object_points"])
         loss = criterion(anchor, positive)
         loss.backward()
         optimizer.step()
