@@ -15,6 +15,23 @@ for it in range(4):
     p = model.encode_objects_packed(*cells, cell_ptr); torch.cuda.synchronize(); t2 = time.time()
     loss = crit(a, p); loss.backward(); torch.cuda.synchronize(); t3 = time.time(); opt.step(); torch.cuda.synchronize(); t4 = time.time()
     print(f"step {it}: loss {loss.item():.4f}  text fwd {1e3*(t1-t0):.1f} ms  cells fwd {1e3*(t2-t1):.1f} ms  loss+bwd {1e3*(t3-t2):.1f} ms  adam {1e3*(t4-t3):.1f} ms  mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+# whole steps back to back (no synchronisation inside a step), text branch on the main stream / on its own stream as training.train_epoch runs it
+def run_steps(n, overlap):
+    side = torch.cuda.Stream() if overlap else None
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(n):
+        opt.zero_grad()
+        if side is not None:
+            main = torch.cuda.current_stream(); side.wait_stream(main)
+            with torch.cuda.stream(side):
+                a = model.encode_text(texts)
+            p = model.encode_objects_packed(*cells, cell_ptr); main.wait_stream(side); a.record_stream(main)
+        else:
+            a = model.encode_text(texts); p = model.encode_objects_packed(*cells, cell_ptr)
+        loss = crit(a, p); loss.backward(); opt.step()
+    torch.cuda.synchronize(); return 1e3 * (time.time() - t0) / n
+for overlap in (False, True, False, True):
+    print(f"8 steps back to back, text branch on {'its own stream' if overlap else 'the main stream'}: {run_steps(8, overlap):.2f} ms per step")
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     opt.zero_grad(); loss = crit(model.encode_text(texts), model.encode_objects_packed(*cells, cell_ptr)); loss.backward(); torch.cuda.synchronize()
