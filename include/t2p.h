@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 20
+#define T2P_ABI_VERSION 21
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
@@ -422,6 +422,14 @@ int t2p_gemm(const float* a, int32_t lda, const float* w, const float* bias, flo
 size_t t2p_gemm_tn_workspace_bytes(int64_t m, int32_t k1, int32_t n);
 int t2p_gemm_tn(const float* a, int32_t lda, const float* b, int32_t ldb, float* c, int32_t ldc, int64_t m, int32_t k1, int32_t n,
                 void* workspace, size_t workspace_bytes, t2p_stream_t stream);
+/* Weight and bias gradient of an nn.Linear in the training-mode path (every `get_mlp` block under model.train(),
+ * models/modules.py:11-36), exact fp32 MFMA (csrc/train_gemm.hip):
+ *   dW[K1][N] = dY[M][K1]^T X[M][N] and colsum[K1] = column sums of dY (the bias gradient; may be null): every operand row is
+ *   read once per row range, the row ranges' partial blocks are added in a fixed order (deterministic).
+ *   lda, ldb multiples of 4, operands 16-byte aligned.  workspace: t2p_linear_wgrad_workspace_bytes. */
+size_t t2p_linear_wgrad_workspace_bytes(int64_t m, int32_t k1, int32_t n);
+int t2p_linear_wgrad_f32(const float* dy, int32_t lda, const float* x, int32_t ldb, float* dw, int32_t ldc, float* colsum, int64_t m,
+                         int32_t k1, int32_t n, void* workspace, size_t workspace_bytes, t2p_stream_t stream);
 /* F.normalize(x, dim=-1), eps 1e-12 */
 int t2p_rownorm(const float* x, int64_t n_rows, int32_t dim, float* out, t2p_stream_t stream);
 

@@ -112,6 +112,24 @@ def test_gemm_tn_matches_fp64(m, k1, n):
     assert (got.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, m ** 0.5)
 
 
+@pytest.mark.parametrize("m,k1,n", [(1, 4, 8), (37, 67, 128), (5000, 256, 1024), (100003, 32, 6), (3, 1024, 512), (0, 8, 8), (70000, 256, 256),
+                                    (9999, 128, 72), (12345, 64, 32), (4000, 512, 264), (2500, 300, 256), (800, 256, 300), (31, 32, 8), (1390000, 32, 8), (1000000, 128, 72)])
+def test_linear_wgrad_matches_fp64(m, k1, n):
+    """t2p_linear_wgrad_f32: dY^T X and the column sums of dY in one pass over the rows; against float64, deterministic."""
+    from text2pos_amd import ops
+    g = torch.Generator().manual_seed(m * 3 + k1)
+    a = torch.randn(m, k1, generator=g)
+    b = torch.randn(m, n, generator=g)
+    got, cs = ops.linear_wgrad(a.to(_dev()), b.to(_dev()))
+    again, cs2 = ops.linear_wgrad(a.to(_dev()), b.to(_dev()))
+    want = a.double().t() @ b.double()
+    assert got.shape == (k1, n) and cs.shape == (k1,) and torch.equal(got, again) and torch.equal(cs, cs2)
+    tol = 2e-5 * max(1.0, m ** 0.5)
+    assert (got.cpu().double() - want).abs().max().item() < tol
+    assert (cs.cpu().double() - a.double().sum(0)).abs().max().item() < tol
+    assert ops.linear_wgrad(a.to(_dev()), b.to(_dev()), want_colsum=False)[1] is None
+
+
 def test_rownorm():
     from text2pos_amd import ops
     x = torch.randn(77, 256)
@@ -1053,18 +1071,25 @@ def test_train_epoch_through_the_reference_signatures(vocab):
         last, _ = T.train_epoch(model, loader, opt, crit)
     assert last < 0.9 * first, (first, last)
     assert T.train_epoch(model, loader, opt, crit, max_batches=1)[1] == loader[:1]
-    # the text branch on its own stream (the default) changes nothing but the schedule: same parameters, bit for bit
+    # the text branch on its own stream (the default) changes nothing but the schedule: the first step's loss is the same bit
+    # for bit (the forward has no atomics), its gradients agree to the rounding noise of the float atomics in the scatter
+    # backward kernels (t2p_edge_features_backward / t2p_pair_features_backward add in arrival order)
     results = []
-    for overlap in (True, False):
+    for overlap in (True, False, False):
         m2 = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args())
         W.fill_state_dict(m2, 37)
         m2 = m2.to(_dev())
-        o2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
-        losses = [T.train_epoch(m2, loader, o2, crit, overlap_text=overlap)[0] for _ in range(2)]
+        o2 = torch.optim.SGD(m2.parameters(), lr=0.0)          # (the step leaves parameters and gradients as backward() left them)
+        loss = T.train_epoch(m2, loader, o2, crit, max_batches=1, overlap_text=overlap)[0]
         torch.cuda.synchronize()
-        results.append((losses, {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}))
-    assert results[0][0] == results[1][0], (results[0][0], results[1][0])
-    assert all(torch.equal(results[0][1][k], results[1][1][k]) for k in results[0][1])
+        results.append((loss, {k: p.grad.detach().cpu().clone() for k, p in m2.named_parameters() if p.grad is not None}))
+    assert results[0][0] == results[1][0] == results[2][0], [r[0] for r in results]
+    assert results[0][1].keys() == results[1][1].keys() and len(results[0][1]) > 40
+    for k, g in results[1][1].items():
+        scale = g.abs().max().item() + 1e-30
+        noise = (results[2][1][k] - g).abs().max().item() / scale          # same schedule twice: the atomics alone
+        diff = (results[0][1][k] - g).abs().max().item() / scale
+        assert diff <= max(10 * noise, 2e-5), (k, diff, noise)
 
 
 # ---------------------------------------------------------------------------------------------------------------

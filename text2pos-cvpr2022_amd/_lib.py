@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -113,6 +113,9 @@ SYMBOLS = {
     "t2p_gemm": (C.c_int, [c_void, C.c_int32, c_void, c_void, c_void, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                            C.c_int32, C.c_int32, c_void]),
     "t2p_rownorm": (C.c_int, [c_void, C.c_int64, C.c_int32, c_void, c_void]),
+    "t2p_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "t2p_linear_wgrad_f32": (C.c_int, [c_void, C.c_int32, c_void, C.c_int32, c_void, C.c_int32, c_void, C.c_int64, C.c_int32,
+                                       C.c_int32, c_void, C.c_size_t, c_void]),
     "t2p_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "t2p_gemm_tn": (C.c_int, [c_void, C.c_int32, c_void, C.c_int32, c_void, C.c_int32, C.c_int64, C.c_int32, C.c_int32, c_void,
                               C.c_size_t, c_void]),

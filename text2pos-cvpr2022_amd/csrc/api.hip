@@ -923,6 +923,13 @@ int t2p_gemm_tn(const float* a, int32_t lda, const float* b, int32_t ldb, float*
     return launch_gemm_tn(a, lda, b, ldb, c, ldc, m, k1, n, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+size_t t2p_linear_wgrad_workspace_bytes(int64_t m, int32_t k1, int32_t n) { return linear_wgrad_workspace_bytes(m, k1, n); }
+
+int t2p_linear_wgrad_f32(const float* dy, int32_t lda, const float* x, int32_t ldb, float* dw, int32_t ldc, float* colsum, int64_t m,
+                         int32_t k1, int32_t n, void* workspace, size_t workspace_bytes, t2p_stream_t stream) {
+    return launch_linear_wgrad_f32(dy, lda, x, ldb, dw, ldc, colsum, m, k1, n, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int t2p_rownorm(const float* x, int64_t n_rows, int32_t dim, float* out, t2p_stream_t stream) {
     return launch_rownorm(x, dim, n_rows, dim, out, dim, 0, (hipStream_t)stream);
 }

@@ -214,6 +214,10 @@ int launch_gemm_x3(const float* A, int lda, const void* Wx, float scale, const f
 
 // tg_gemm_tn.hip: C[K1, N] = A[M, K1]^T B[M, N], rows split over the grid + fixed-order reduction (training-mode gradients)
 size_t gemm_tn_workspace_bytes(int64_t M, int K1, int N);
+// train_gemm.hip: weight + bias gradient of the training-mode Linear layers
+size_t linear_wgrad_workspace_bytes(int64_t M, int K1, int N);
+int launch_linear_wgrad_f32(const float* dY, int lda, const float* X, int ldb, float* dW, int ldc, float* colsum, int64_t M, int K1, int N,
+                            void* ws, size_t ws_bytes, hipStream_t st);
 int launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int64_t M, int K1, int N, void* ws,
                    size_t ws_bytes, hipStream_t st);
 

@@ -159,6 +159,27 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_colsum: bool = True):
+    """(dy[M, K1]^T @ x[M, N] -> [K1, N], column sums of dy [K1] or None) in one pass over the rows (t2p_linear_wgrad_f32): the
+    weight and bias gradients of a Linear.  Row pitches must be multiples of 4 floats (the layers of the path are)."""
+    _need(dy, "dy", torch.float32, 2)
+    _need(x, "x", torch.float32, 2, dy.device)
+    m, k1 = dy.shape
+    if x.shape[0] != m:
+        raise RuntimeError(f"linear_wgrad: dy is [{m},{k1}] but x is {tuple(x.shape)}")
+    n = x.shape[1]
+    if k1 % 4:
+        dy = torch.nn.functional.pad(dy, (0, (-k1) % 4)).contiguous()
+    if n % 4:
+        x = torch.nn.functional.pad(x, (0, (-n) % 4)).contiguous()
+    out = torch.empty((k1, n), dtype=torch.float32, device=dy.device)
+    colsum = torch.empty((k1,), dtype=torch.float32, device=dy.device) if want_colsum else None
+    ws = torch.empty((L.lib().t2p_linear_wgrad_workspace_bytes(m, k1, n),), dtype=torch.uint8, device=dy.device)
+    L.check(L.lib().t2p_linear_wgrad_f32(_ptr(dy), dy.shape[1], _ptr(x), x.shape[1], _ptr(out), n, _ptr(colsum), m, k1, n, _ptr(ws),
+                                         ws.numel(), _stream(dy.device)), "t2p_linear_wgrad_f32")
+    return out, colsum
+
+
 def rownorm(x: torch.Tensor) -> torch.Tensor:
     _need(x, "x", torch.float32, 2)
     out = torch.empty_like(x)

@@ -211,7 +211,8 @@ def normalize(x):
 
 class _LinearFn(torch.autograd.Function):
     """x [M, K] @ weight[N, K]^T + bias on the tiled fp32-MFMA GEMM (t2p_gemm); dX on the same GEMM (weight is its k-major
-    operand), dW = dY^T X on t2p_gemm_tn (rows split over the grid, fixed-order reduction), db a row sum."""
+    operand); dW = dY^T X and db = column sums of dY in ONE pass over the rows on t2p_linear_wgrad_f32 (csrc/train_gemm.hip:
+    every row of dY and X read once per row range, fixed-order reduction of the partial blocks: deterministic)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -237,8 +238,13 @@ class _LinearFn(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad
         # [M, N] x [N, K]: the weight is its own k-major operand
         dx = ops.gemm(dy, wp)[:, : ctx.k] if need_x else None
-        dw = ops.gemm_tn(dy, xp)[:, : ctx.k] if need_w else None   # dY^T X; frozen layers (--pointnet_freeze) skip it
-        db = dy.sum(0) if (need_b and ctx.has_bias) else None
+        dw = db = None
+        want_b = bool(need_b and ctx.has_bias)
+        if need_w:                                         # frozen layers (--pointnet_freeze) skip it
+            dw, db = ops.linear_wgrad(dy, xp, want_colsum=want_b)
+            dw = dw[:, : ctx.k]
+        elif want_b:
+            db = dy.sum(0)
         return dx, dw, db
 
 
