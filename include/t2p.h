@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 21
+#define T2P_ABI_VERSION 22
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
@@ -343,7 +343,8 @@ int t2p_lstm_cell_backward(const float* dh_gemm, const float* dh_carry_in, const
  * x, y [M][C] fp32; seg_ptr [n_seg+1] int32 (device) tiles the rows; mean / invstd / var_unbiased [n_seg][C] (biased
  * variance normalises, the unbiased one feeds the running estimate; float64 accumulation in a fixed order: row chunks of a
  * segment are reduced by separate workgroups into `workspace` - t2p_bn_train_workspace_bytes - and combined in order).
- * backward: dx [M][C]; dgamma_seg / dbeta_seg [n_seg][C] per segment (the caller sums them over the segments).
+ * backward: dx [M][C]; dgamma_seg / dbeta_seg [n_seg][C] per segment (the caller sums them over the segments); it takes x
+ * and the layer's beta [C], not y: the ReLU mask (y > 0) is recomputed from x exactly as the forward formed y.
  * Segment max (PointConv aggr="max", gnn.global_max_pool, DynamicEdgeConv aggr="max" over rows sorted by destination):
  * out [n_seg][C], arg [n_seg][C] = winning row (first one on ties, -1 and out = 0 for an empty segment); the backward
  * routes dout to the winning rows. */
@@ -352,7 +353,7 @@ int t2p_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int32_t n_
                               const float* gamma, const float* beta, float eps, int32_t relu, float* y, float* mean,
                               float* invstd, float* var_unbiased, void* workspace, size_t workspace_bytes,
                               t2p_stream_t stream);
-int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int32_t n_seg,
+int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* beta, const int32_t* seg_ptr, int32_t n_seg,
                                int64_t rows, int32_t channels, const float* mean, const float* invstd, const float* gamma,
                                int32_t relu, float* dx, float* dgamma_seg, float* dbeta_seg, void* workspace,
                                size_t workspace_bytes, t2p_stream_t stream);

@@ -780,11 +780,11 @@ int t2p_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int32_t n_
                                         var_unbiased, (double*)workspace, (hipStream_t)stream);
 }
 
-int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int32_t n_seg,
+int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* beta, const int32_t* seg_ptr, int32_t n_seg,
                                int64_t rows, int32_t channels, const float* mean, const float* invstd, const float* gamma,
                                int32_t relu, float* dx, float* dgamma_seg, float* dbeta_seg, void* workspace,
                                size_t workspace_bytes, t2p_stream_t stream) {
-    T2P_CHECK_ARG(dy && x && y && seg_ptr && mean && invstd && gamma && dx && dgamma_seg && dbeta_seg,
+    T2P_CHECK_ARG(dy && x && beta && seg_ptr && mean && invstd && gamma && dx && dgamma_seg && dbeta_seg,
                   "bn_relu_train_backward: NULL argument");
     T2P_CHECK_ARG(n_seg >= 0 && channels >= 1 && rows >= 0, "bn_relu_train_backward: bad sizes");
     if (n_seg > 0 && (workspace == nullptr || workspace_bytes < bn_train_workspace_bytes(rows, n_seg, channels))) {
@@ -792,7 +792,7 @@ int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* y, 
                   bn_train_workspace_bytes(rows, n_seg, channels));
         return T2P_E_WORKSPACE;
     }
-    return launch_bn_relu_train_backward(dy, x, y, seg_ptr, n_seg, rows, channels, mean, invstd, gamma, relu, dx, dgamma_seg,
+    return launch_bn_relu_train_backward(dy, x, beta, seg_ptr, n_seg, rows, channels, mean, invstd, gamma, relu, dx, dgamma_seg,
                                          dbeta_seg, (double*)workspace, (hipStream_t)stream);
 }
 

@@ -318,7 +318,7 @@ size_t bn_train_workspace_bytes(int64_t rows, int n_seg, int C);
 int launch_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int n_seg, int64_t rows, int C, const float* gamma,
                                  const float* beta, float eps, int relu, float* y, float* mean, float* invstd,
                                  float* var_unbiased, double* part, hipStream_t st);
-int launch_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int n_seg,
+int launch_bn_relu_train_backward(const float* dy, const float* x, const float* beta, const int32_t* seg_ptr, int n_seg,
                                   int64_t rows, int C, const float* mean, const float* invstd, const float* gamma, int relu,
                                   float* dx, float* dgamma_seg, float* dbeta_seg, double* part, hipStream_t st);
 int launch_edge_feat_fwd(const float* x, const float* pos, const float* pos_c, const int32_t* src, const int32_t* dst, int64_t E,

@@ -24,6 +24,23 @@ __device__ __forceinline__ double combine4(double (*red)[kCols], int rl, int cl,
     return r;
 }
 
+// BatchNorm output of one element, the ONE place that spells the formula: the backward kernels recompute the ReLU mask
+// (y > 0) from x with it instead of reading y back (two of the seven tensor passes of the backward), so it must give the
+// forward's bits (-ffp-contract=off: four separate roundings, in this order)
+__device__ __forceinline__ float bn_out(float x, float mean, float invstd, float gamma, float beta) {
+    return (x - mean) * invstd * gamma + beta;
+}
+
+// dz = dy where the ReLU let the activation through (or everywhere without a ReLU), else 0 - as a bit mask.  Written as the
+// select `(!relu || bn_out(...) > 0.f) ? dy : 0.f`, hipcc (ROCm 7.2, -O3) compiled k_bn_bwd_apply4 to `v_mov dz, 0` for ALL lanes
+// followed by an EMPTY `s_and_saveexec` region where the move back belonged: dx came out as if no row had passed the ReLU
+// (the statistics kernel next to it, same expression, was compiled correctly).  test_bn_relu_train_matches_torch_per_segment
+// catches it; the mask form below leaves no branch to get wrong.
+__device__ __forceinline__ float relu_gate(float dy, int relu, float x, float mean, float invstd, float gamma, float beta) {
+    const int keep = (relu == 0) | (int)(bn_out(x, mean, invstd, gamma, beta) > 0.f);
+    return __int_as_float(__float_as_int(dy) & -keep);
+}
+
 // Row chunk z of gridDim.z of segment s: [lo, hi)
 __device__ __forceinline__ void chunk_rows(const int32_t* seg_ptr, int s, int& lo, int& hi, int& n) {
     const int r0 = seg_ptr[s], r1 = seg_ptr[s + 1];
@@ -92,15 +109,15 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
     chunk_rows(seg_ptr, s, lo, hi, n);
     const float m = mean[(int64_t)s * C + c], is = invstd[(int64_t)s * C + c], g = gamma[c], b = beta[c];
     for (int r = lo + rl; r < hi; r += kRowsPar) {
-        const float v = (x[(int64_t)r * C + c] - m) * is * g + b;
+        const float v = bn_out(x[(int64_t)r * C + c], m, is, g, b);
         y[(int64_t)r * C + c] = relu ? fmaxf(v, 0.f) : v;
     }
 }
 
-// backward, stage 1: per chunk partial sums of dz = dy (y > 0) and dz xhat; part [n_seg][R][2][C]
+// backward, stage 1: per chunk partial sums of dz = dy (bn_out(x) > 0) and dz xhat; part [n_seg][R][2][C]
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x,
-                                                        const float* __restrict__ y, const int32_t* __restrict__ seg_ptr,
-                                                        int C, const float* __restrict__ mean,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const int32_t* __restrict__ seg_ptr, int C, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, int relu,
                                                         double* __restrict__ part) {
     __shared__ double red[kRowsPar][kCols];
@@ -110,11 +127,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
     chunk_rows(seg_ptr, s, lo, hi, n);
     const bool ok = c < C;
     const float m = ok ? mean[(int64_t)s * C + c] : 0.f, is = ok ? invstd[(int64_t)s * C + c] : 0.f;
+    const float g = ok ? gamma[c] : 0.f, b = ok ? beta[c] : 0.f;
     double a0 = 0.0, a1 = 0.0;
     if (ok)
         for (int r = lo + rl; r < hi; r += kRowsPar) {
             const int64_t i = (int64_t)r * C + c;
-            const float dz = (!relu || y[i] > 0.f) ? dy[i] : 0.f;
+            const float dz = relu_gate(dy[i], relu, x[i], m, is, g, b);
             a0 += (double)dz;
             a1 += (double)dz * (double)((x[i] - m) * is);
         }
@@ -143,7 +161,7 @@ __global__ void k_bn_bwd_finish(const double* __restrict__ part, int n_seg, int 
 }
 // stage 3: dx = gamma invstd (dz - sum dz / n - xhat sum(dz xhat) / n)
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
-                                                      const float* __restrict__ y, const int32_t* __restrict__ seg_ptr, int C,
+                                                      const float* __restrict__ beta, const int32_t* __restrict__ seg_ptr, int C,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, int relu,
                                                       const float* __restrict__ dgamma_seg,
@@ -153,12 +171,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     if (c >= C) return;
     int lo, hi, n;
     chunk_rows(seg_ptr, s, lo, hi, n);
-    const float m = mean[(int64_t)s * C + c], is = invstd[(int64_t)s * C + c], g = gamma[c];
+    const float m = mean[(int64_t)s * C + c], is = invstd[(int64_t)s * C + c], g = gamma[c], b = beta[c];
     const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
     const float sdz = dbeta_seg[(int64_t)s * C + c] * inv_n, sdx = dgamma_seg[(int64_t)s * C + c] * inv_n;
     for (int r = lo + rl; r < hi; r += kRowsPar) {
         const int64_t i = (int64_t)r * C + c;
-        const float dz = (!relu || y[i] > 0.f) ? dy[i] : 0.f;
+        const float dz = relu_gate(dy[i], relu, x[i], m, is, g, b);
         dx[i] = g * is * (dz - sdz - (x[i] - m) * is * sdx);
     }
 }
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(256) void k_bn_apply4(const float* __restrict__ x, 
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const float t = (v[e] - m[e]) * is[e] * g[e] + b[e];
+            const float t = bn_out(v[e], m[e], is[e], g[e], b[e]);
             o[e] = relu ? fmaxf(t, 0.f) : t;
         }
         return o;
@@ -270,8 +288,8 @@ __global__ __launch_bounds__(256) void k_bn_apply4(const float* __restrict__ x, 
 
 template <int TQ>
 __global__ __launch_bounds__(256) void k_bn_bwd_partial4(const float* __restrict__ dy, const float* __restrict__ x,
-                                                         const float* __restrict__ y, const int32_t* __restrict__ seg_ptr,
-                                                         int C, const float* __restrict__ mean,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const int32_t* __restrict__ seg_ptr, int C, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, int relu,
                                                          double* __restrict__ part) {
     constexpr int RL = 256 / TQ, W = TQ * 4;
@@ -284,10 +302,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial4(const float* __restrict
     double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
     if (ok) {
         const f32x4 m = *(const f32x4*)(mean + (int64_t)s * C + c), is = *(const f32x4*)(invstd + (int64_t)s * C + c);
-        auto add = [&](const f32x4& vdy, const f32x4& vx, const f32x4& vy) {
+        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+        auto add = [&](const f32x4& vdy, const f32x4& vx) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float dz = (!relu || vy[e] > 0.f) ? vdy[e] : 0.f;
+                const float dz = relu_gate(vdy[e], relu, vx[e], m[e], is[e], g[e], b[e]);
                 a0[e] += (double)dz;
                 a1[e] += (double)dz * (double)((vx[e] - m[e]) * is[e]);
             }
@@ -295,14 +314,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial4(const float* __restrict
         int r = lo + rl;
         for (; r + RL < hi; r += 2 * RL) {
             const int64_t i0 = (int64_t)r * C + c, i1 = (int64_t)(r + RL) * C + c;
-            const f32x4 d0 = *(const f32x4*)(dy + i0), x0 = *(const f32x4*)(x + i0), y0 = *(const f32x4*)(y + i0);
-            const f32x4 d1 = *(const f32x4*)(dy + i1), x1 = *(const f32x4*)(x + i1), y1 = *(const f32x4*)(y + i1);
-            add(d0, x0, y0);
-            add(d1, x1, y1);
+            const f32x4 d0 = *(const f32x4*)(dy + i0), x0 = *(const f32x4*)(x + i0);
+            const f32x4 d1 = *(const f32x4*)(dy + i1), x1 = *(const f32x4*)(x + i1);
+            add(d0, x0);
+            add(d1, x1);
         }
         for (; r < hi; r += RL) {
             const int64_t i0 = (int64_t)r * C + c;
-            add(*(const f32x4*)(dy + i0), *(const f32x4*)(x + i0), *(const f32x4*)(y + i0));
+            add(*(const f32x4*)(dy + i0), *(const f32x4*)(x + i0));
         }
     }
     double s0[4], s1[4];
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial4(const float* __restrict
 
 template <int TQ>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float* __restrict__ dy, const float* __restrict__ x,
-                                                       const float* __restrict__ y, const int32_t* __restrict__ seg_ptr, int C,
+                                                       const float* __restrict__ beta, const int32_t* __restrict__ seg_ptr, int C,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, int relu,
                                                        const float* __restrict__ dgamma_seg,
@@ -333,13 +352,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float* __restrict__
     chunk_rows(seg_ptr, s, lo, hi, n);
     const int64_t sc = (int64_t)s * C + c;
     const f32x4 m = *(const f32x4*)(mean + sc), is = *(const f32x4*)(invstd + sc), g = *(const f32x4*)(gamma + c);
+    const f32x4 b = *(const f32x4*)(beta + c);
     const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
     const f32x4 sdz = *(const f32x4*)(dbeta_seg + sc) * inv_n, sdx = *(const f32x4*)(dgamma_seg + sc) * inv_n;
-    auto one = [&](const f32x4& vdy, const f32x4& vx, const f32x4& vy) {
+    auto one = [&](const f32x4& vdy, const f32x4& vx) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const float dz = (!relu || vy[e] > 0.f) ? vdy[e] : 0.f;
+            const float dz = relu_gate(vdy[e], relu, vx[e], m[e], is[e], g[e], b[e]);
             o[e] = g[e] * is[e] * (dz - sdz[e] - (vx[e] - m[e]) * is[e] * sdx[e]);
         }
         return o;
@@ -347,14 +367,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float* __restrict__
     int r = lo + rl;
     for (; r + RL < hi; r += 2 * RL) {
         const int64_t i0 = (int64_t)r * C + c, i1 = (int64_t)(r + RL) * C + c;
-        const f32x4 d0 = *(const f32x4*)(dy + i0), x0 = *(const f32x4*)(x + i0), y0 = *(const f32x4*)(y + i0);
-        const f32x4 d1 = *(const f32x4*)(dy + i1), x1 = *(const f32x4*)(x + i1), y1 = *(const f32x4*)(y + i1);
-        *(f32x4*)(dx + i0) = one(d0, x0, y0);
-        *(f32x4*)(dx + i1) = one(d1, x1, y1);
+        const f32x4 d0 = *(const f32x4*)(dy + i0), x0 = *(const f32x4*)(x + i0);
+        const f32x4 d1 = *(const f32x4*)(dy + i1), x1 = *(const f32x4*)(x + i1);
+        *(f32x4*)(dx + i0) = one(d0, x0);
+        *(f32x4*)(dx + i1) = one(d1, x1);
     }
     for (; r < hi; r += RL) {
         const int64_t i0 = (int64_t)r * C + c;
-        *(f32x4*)(dx + i0) = one(*(const f32x4*)(dy + i0), *(const f32x4*)(x + i0), *(const f32x4*)(y + i0));
+        *(f32x4*)(dx + i0) = one(*(const f32x4*)(dy + i0), *(const f32x4*)(x + i0));
     }
 }
 
@@ -575,25 +595,25 @@ int launch_bn_relu_train_forward(const float* x, const int32_t* seg_ptr, int n_s
     return 0;
 }
 
-int launch_bn_relu_train_backward(const float* dy, const float* x, const float* y, const int32_t* seg_ptr, int n_seg,
+int launch_bn_relu_train_backward(const float* dy, const float* x, const float* beta, const int32_t* seg_ptr, int n_seg,
                                   int64_t rows, int C, const float* mean, const float* invstd, const float* gamma, int relu,
                                   float* dx, float* dgamma_seg, float* dbeta_seg, double* part, hipStream_t st) {
     if (n_seg == 0) return 0;
     const int R = bn_chunks(rows, n_seg);
     const dim3 grid((unsigned)n_seg, (unsigned)((C + kCols - 1) / kCols), (unsigned)R);
-    const bool vec = bn_vec_ok(C, x, y, mean, invstd, gamma) && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dgamma_seg | (uintptr_t)dbeta_seg) & 15) == 0;
+    const bool vec = bn_vec_ok(C, x, beta, mean, invstd, gamma) && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dgamma_seg | (uintptr_t)dbeta_seg) & 15) == 0;
     const dim3 grid8((unsigned)n_seg, (unsigned)((C + 31) / 32), (unsigned)R);
-    if (vec && C <= 32) hipLaunchKernelGGL(k_bn_bwd_partial4<8>, grid8, dim3(256), 0, st, dy, x, y, seg_ptr, C, mean, invstd, relu, part);
-    else if (vec) hipLaunchKernelGGL(k_bn_bwd_partial4<16>, grid, dim3(256), 0, st, dy, x, y, seg_ptr, C, mean, invstd, relu, part);
-    else hipLaunchKernelGGL(k_bn_bwd_partial, grid, dim3(256), 0, st, dy, x, y, seg_ptr, C, mean, invstd, relu, part);
+    if (vec && C <= 32) hipLaunchKernelGGL(k_bn_bwd_partial4<8>, grid8, dim3(256), 0, st, dy, x, gamma, beta, seg_ptr, C, mean, invstd, relu, part);
+    else if (vec) hipLaunchKernelGGL(k_bn_bwd_partial4<16>, grid, dim3(256), 0, st, dy, x, gamma, beta, seg_ptr, C, mean, invstd, relu, part);
+    else hipLaunchKernelGGL(k_bn_bwd_partial, grid, dim3(256), 0, st, dy, x, gamma, beta, seg_ptr, C, mean, invstd, relu, part);
     T2P_CHECK_LAUNCH("bn_bwd_partial");
     const int64_t sc = (int64_t)n_seg * C;
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3((unsigned)((sc + 255) / 256)), dim3(256), 0, st, part, n_seg, C, R, dgamma_seg,
                        dbeta_seg);
     T2P_CHECK_LAUNCH("bn_bwd_finish");
-    if (vec && C <= 32) hipLaunchKernelGGL(k_bn_bwd_apply4<8>, grid8, dim3(256), 0, st, dy, x, y, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg, dbeta_seg, dx);
-    else if (vec) hipLaunchKernelGGL(k_bn_bwd_apply4<16>, grid, dim3(256), 0, st, dy, x, y, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg, dbeta_seg, dx);
-    else hipLaunchKernelGGL(k_bn_bwd_apply, grid, dim3(256), 0, st, dy, x, y, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg,
+    if (vec && C <= 32) hipLaunchKernelGGL(k_bn_bwd_apply4<8>, grid8, dim3(256), 0, st, dy, x, beta, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg, dbeta_seg, dx);
+    else if (vec) hipLaunchKernelGGL(k_bn_bwd_apply4<16>, grid, dim3(256), 0, st, dy, x, beta, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg, dbeta_seg, dx);
+    else hipLaunchKernelGGL(k_bn_bwd_apply, grid, dim3(256), 0, st, dy, x, beta, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg,
                             dbeta_seg, dx);
     T2P_CHECK_LAUNCH("bn_bwd_apply");
     return 0;

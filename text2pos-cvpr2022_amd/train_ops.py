@@ -30,14 +30,14 @@ class _BnReluTrainFn(torch.autograd.Function):
                                                   _ptr(beta.detach()), float(eps), int(bool(relu)), _ptr(y), _ptr(mean),
                                                   _ptr(invstd), _ptr(var_u), _ptr(ws), ws.numel(), _stream(dev)),
                 "t2p_bn_relu_train_forward")
-        ctx.save_for_backward(x, y, seg_ptr, mean, invstd, gamma.detach())
+        ctx.save_for_backward(x, seg_ptr, mean, invstd, gamma.detach(), beta.detach())   # (not y: its sign is recomputed from x)
         ctx.relu = bool(relu)
         ctx.mark_non_differentiable(mean, var_u)
         return y, mean, var_u
 
     @staticmethod
     def backward(ctx, dy, _dmean, _dvar):
-        x, y, seg_ptr, mean, invstd, gamma = ctx.saved_tensors
+        x, seg_ptr, mean, invstd, gamma, beta = ctx.saved_tensors
         dev = x.device
         n_seg, c = mean.shape
         dy = dy.contiguous()
@@ -45,7 +45,7 @@ class _BnReluTrainFn(torch.autograd.Function):
         dg, db = (torch.empty((n_seg, c), dtype=torch.float32, device=dev) for _ in range(2))
         m = x.shape[0]
         ws = torch.empty((max(1, L.lib().t2p_bn_train_workspace_bytes(m, n_seg, c)),), dtype=torch.uint8, device=dev)
-        L.check(L.lib().t2p_bn_relu_train_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(seg_ptr), n_seg, m, c, _ptr(mean),
+        L.check(L.lib().t2p_bn_relu_train_backward(_ptr(dy), _ptr(x), _ptr(beta.contiguous()), _ptr(seg_ptr), n_seg, m, c, _ptr(mean),
                                                    _ptr(invstd), _ptr(gamma), int(ctx.relu), _ptr(dx), _ptr(dg), _ptr(db),
                                                    _ptr(ws), ws.numel(), _stream(dev)), "t2p_bn_relu_train_backward")
         return dx, None, dg.sum(0), db.sum(0), None, None
