@@ -93,7 +93,7 @@ def build_host_ext() -> str:
     lib = os.path.join(HERE, "_t2p_host" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
     if _stale(lib, [src]):
         cc = os.environ.get("CC") or "gcc"
-        r = subprocess.run([cc, "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], "-o", lib, src,
+        r = subprocess.run([cc, "-O3", "-std=gnu11", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], "-o", lib, src,
                             "-lpthread", "-lm"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("building _t2p_host failed:\n" + r.stderr)

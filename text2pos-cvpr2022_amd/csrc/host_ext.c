@@ -37,30 +37,28 @@ typedef struct {
     double* asums;
 } job_t;
 
+/* Column sums and sums of absolute values of one [m, 3] array.  The array is read as a flat stream of doubles with TWELVE
+ * independent accumulators each (element i goes to accumulator i % 12: four interleaved partial sums per column), a form the
+ * compiler turns into three 4-wide vector adds per 12 elements without re-associating anything; cloned for AVX2 with run-time
+ * dispatch (the library is built in one container and runs in another). */
+__attribute__((target_clones("avx2", "default")))
 static void sum_one(const double* p, Py_ssize_t m, double* s, double* t) {
-    double s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0}, s3[3] = {0, 0, 0};
-    double t0[3] = {0, 0, 0}, t1[3] = {0, 0, 0}, t2[3] = {0, 0, 0}, t3[3] = {0, 0, 0};
+    double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, b[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const Py_ssize_t n = 3 * m;
     Py_ssize_t i = 0;
-    for (; i + 4 <= m; i += 4, p += 12) {
-        for (int c = 0; c < 3; c++) {
-            s0[c] += p[c];
-            s1[c] += p[3 + c];
-            s2[c] += p[6 + c];
-            s3[c] += p[9 + c];
-            t0[c] += fabs(p[c]);
-            t1[c] += fabs(p[3 + c]);
-            t2[c] += fabs(p[6 + c]);
-            t3[c] += fabs(p[9 + c]);
+    for (; i + 12 <= n; i += 12)
+        for (int j = 0; j < 12; j++) {
+            const double v = p[i + j];
+            a[j] += v;
+            b[j] += fabs(v);
         }
+    for (int j = 0; i < n; i++, j++) {
+        a[j] += p[i];
+        b[j] += fabs(p[i]);
     }
-    for (; i < m; i++, p += 3)
-        for (int c = 0; c < 3; c++) {
-            s0[c] += p[c];
-            t0[c] += fabs(p[c]);
-        }
     for (int c = 0; c < 3; c++) {
-        s[c] = (s0[c] + s1[c]) + (s2[c] + s3[c]);
-        t[c] = (t0[c] + t1[c]) + (t2[c] + t3[c]);
+        s[c] = (a[c] + a[3 + c]) + (a[6 + c] + a[9 + c]);
+        t[c] = (b[c] + b[3 + c]) + (b[6 + c] + b[9 + c]);
     }
 }
 
@@ -139,7 +137,8 @@ static PyObject* column_sums(PyObject* self, PyObject* args) {
         int64_t* r = (int64_t*)rows.buf;
         for (Py_ssize_t i = 0; i < n; i++) r[i] = (int64_t)arrs[i].rows;
         if (threads > 16) threads = 16;
-        if (threads < 1 || total_rows < 200000) threads = 1;     /* a thread start costs as much as ~100 k rows */
+        if (threads < 1) threads = 1;
+        if ((Py_ssize_t)threads > total_rows / 150000 + 1) threads = (int)(total_rows / 150000 + 1);   /* a thread start costs as much as ~100 k rows */
         job_t jobs[16];
         Py_ssize_t lo = 0, acc = 0;
         int nj = 0;
