@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 22
+#define T2P_ABI_VERSION 23
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
@@ -402,6 +402,21 @@ int t2p_hardest_ranking(const float* scores, int32_t batch, float margin, float*
 int t2p_sample_group(const float* xyz, int64_t n_obj, int32_t n_pts, const float* radius_host /*[3]*/,
                      uint8_t* const* fps_idx /*[3]*/, uint8_t* const* nbr /*[3]*/, uint8_t* const* cnt /*[3]*/,
                      t2p_stream_t stream);
+/* The same kernel with its compact edge-row lists as output (what the SA edge kernels of t2p_encode_cells consume):
+ * rows[l] uint16 [n_obj][n_cent_l * 33], per object sorted by centroid: (centroid | 0x80 for the self-loop row) << 8 | source,
+ * hits in ascending source order (<= 32), then - with self_loops - the centroid's self-loop row (source byte = centroid);
+ * n_rows[l] uint16 [n_obj].  t2p_edge_counts / t2p_edge_expand turn a level's lists into the edge arrays of
+ * gnn.PointConv(...)(x, (pos, pos[idx]), edge_index) with torch_geometric's self-loop rewrite (pointnet2.py:26-35) for the
+ * training-mode path: counts [n_obj * n_cent] kept rows per centroid (a hit whose two CELL-local indices agree is dropped: the
+ * appended loop (i, i) replaces it; first_obj [n_obj] = first object of the object's cell); with cent_ptr = exclusive prefix of
+ * counts (n_obj * n_cent + 1 entries), src / dst [cent_ptr[last]] int32 = (dense row, centroid row) of every edge, sorted by dst. */
+int t2p_group_rows(const float* xyz, int64_t n_obj, int32_t n_pts, const float* radius_host /*[3]*/, int32_t self_loops,
+                   uint8_t* const* fps_idx /*[3]*/, uint16_t* const* rows /*[3]*/, uint16_t* const* n_rows /*[3]*/,
+                   t2p_stream_t stream);
+int t2p_edge_counts(const uint16_t* rows, const uint16_t* n_rows, const int32_t* first_obj, int64_t n_obj, int32_t n_dense,
+                    int32_t n_cent, int32_t self_loops, int32_t* counts, t2p_stream_t stream);
+int t2p_edge_expand(const uint16_t* rows, const uint16_t* n_rows, const int32_t* first_obj, const int32_t* cent_ptr, int64_t n_obj,
+                    int32_t n_dense, int32_t n_cent, int32_t self_loops, int32_t* src, int32_t* dst, t2p_stream_t stream);
 /* Level-1 (SA1) row lists without the edges of repeated points.  rows uint16 [n_obj][(n_pts/2) * 33]: per object the compact
  * edge-row list of k_sample_group, sorted by centroid: (centroid | 0x80 for the self-loop row) << 8 | source point, terminated
  * by four 0xFFFF; n_rows uint16 [n_obj].  A row whose source point repeats an EARLIER point of the object bit for bit (xyz and

@@ -788,6 +788,39 @@ def test_bn_relu_train_matches_torch_per_segment(sizes, c, relu):
     assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == len(sizes)
 
 
+@pytest.mark.parametrize("n_pts,self_loops", [(256, True), (256, False), (100, True), (16, True)])
+def test_group_edges_equal_the_tensor_formulation(n_pts, self_loops):
+    """ops.group_edges (edge lists of the three SA levels built on the device from k_sample_group's compact row lists:
+    t2p_group_rows -> t2p_edge_counts -> prefix -> t2p_edge_expand) against train_cell._sa_edges, the torch statement of
+    torch_geometric's rewrite (hit mask -> nonzero -> remove cell-local self loops -> append (i, i) -> stable sort by target) on
+    the neighbour tables of t2p_sample_group: identical arrays, including first-of-cell objects whose hit i -> i the appended
+    loop replaces, duplicate-heavy objects, odd dense counts (n_pts = 100: 100 / 50 / 25) and cells of 1 .. 9 objects."""
+    from text2pos_amd import ops, train_cell as TC
+    rng = np.random.default_rng(n_pts + int(self_loops))
+    sizes = [1, 2, 9, 3, 1, 6, 4]
+    n_obj = sum(sizes)
+    xyz = (rng.random((n_obj, n_pts, 3), dtype=np.float32) * 2 - 1) * rng.uniform(0.2, 1.0, (n_obj, 1, 1)).astype(np.float32)
+    xyz[3, :, :] = xyz[3, rng.integers(0, 5, n_pts), :]             # five distinct points
+    xyz[7] = xyz[7, 0]                                              # all points identical: every centroid sees all (capped at 32)
+    cp = np.concatenate([[0], np.cumsum(sizes)])
+    first = torch.from_numpy(np.repeat(cp[:-1], sizes)).to(_dev())
+    d = torch.from_numpy(xyz).to(_dev())
+    tables = ops.sample_group(d)
+    got = ops.group_edges(d, first.to(torch.int32), self_loops=self_loops)
+    nd = n_pts
+    for lvl in range(3):
+        nc = (nd + 1) // 2
+        src, dst = TC._sa_edges(tables["nbr"][lvl], tables["cnt"][lvl], first, nd, nc, self_loops)
+        g = got[lvl]
+        assert torch.equal(g["fps_idx"], tables["fps_idx"][lvl])
+        assert g["src"].dtype == torch.int32 and torch.equal(g["src"].long(), src) and torch.equal(g["dst"].long(), dst), lvl
+        want_ptr = torch.cat([dst.new_zeros(1), torch.cumsum(torch.bincount(dst, minlength=n_obj * nc), 0)])
+        assert torch.equal(g["cent_ptr"].long(), want_ptr)
+        if self_loops:
+            assert int((g["cent_ptr"][1:] - g["cent_ptr"][:-1]).min()) >= 1
+        nd = nc
+
+
 def test_segment_max_and_linear_match_torch():
     """Segment max (PointConv / global_max_pool / DynamicEdgeConv aggregation over rows sorted by destination) and Linear on
     the tiled GEMM, forward and backward, against torch; K = 67 exercises the zero-padded operand."""

@@ -890,6 +890,35 @@ int t2p_sample_group(const float* xyz, int64_t n_obj, int32_t n_pts, const float
     return launch_sample_group(xyz, n_obj, n_pts, radius_host, gt, (hipStream_t)stream);
 }
 
+int t2p_group_rows(const float* xyz, int64_t n_obj, int32_t n_pts, const float* radius_host, int32_t self_loops,
+                   uint8_t* const* fps_idx, uint16_t* const* rows, uint16_t* const* n_rows, t2p_stream_t stream) {
+    T2P_CHECK_ARG(xyz && radius_host && fps_idx && rows && n_rows, "group_rows: NULL argument");
+    Geo g(n_pts);
+    GroupTables gt{};
+    gt.self_loops = self_loops ? 1 : 0;
+    for (int l = 0; l < 3; l++) {
+        T2P_CHECK_ARG(fps_idx[l] && rows[l] && n_rows[l], "group_rows: NULL table of level %d", l);
+        gt.fps_idx[l] = fps_idx[l];
+        gt.rows[l] = rows[l];
+        gt.n_rows[l] = n_rows[l];
+        gt.n_dense[l] = g.nd[l];
+        gt.n_cent[l] = g.nc[l];
+    }
+    return launch_sample_group(xyz, n_obj, n_pts, radius_host, gt, (hipStream_t)stream);
+}
+
+int t2p_edge_counts(const uint16_t* rows, const uint16_t* n_rows, const int32_t* first_obj, int64_t n_obj, int32_t n_dense,
+                    int32_t n_cent, int32_t self_loops, int32_t* counts, t2p_stream_t stream) {
+    T2P_CHECK_ARG(n_obj >= 0 && (n_obj == 0 || (rows && n_rows && first_obj && counts)), "edge_counts: NULL argument");
+    return launch_edge_counts(rows, n_rows, first_obj, n_obj, n_dense, n_cent, self_loops, counts, (hipStream_t)stream);
+}
+
+int t2p_edge_expand(const uint16_t* rows, const uint16_t* n_rows, const int32_t* first_obj, const int32_t* cent_ptr, int64_t n_obj,
+                    int32_t n_dense, int32_t n_cent, int32_t self_loops, int32_t* src, int32_t* dst, t2p_stream_t stream) {
+    T2P_CHECK_ARG(n_obj >= 0 && (n_obj == 0 || (rows && n_rows && first_obj && cent_ptr)), "edge_expand: NULL argument");
+    return launch_edge_expand(rows, n_rows, first_obj, cent_ptr, n_obj, n_dense, n_cent, self_loops, src, dst, (hipStream_t)stream);
+}
+
 int t2p_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
                      const float* rot_cos_sin, int64_t n_obj, int32_t n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
                      t2p_stream_t stream) {

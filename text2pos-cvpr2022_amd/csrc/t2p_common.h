@@ -214,6 +214,11 @@ int launch_gemm_x3(const float* A, int lda, const void* Wx, float scale, const f
 
 // tg_gemm_tn.hip: C[K1, N] = A[M, K1]^T B[M, N], rows split over the grid + fixed-order reduction (training-mode gradients)
 size_t gemm_tn_workspace_bytes(int64_t M, int K1, int N);
+// train_ops.hip: PointConv edge lists (source row, target row) of a level from k_sample_group's compact row lists
+int launch_edge_counts(const uint16_t* rows, const uint16_t* n_rows, const int32_t* first_obj, int64_t n_obj, int n_dense, int n_cent,
+                       int self_loops, int32_t* counts, hipStream_t st);
+int launch_edge_expand(const uint16_t* rows, const uint16_t* n_rows, const int32_t* first_obj, const int32_t* cent_ptr, int64_t n_obj,
+                       int n_dense, int n_cent, int self_loops, int32_t* src, int32_t* dst, hipStream_t st);
 // train_gemm.hip: weight + bias gradient of the training-mode Linear layers
 size_t linear_wgrad_workspace_bytes(int64_t M, int K1, int N);
 int launch_linear_wgrad_f32(const float* dY, int lda, const float* X, int ldb, float* dW, int ldc, float* colsum, int64_t M, int K1, int N,

@@ -562,6 +562,76 @@ int launch_rownorm_bwd(const float* x, const float* dy, int64_t n_rows, int dim,
     return 0;
 }
 
+// ---- edge lists of a set-abstraction level from the compact row lists of k_sample_group ------------------------------------
+// The training-mode path needs PointConv's edges as (source dense row, target centroid row) arrays sorted by target
+// (models/pointcloud/pointnet2.py:26-35 with torch_geometric's self-loop rewrite: remove the edges whose two CELL-local indices
+// agree, append (i, i) for every centroid row i of the cell).  k_sample_group already writes exactly that list per object -
+// hits in ascending source order, then the self-loop row, centroid after centroid - for the inference kernels; under their
+// max-aggregation a hit that duplicates the self loop is harmless, under batch statistics it is not, so it is dropped here.
+// First version of the path built the lists with torch tensor ops (nonzero of the hit mask, stable sort, bincounts): ~30
+// launches and 3 size read-backs per level; now: one count kernel, one cumsum, one expand kernel per level and ONE read-back
+// of the three edge totals.
+//   keep(row) = not (self_loops and row is a hit and (o - f) n_dense + src == (o - f) n_cent + centroid)    f = first object of o's cell
+__device__ __forceinline__ bool edge_row_kept(uint32_t e16, int rank_in_cell, int n_dense, int n_cent, int self_loops) {
+    const int cb = (int)(e16 >> 8), src = (int)(e16 & 0xFFu);
+    if (!self_loops || (cb & 0x80)) return true;
+    return rank_in_cell * n_dense + src != rank_in_cell * n_cent + cb;
+}
+
+// counts [n_obj * n_cent]: kept rows per centroid.  One wave per object.
+__global__ __launch_bounds__(64) void k_edge_counts(const uint16_t* __restrict__ rows, const uint16_t* __restrict__ n_rows,
+                                                    const int32_t* __restrict__ first_obj, int64_t n_obj, int n_dense, int n_cent,
+                                                    int self_loops, int32_t* __restrict__ counts) {
+    __shared__ int cnt[128];
+    const int lane = threadIdx.x;
+    const int pitch = n_cent * 33;
+    for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
+        for (int i = lane; i < n_cent; i += 64) cnt[i] = 0;
+        __syncthreads();
+        const uint16_t* r = rows + o * pitch;
+        const int n = n_rows[o], rank = (int)(o - first_obj[o]);
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t e = r[i];
+            if (edge_row_kept(e, rank, n_dense, n_cent, self_loops)) atomicAdd(&cnt[(e >> 8) & 0x7F], 1);
+        }
+        __syncthreads();
+        for (int i = lane; i < n_cent; i += 64) counts[o * n_cent + i] = cnt[i];
+        __syncthreads();
+    }
+}
+
+// src / dst [E] int32: the kept rows of all objects in list order (= sorted by target row); cent_ptr [n_obj * n_cent + 1] is the
+// exclusive prefix of `counts`, so an object's rows start at cent_ptr[o n_cent].  One wave per object, 64 rows per round.
+__global__ __launch_bounds__(64) void k_edge_expand(const uint16_t* __restrict__ rows, const uint16_t* __restrict__ n_rows,
+                                                    const int32_t* __restrict__ first_obj, const int32_t* __restrict__ cent_ptr,
+                                                    int64_t n_obj, int n_dense, int n_cent, int self_loops,
+                                                    int32_t* __restrict__ src, int32_t* __restrict__ dst) {
+    const int lane = threadIdx.x;
+    const int pitch = n_cent * 33;
+    for (int64_t o = blockIdx.x; o < n_obj; o += gridDim.x) {
+        const uint16_t* r = rows + o * pitch;
+        const int n = n_rows[o];
+        const int64_t f = first_obj[o];
+        const int rank = (int)(o - f);
+        int64_t base = cent_ptr[o * n_cent];
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t e = i < n ? r[i] : 0u;
+            const bool keep = i < n && edge_row_kept(e, rank, n_dense, n_cent, self_loops);
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                const int cb = (int)(e >> 8), c = cb & 0x7F, sidx = (int)(e & 0xFFu);
+                // a self-loop row names the dense row of the cell's batch with the centroid row's cell-local index
+                const int64_t s_row = (cb & 0x80) ? f * n_dense + ((int64_t)rank * n_cent + sidx) : o * n_dense + sidx;
+                src[base + before] = (int32_t)s_row;
+                dst[base + before] = (int32_t)(o * n_cent + c);
+            }
+            base += __popcll(m);
+        }
+    }
+}
+
 // the 16-byte forms need C % 4 == 0 and 16-byte aligned rows / per-channel vectors
 static bool bn_vec_ok(int C, const void* a, const void* b, const void* c, const void* d, const void* e) {
     return C % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e) & 15) == 0;
@@ -637,6 +707,29 @@ int launch_segment_max_backward(const float* dout, const int32_t* arg, const int
     hipLaunchKernelGGL(k_segment_max_backward, dim3((unsigned)n_seg, (unsigned)((C + kCols - 1) / kCols)), dim3(256), 0, st,
                        dout, arg, seg_ptr, C, dx);
     T2P_CHECK_LAUNCH("segment_max_backward");
+    return 0;
+}
+
+int launch_edge_counts(const uint16_t* rows, const uint16_t* n_rows, const int32_t* first_obj, int64_t n_obj, int n_dense, int n_cent,
+                       int self_loops, int32_t* counts, hipStream_t st) {
+    T2P_CHECK_ARG(n_cent >= 1 && n_cent <= 128 && n_dense >= n_cent && n_dense <= 256, "edge_counts: n_dense=%d n_cent=%d", n_dense, n_cent);
+    if (n_obj == 0) return 0;
+    const int64_t grid = n_obj < 65535 * 16 ? n_obj : 65535 * 16;
+    hipLaunchKernelGGL(k_edge_counts, dim3((unsigned)grid), dim3(64), 0, st, rows, n_rows, first_obj, n_obj, n_dense, n_cent, self_loops,
+                       counts);
+    T2P_CHECK_LAUNCH("edge_counts");
+    return 0;
+}
+
+int launch_edge_expand(const uint16_t* rows, const uint16_t* n_rows, const int32_t* first_obj, const int32_t* cent_ptr, int64_t n_obj,
+                       int n_dense, int n_cent, int self_loops, int32_t* src, int32_t* dst, hipStream_t st) {
+    T2P_CHECK_ARG(n_cent >= 1 && n_cent <= 128 && n_dense >= n_cent && n_dense <= 256, "edge_expand: n_dense=%d n_cent=%d", n_dense, n_cent);
+    T2P_CHECK_ARG(n_obj * (int64_t)n_dense < (1LL << 31), "edge_expand: row indices beyond int32");
+    if (n_obj == 0) return 0;
+    const int64_t grid = n_obj < 65535 * 16 ? n_obj : 65535 * 16;
+    hipLaunchKernelGGL(k_edge_expand, dim3((unsigned)grid), dim3(64), 0, st, rows, n_rows, first_obj, cent_ptr, n_obj, n_dense, n_cent,
+                       self_loops, src, dst);
+    T2P_CHECK_LAUNCH("edge_expand");
     return 0;
 }
 

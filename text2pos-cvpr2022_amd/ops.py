@@ -78,6 +78,54 @@ def sample_group(xyz: torch.Tensor, radius=(0.2, 0.3, 0.4)):
     return out
 
 
+def group_edges(xyz: torch.Tensor, first_obj: torch.Tensor, radius=(0.2, 0.3, 0.4), self_loops: bool = True):
+    """FPS + ball query of the three SA levels as EDGE LISTS for the training-mode path, built on the device:
+    t2p_group_rows (k_sample_group's compact row lists) -> t2p_edge_counts -> prefix sum -> t2p_edge_expand.  One host
+    read-back (the three edge totals) instead of the size read-backs of a nonzero / sort / bincount chain per level.
+    xyz [n_obj, n_pts, 3] fp32; first_obj [n_obj] int32 (device): first object of each object's cell.
+    Returns a list of three dicts: fps_idx uint8 [n_obj, n_c], src / dst int32 [E] (dense row, centroid row; sorted by dst,
+    torch_geometric's self-loop rewrite applied when self_loops), cent_ptr int32 [n_obj * n_c + 1]."""
+    _need(xyz, "xyz", torch.float32, 3)
+    dev = xyz.device
+    _need(first_obj, "first_obj", torch.int32, 1, dev)
+    n_obj, n_pts, three = xyz.shape
+    if three != 3 or first_obj.numel() != n_obj:
+        raise RuntimeError("group_edges: xyz must be [n_obj, n_pts, 3] and first_obj [n_obj]")
+    nds, ncs, fps, rows, n_rows = [], [], [], [], []
+    nd = n_pts
+    for _ in range(3):
+        nc = (nd + 1) // 2
+        nds.append(nd)
+        ncs.append(nc)
+        fps.append(torch.empty((n_obj, nc), dtype=torch.uint8, device=dev))
+        rows.append(torch.empty((n_obj, nc * 33), dtype=torch.int16, device=dev))
+        n_rows.append(torch.empty((n_obj,), dtype=torch.int16, device=dev))
+        nd = nc
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    r = (C.c_float * 3)(*[float(v) for v in radius])
+    st = _stream(dev)
+    L.check(L.lib().t2p_group_rows(_ptr(xyz), n_obj, n_pts, r, int(bool(self_loops)), arr(fps), arr(rows), arr(n_rows), st),
+            "t2p_group_rows")
+    cent_ptrs = []
+    for l in range(3):
+        counts = torch.empty((n_obj * ncs[l],), dtype=torch.int32, device=dev)
+        L.check(L.lib().t2p_edge_counts(_ptr(rows[l]), _ptr(n_rows[l]), _ptr(first_obj), n_obj, nds[l], ncs[l],
+                                        int(bool(self_loops)), _ptr(counts), st), "t2p_edge_counts")
+        cp = torch.zeros((n_obj * ncs[l] + 1,), dtype=torch.int32, device=dev)
+        torch.cumsum(counts, 0, dtype=torch.int32, out=cp[1:])
+        cent_ptrs.append(cp)
+    totals = torch.stack([cp[-1] for cp in cent_ptrs]).cpu().tolist()      # the one read-back
+    out = []
+    for l in range(3):
+        e = int(totals[l])
+        src = torch.empty((e,), dtype=torch.int32, device=dev)
+        dst = torch.empty((e,), dtype=torch.int32, device=dev)
+        L.check(L.lib().t2p_edge_expand(_ptr(rows[l]), _ptr(n_rows[l]), _ptr(first_obj), _ptr(cent_ptrs[l]), n_obj, nds[l], ncs[l],
+                                        int(bool(self_loops)), _ptr(src), _ptr(dst), st), "t2p_edge_expand")
+        out.append(dict(fps_idx=fps[l], src=src, dst=dst, cent_ptr=cent_ptrs[l], n_dense=nds[l], n_cent=ncs[l]))
+    return out
+
+
 def dedup_rows(xyz: torch.Tensor, rgb: torch.Tensor, rows: torch.Tensor, n_rows: torch.Tensor):
     """In-place t2p_dedup_rows: rows uint16 [n_obj, (n_pts / 2) * 33] (as int16 storage), n_rows uint16 [n_obj] (int16)."""
     _need(xyz, "xyz", torch.float32, 3)

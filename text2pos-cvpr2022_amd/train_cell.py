@@ -84,7 +84,9 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
 
     def pointnet_branch():
         """models/object_encoder.py:86-98: the PointNet++ (one call per cell) + mlp_pointnet."""
-        gt = ops.sample_group(xyz.contiguous(), pn.radii)
+        # FPS + ball query + torch_geometric's self-loop rewrite as edge lists, built on the device (ops.group_edges; the torch
+        # formulation of the same lists is _sa_edges above, kept as the statement the tests compare against)
+        levels = ops.group_edges(xyz.contiguous(), _i32(first_obj), pn.radii, model.add_self_loops)
         pos = xyz.reshape(n_obj * n_pts, 3)
         x = rgb.reshape(n_obj * n_pts, 3)
         if "color" not in a.use_features:                       # models/object_encoder.py:87-90
@@ -92,12 +94,12 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
         nd = n_pts
         for lvl, sa in enumerate((pn.sa1, pn.sa2, pn.sa3)):
             nc = (nd + 1) // 2
-            fps = gt["fps_idx"][lvl].long()
+            g = levels[lvl]
+            fps = g["fps_idx"].long()
             pos_c = pos.view(n_obj, nd, 3).gather(1, fps[:, :, None].expand(-1, -1, 3)).reshape(n_obj * nc, 3)
-            src, dst = _sa_edges(gt["nbr"][lvl], gt["cnt"][lvl], first_obj, nd, nc, model.add_self_loops)
-            cent_ptr = _ptr_from_counts(torch.bincount(dst, minlength=n_obj * nc))
-            cell_edge_ptr = _ptr_from_counts(torch.bincount(cell_of_obj[dst // nc], minlength=n_cells))
-            msg = TO.edge_features(x, pos, pos_c, _i32(src), _i32(dst))
+            cent_ptr = g["cent_ptr"]
+            cell_edge_ptr = cent_ptr[cell_ptr_dev.long() * nc].contiguous()      # edges per cell = BatchNorm's row segments
+            msg = TO.edge_features(x, pos, pos_c, g["src"], g["dst"])
             h = _mlp_train(msg, sa.point_conv.local_nn, cell_edge_ptr, nc)    # >= one self loop / hit per centroid
             x, pos, nd = TO.segment_max(h, cent_ptr), pos_c, nc
         h = _mlp_train(torch.cat([x, pos], dim=1), pn.ga.mlp, _i32(cell_ptr_dev.long() * nd), nd)
