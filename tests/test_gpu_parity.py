@@ -821,6 +821,28 @@ def test_group_edges_equal_the_tensor_formulation(n_pts, self_loops):
         nd = nc
 
 
+def test_knn_edges_follow_from_the_cell_sizes():
+    """train_cell._host_plan: DynamicEdgeConv's edge arrays (models/cell_retrieval.py:46-48) as gathers through index lists built
+    on the host from the cell sizes alone - t2p_knn lists an object's min(k, cell size) neighbours first and pads with -1 -
+    against the mask formulation (knn >= 0, boolean indexing) they replace: identical targets, sources and row pointers."""
+    from text2pos_amd import ops, train_cell as TC
+    sizes = np.array([1, 9, 8, 3, 26, 7, 2])
+    cp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n_obj, k = int(cp[-1]), 8
+    x = torch.nn.functional.normalize(torch.randn(n_obj, 256, generator=torch.Generator().manual_seed(5)), dim=-1).to(_dev())
+    plan = TC._host_plan(cp, k, _dev())
+    knn = ops.knn(x, plan["cell_ptr"], k, max_seg_rows=int(sizes.max()))
+    valid = knn >= 0
+    assert torch.equal(valid.sum(1).cpu(), torch.from_numpy(np.minimum(k, np.repeat(sizes, sizes))))
+    want_tgt = torch.arange(n_obj, device=_dev())[:, None].expand(-1, k)[valid]
+    want_src = knn[valid]
+    assert torch.equal(plan["knn_tgt"].long(), want_tgt)
+    assert torch.equal(knn.reshape(-1)[plan["knn_slot"].long()], want_src)
+    assert torch.equal(plan["knn_ptr"].long().cpu(), torch.cat([torch.zeros(1, dtype=torch.long), valid.sum(1).cumsum(0).cpu()]))
+    assert plan["first_obj"].cpu().tolist() == np.repeat(cp[:-1], sizes).tolist() and plan["cell_ptr"].cpu().tolist() == cp.tolist()
+    assert plan["seg"][n_obj].cpu().tolist() == [0, n_obj] and plan["seg"][len(sizes)].cpu().tolist() == [0, len(sizes)]
+
+
 def test_segment_max_and_linear_match_torch():
     """Segment max (PointConv / global_max_pool / DynamicEdgeConv aggregation over rows sorted by destination) and Linear on
     the tiled GEMM, forward and backward, against torch; K = 67 exercises the zero-padded operand."""

@@ -62,6 +62,37 @@ def _sa_edges(nbr, cnt, first_obj, nd, nc, self_loops):
     return src, dst
 
 
+def _host_plan(cp: np.ndarray, k: int, dev):
+    """Everything the step's integer plumbing can know from the cell sizes alone, computed on the host and uploaded in ONE
+    (pinned, asynchronous) copy: a tensor created from host data in the middle of the step is a blocking copy queued behind every
+    kernel launched so far - sixteen of those per step kept the host waiting for the GPU.
+    first_obj [n_obj], cell_ptr [B + 1]; the kNN edges of DynamicEdgeConv: knn_ptr [n_obj + 1] (min(k, cell size) edges per
+    object), knn_tgt [E] (target object of every edge), knn_slot [E] (its position in the flattened [n_obj, k] neighbour table);
+    seg[n] = the one-segment row pointer [0, n] for n in {n_obj, n_cells, E}.  All int32."""
+    sizes = cp[1:] - cp[:-1]
+    n_obj, n_cells = int(cp[-1]), int(sizes.shape[0])
+    first = np.repeat(cp[:-1], sizes)
+    kk = np.minimum(k, np.repeat(sizes, sizes))
+    knn_ptr = np.zeros(n_obj + 1, dtype=np.int64)
+    np.cumsum(kk, out=knn_ptr[1:])
+    e = int(knn_ptr[-1])
+    tgt = np.repeat(np.arange(n_obj), kk)
+    slot = np.arange(e) - np.repeat(knn_ptr[:-1], kk) + tgt * k
+    segs = sorted({n_obj, n_cells, e})
+    parts = [first, cp, knn_ptr, tgt, slot] + [np.array([0, n]) for n in segs]
+    flat = np.concatenate(parts).astype(np.int32)
+    host = torch.from_numpy(flat)
+    if dev.type == "cuda":
+        host = host.pin_memory()
+    d = host.to(dev, non_blocking=True)
+    views, a = [], 0
+    for p_ in parts:
+        views.append(d[a: a + p_.shape[0]])
+        a += p_.shape[0]
+    return dict(first_obj=views[0], cell_ptr=views[1], knn_ptr=views[2], knn_tgt=views[3], knn_slot=views[4],
+                seg={n: v for n, v in zip(segs, views[5:])}, _host=host)   # (the pinned buffer outlives the copy with the plan)
+
+
 def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=None, color_idx=None):
     """model: CellRetrievalNetwork in train(); packed device inputs as encode_objects_packed.  Returns [B, D] unit rows with
     a grad_fn; BatchNorm running estimates are updated as the reference's per-cell / per-batch module calls would."""
@@ -74,11 +105,10 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
     n_obj, n_pts = xyz.shape[0], xyz.shape[1]
     cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int64)
     n_cells = cp.shape[0] - 1
-    sizes = torch.from_numpy(cp[1:] - cp[:-1]).to(dev)
-    first_obj = torch.repeat_interleave(torch.from_numpy(cp[:-1]).to(dev), sizes)       # [n_obj]
-    cell_of_obj = torch.repeat_interleave(torch.arange(n_cells, device=dev), sizes)
-    cell_ptr_dev = _i32(torch.from_numpy(cp).to(dev))
-    one = lambda n: torch.tensor([0, n], dtype=torch.int32, device=dev)
+    k = model.graph1.k
+    plan = _host_plan(cp, k, dev)
+    first_obj, cell_ptr_dev = plan["first_obj"], plan["cell_ptr"]
+    one = lambda n: plan["seg"][n]
 
     parts = []
 
@@ -86,7 +116,7 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
         """models/object_encoder.py:86-98: the PointNet++ (one call per cell) + mlp_pointnet."""
         # FPS + ball query + torch_geometric's self-loop rewrite as edge lists, built on the device (ops.group_edges; the torch
         # formulation of the same lists is _sa_edges above, kept as the statement the tests compare against)
-        levels = ops.group_edges(xyz.contiguous(), _i32(first_obj), pn.radii, model.add_self_loops)
+        levels = ops.group_edges(xyz.contiguous(), first_obj, pn.radii, model.add_self_loops)
         pos = xyz.reshape(n_obj * n_pts, 3)
         x = rgb.reshape(n_obj * n_pts, 3)
         if "color" not in a.use_features:                       # models/object_encoder.py:87-90
@@ -127,15 +157,16 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
     emb = _mlp_train(torch.cat(parts, dim=-1), oe.mlp_merge, one(n_obj), n_obj) if len(parts) > 1 else parts[0]
     emb = TO.normalize(emb)
 
-    # DynamicEdgeConv(k = 8, max) inside each cell (models/cell_retrieval.py:46-48, :97), pool, lin, normalize (:98-106)
-    k = model.graph1.k
+    # DynamicEdgeConv(k = 8, max) inside each cell (models/cell_retrieval.py:46-48, :97), pool, lin, normalize (:98-106).
+    # t2p_knn lists an object's min(k, cell size) neighbours first and pads with -1, so which of its slots are edges is known from
+    # the cell sizes: the edge arrays are gathers through host-built index lists (no mask, no nonzero, no size read-back)
     knn = ops.knn(emb.detach().contiguous(), cell_ptr_dev, k, max_seg_rows=int((cp[1:] - cp[:-1]).max()))
-    valid = knn >= 0
-    tgt = torch.arange(n_obj, device=dev)[:, None].expand(-1, k)[valid]
-    srcn = knn[valid].long()
-    msg = TO.pair_features(emb, _i32(tgt), _i32(srcn))
-    h = _mlp_train(msg, model.graph1.nn, one(msg.shape[0]), int(msg.shape[0]))
+    tgt = plan["knn_tgt"]
+    srcn = knn.reshape(-1)[plan["knn_slot"].long()].contiguous()
+    msg = TO.pair_features(emb, tgt, srcn)
+    e_knn = int(tgt.numel())
+    h = _mlp_train(msg, model.graph1.nn, one(e_knn), e_knn)
     pool = TO.segment_max if model.variation == 0 else TO.segment_mean    # models/cell_retrieval.py:46-54, :98-103
-    xg = pool(h, _ptr_from_counts(valid.sum(1)))
+    xg = pool(h, plan["knn_ptr"])
     xc = pool(xg, cell_ptr_dev)
     return TO.normalize(_mlp_train(xc, model.lin, one(n_cells), n_cells))
