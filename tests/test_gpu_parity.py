@@ -788,10 +788,34 @@ def test_bn_relu_train_matches_torch_per_segment(sizes, c, relu):
     assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == len(sizes)
 
 
+def _sa_edges_torch(nbr, cnt, first_obj, nd, nc, self_loops):
+    """Edge list (source dense row, target centroid row) of one set-abstraction level over all objects, sorted by target.
+    nbr [n_obj, nc, 32] / cnt [n_obj, nc]: ball-query hits as indices local to the object's dense set; first_obj [n_obj]:
+    first object of the object's cell."""
+    n_obj = cnt.shape[0]
+    dev = cnt.device
+    hit = torch.arange(32, device=dev)[None, None, :] < cnt.long()[:, :, None]
+    o, c, k = hit.nonzero(as_tuple=True)                       # lexicographic: already sorted by (object, centroid)
+    src = o * nd + nbr[o, c, k].long()
+    dst = o * nc + c
+    if self_loops:
+        f = first_obj[o]
+        keep = (src - f * nd) != (dst - f * nc)                # remove_self_loops on the cell-local indices
+        src, dst = src[keep], dst[keep]
+        rows = torch.arange(n_obj * nc, device=dev)            # every centroid row r: dense row with the same cell-local index
+        fr = first_obj[rows // nc]
+        src = torch.cat([src, fr * nd + (rows - fr * nc)])
+        dst = torch.cat([dst, rows])
+        order = torch.sort(dst, stable=True).indices
+        src, dst = src[order], dst[order]
+    return src, dst
+
+
+
 @pytest.mark.parametrize("n_pts,self_loops", [(256, True), (256, False), (100, True), (16, True)])
 def test_group_edges_equal_the_tensor_formulation(n_pts, self_loops):
     """ops.group_edges (edge lists of the three SA levels built on the device from k_sample_group's compact row lists:
-    t2p_group_rows -> t2p_edge_counts -> prefix -> t2p_edge_expand) against train_cell._sa_edges, the torch statement of
+    t2p_group_rows -> t2p_edge_counts -> prefix -> t2p_edge_expand) against _sa_edges_torch above, the torch statement of
     torch_geometric's rewrite (hit mask -> nonzero -> remove cell-local self loops -> append (i, i) -> stable sort by target) on
     the neighbour tables of t2p_sample_group: identical arrays, including first-of-cell objects whose hit i -> i the appended
     loop replaces, duplicate-heavy objects, odd dense counts (n_pts = 100: 100 / 50 / 25) and cells of 1 .. 9 objects."""
@@ -810,7 +834,7 @@ def test_group_edges_equal_the_tensor_formulation(n_pts, self_loops):
     nd = n_pts
     for lvl in range(3):
         nc = (nd + 1) // 2
-        src, dst = TC._sa_edges(tables["nbr"][lvl], tables["cnt"][lvl], first, nd, nc, self_loops)
+        src, dst = _sa_edges_torch(tables["nbr"][lvl], tables["cnt"][lvl], first, nd, nc, self_loops)
         g = got[lvl]
         assert torch.equal(g["fps_idx"], tables["fps_idx"][lvl])
         assert g["src"].dtype == torch.int32 and torch.equal(g["src"].long(), src) and torch.equal(g["dst"].long(), dst), lvl

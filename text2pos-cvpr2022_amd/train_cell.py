@@ -10,8 +10,9 @@ Same graph as the inference kernels, but every BatchNorm1d normalises with the s
     BatchNorm + ReLU per segment, segment max with arg-max routing);
   * the message inputs of the two graph operators and F.normalize are HIP kernels with backward kernels as well
     (t2p_edge_features_*, t2p_pair_features_*, t2p_rownorm / t2p_rownorm_backward); what is left to torch tensor ops is
-    integer plumbing (edge lists, row pointers), the concatenation of the three object feature parts and the ReLU behind
-    the two plain Linear heads.
+    a few gathers and row-pointer products, the concatenation of the three object feature parts and the ReLU behind the two
+    plain Linear heads; PointConv's edge lists come from ops.group_edges (device-side), everything the cell sizes alone
+    determine from one host plan (_host_plan).
 The PointConv self-loop rewrite of torch_geometric (remove edges whose two CELL-local indices agree, append (i, i) for
 every centroid row i of the cell: dense row i of the cell feeds centroid row i) is reproduced on the edge lists exactly as
 the inference path encodes it in its row tables."""
@@ -26,40 +27,12 @@ def _i32(t):
     return t.to(torch.int32).contiguous()
 
 
-def _ptr_from_counts(counts):
-    """[n] counts -> int32 [n + 1] row pointer (device)."""
-    return _i32(torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]))
-
-
 def _mlp_train(x, mlp, seg_ptr, rows_min):
     """get_mlp block list (Linear, BatchNorm1d, ReLU) in training mode; statistics per row segment.  rows_min: the
     smallest segment's row count (known on the host); a single-row segment raises as nn.BatchNorm1d does."""
     for blk in mlp:
         x = TO.bn_relu_train(TO.linear(x, blk[0]), seg_ptr, blk[1], relu=True, rows_min=rows_min)
     return x
-
-
-def _sa_edges(nbr, cnt, first_obj, nd, nc, self_loops):
-    """Edge list (source dense row, target centroid row) of one set-abstraction level over all objects, sorted by target.
-    nbr [n_obj, nc, 32] / cnt [n_obj, nc]: ball-query hits as indices local to the object's dense set; first_obj [n_obj]:
-    first object of the object's cell."""
-    n_obj = cnt.shape[0]
-    dev = cnt.device
-    hit = torch.arange(32, device=dev)[None, None, :] < cnt.long()[:, :, None]
-    o, c, k = hit.nonzero(as_tuple=True)                       # lexicographic: already sorted by (object, centroid)
-    src = o * nd + nbr[o, c, k].long()
-    dst = o * nc + c
-    if self_loops:
-        f = first_obj[o]
-        keep = (src - f * nd) != (dst - f * nc)                # remove_self_loops on the cell-local indices
-        src, dst = src[keep], dst[keep]
-        rows = torch.arange(n_obj * nc, device=dev)            # every centroid row r: dense row with the same cell-local index
-        fr = first_obj[rows // nc]
-        src = torch.cat([src, fr * nd + (rows - fr * nc)])
-        dst = torch.cat([dst, rows])
-        order = torch.sort(dst, stable=True).indices
-        src, dst = src[order], dst[order]
-    return src, dst
 
 
 def _host_plan(cp: np.ndarray, k: int, dev):
@@ -115,7 +88,8 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
     def pointnet_branch():
         """models/object_encoder.py:86-98: the PointNet++ (one call per cell) + mlp_pointnet."""
         # FPS + ball query + torch_geometric's self-loop rewrite as edge lists, built on the device (ops.group_edges; the torch
-        # formulation of the same lists is _sa_edges above, kept as the statement the tests compare against)
+        # formulation of the same lists - hit mask, nonzero, remove / append self loops, stable sort - is the statement
+        # tests/test_gpu_parity.py::test_group_edges_equal_the_tensor_formulation compares it against)
         levels = ops.group_edges(xyz.contiguous(), first_obj, pn.radii, model.add_self_loops)
         pos = xyz.reshape(n_obj * n_pts, 3)
         x = rgb.reshape(n_obj * n_pts, 3)
