@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 23
+#define T2P_ABI_VERSION 24
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
@@ -343,7 +343,8 @@ int t2p_lstm_cell_backward(const float* dh_gemm, const float* dh_carry_in, const
  * x, y [M][C] fp32; seg_ptr [n_seg+1] int32 (device) tiles the rows; mean / invstd / var_unbiased [n_seg][C] (biased
  * variance normalises, the unbiased one feeds the running estimate; float64 accumulation in a fixed order: row chunks of a
  * segment are reduced by separate workgroups into `workspace` - t2p_bn_train_workspace_bytes - and combined in order).
- * backward: dx [M][C]; dgamma_seg / dbeta_seg [n_seg][C] per segment (the caller sums them over the segments); it takes x
+ * backward: dx [M][C]; dgamma_seg / dbeta_seg [n_seg + 1][C]: per segment, and in row n_seg their sum over the segments (the
+ * layer's weight / bias gradient, added in float64 in segment order); it takes x
  * and the layer's beta [C], not y: the ReLU mask (y > 0) is recomputed from x exactly as the forward formed y.
  * Segment max (PointConv aggr="max", gnn.global_max_pool, DynamicEdgeConv aggr="max" over rows sorted by destination):
  * out [n_seg][C], arg [n_seg][C] = winning row (first one on ties, -1 and out = 0 for an empty segment); the backward

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p

@@ -159,6 +159,18 @@ __global__ void k_bn_bwd_finish(const double* __restrict__ part, int n_seg, int 
     dbeta_seg[i] = (float)s0;
     dgamma_seg[i] = (float)s1;
 }
+// stage 2b: row n_seg of both tables = the sum over the segments (the layer's weight / bias gradient), float64, segment order
+__global__ void k_bn_bwd_total(int n_seg, int C, float* __restrict__ dgamma_seg, float* __restrict__ dbeta_seg) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double t0 = 0.0, t1 = 0.0;
+    for (int s = 0; s < n_seg; s++) {
+        t0 += (double)dbeta_seg[(int64_t)s * C + c];
+        t1 += (double)dgamma_seg[(int64_t)s * C + c];
+    }
+    dbeta_seg[(int64_t)n_seg * C + c] = (float)t0;
+    dgamma_seg[(int64_t)n_seg * C + c] = (float)t1;
+}
 // stage 3: dx = gamma invstd (dz - sum dz / n - xhat sum(dz xhat) / n)
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ beta, const int32_t* __restrict__ seg_ptr, int C,
@@ -681,6 +693,8 @@ int launch_bn_relu_train_backward(const float* dy, const float* x, const float* 
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3((unsigned)((sc + 255) / 256)), dim3(256), 0, st, part, n_seg, C, R, dgamma_seg,
                        dbeta_seg);
     T2P_CHECK_LAUNCH("bn_bwd_finish");
+    hipLaunchKernelGGL(k_bn_bwd_total, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, n_seg, C, dgamma_seg, dbeta_seg);
+    T2P_CHECK_LAUNCH("bn_bwd_total");
     if (vec && C <= 32) hipLaunchKernelGGL(k_bn_bwd_apply4<8>, grid8, dim3(256), 0, st, dy, x, beta, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg, dbeta_seg, dx);
     else if (vec) hipLaunchKernelGGL(k_bn_bwd_apply4<16>, grid, dim3(256), 0, st, dy, x, beta, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg, dbeta_seg, dx);
     else hipLaunchKernelGGL(k_bn_bwd_apply, grid, dim3(256), 0, st, dy, x, beta, seg_ptr, C, mean, invstd, gamma, relu, dgamma_seg,

@@ -42,13 +42,16 @@ class _BnReluTrainFn(torch.autograd.Function):
         n_seg, c = mean.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dg, db = (torch.empty((n_seg, c), dtype=torch.float32, device=dev) for _ in range(2))
+        dg, db = (torch.empty((n_seg + 1, c), dtype=torch.float32, device=dev) for _ in range(2))   # row n_seg: the sum over the segments
         m = x.shape[0]
+        if n_seg == 0:
+            dg.zero_()
+            db.zero_()
         ws = torch.empty((max(1, L.lib().t2p_bn_train_workspace_bytes(m, n_seg, c)),), dtype=torch.uint8, device=dev)
         L.check(L.lib().t2p_bn_relu_train_backward(_ptr(dy), _ptr(x), _ptr(beta.contiguous()), _ptr(seg_ptr), n_seg, m, c, _ptr(mean),
                                                    _ptr(invstd), _ptr(gamma), int(ctx.relu), _ptr(dx), _ptr(dg), _ptr(db),
                                                    _ptr(ws), ws.numel(), _stream(dev)), "t2p_bn_relu_train_backward")
-        return dx, None, dg.sum(0), db.sum(0), None, None
+        return dx, None, dg[n_seg], db[n_seg], None, None
 
 
 def bn_relu_train(x, seg_ptr, bn: torch.nn.BatchNorm1d, relu: bool = True, rows_min: int = None):
@@ -101,7 +104,9 @@ class _SegmentMaxFn(torch.autograd.Function):
     def backward(ctx, dout):
         arg, seg_ptr = ctx.saved_tensors
         n_seg, c = arg.shape
-        dx = torch.zeros((ctx.rows, c), dtype=torch.float32, device=dout.device)
+        # (no zero fill: the segments tile the rows - every caller's seg_ptr runs from 0 to the row count - and the kernel writes
+        # every element of every segment's rows, the winner's gradient or 0)
+        dx = torch.empty((ctx.rows, c), dtype=torch.float32, device=dout.device)
         L.check(L.lib().t2p_segment_max_backward(_ptr(dout.contiguous()), _ptr(arg), _ptr(seg_ptr), n_seg, c, _ptr(dx),
                                                  _stream(dout.device)), "t2p_segment_max_backward")
         return dx, None
