@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 24
+#define T2P_ABI_VERSION 25
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
@@ -369,13 +369,14 @@ int t2p_segment_mean_backward(const float* dout, const int32_t* seg_ptr, int32_t
                               t2p_stream_t stream);
 
 /* Message inputs of the two graph operators and F.normalize, with their backward (training mode):
- *   edge features  out [E][C+3] = [x[src] | pos[src] - pos_c[dst]]   (PointConv, models/pointcloud/pointnet2.py:31-35);
+ *   edge features  out [E][width] = [x[src] | pos[src] - pos_c[dst] | 0 ..]   (PointConv, models/pointcloud/pointnet2.py:31-35;
+ *                  width >= C + 3 is the row pitch of out / d_out: a multiple of 8 spares the Linear behind it a padded copy);
  *                  backward: dx [rows of x][C] += d_out[:, :C] at src (dx zeroed by the caller; float atomics)
  *   pair features  out [E][2D] = [x[tgt] | x[src] - x[tgt]]          (DynamicEdgeConv, models/cell_retrieval.py:46-48)
  *   rownorm backward: gradient of t2p_rownorm (F.normalize, eps 1e-12) */
 int t2p_edge_features_forward(const float* x, const float* pos, const float* pos_c, const int32_t* src, const int32_t* dst,
-                              int64_t n_edges, int32_t channels, float* out, t2p_stream_t stream);
-int t2p_edge_features_backward(const float* d_out, const int32_t* src, int64_t n_edges, int32_t channels, float* dx,
+                              int64_t n_edges, int32_t channels, int32_t width, float* out, t2p_stream_t stream);
+int t2p_edge_features_backward(const float* d_out, const int32_t* src, int64_t n_edges, int32_t channels, int32_t width, float* dx,
                                t2p_stream_t stream);
 int t2p_pair_features_forward(const float* x, const int32_t* tgt, const int32_t* src, int64_t n_edges, int32_t dim, float* out,
                               t2p_stream_t stream);

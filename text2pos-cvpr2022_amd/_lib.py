@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -87,8 +87,8 @@ SYMBOLS = {
                                             C.c_int32, c_void, c_void, c_void, c_void, c_void, C.c_size_t, c_void]),
     "t2p_bn_relu_train_backward": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int32, C.c_int64, C.c_int32, c_void, c_void,
                                              c_void, C.c_int32, c_void, c_void, c_void, c_void, C.c_size_t, c_void]),
-    "t2p_edge_features_forward": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, c_void, c_void]),
-    "t2p_edge_features_backward": (C.c_int, [c_void, c_void, C.c_int64, C.c_int32, c_void, c_void]),
+    "t2p_edge_features_forward": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, C.c_int32, c_void, c_void]),
+    "t2p_edge_features_backward": (C.c_int, [c_void, c_void, C.c_int64, C.c_int32, C.c_int32, c_void, c_void]),
     "t2p_pair_features_forward": (C.c_int, [c_void, c_void, c_void, C.c_int64, C.c_int32, c_void, c_void]),
     "t2p_pair_features_backward": (C.c_int, [c_void, c_void, c_void, C.c_int64, C.c_int32, c_void, c_void]),
     "t2p_rownorm_backward": (C.c_int, [c_void, c_void, C.c_int64, C.c_int32, c_void, c_void]),

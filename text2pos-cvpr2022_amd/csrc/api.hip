@@ -797,16 +797,16 @@ int t2p_bn_relu_train_backward(const float* dy, const float* x, const float* bet
 }
 
 int t2p_edge_features_forward(const float* x, const float* pos, const float* pos_c, const int32_t* src, const int32_t* dst,
-                              int64_t n_edges, int32_t channels, float* out, t2p_stream_t stream) {
+                              int64_t n_edges, int32_t channels, int32_t width, float* out, t2p_stream_t stream) {
     T2P_CHECK_ARG(pos && pos_c && src && dst && out && (x || channels == 0), "edge_features_forward: NULL argument");
     T2P_CHECK_ARG(n_edges >= 0 && channels >= 0, "edge_features_forward: bad sizes");
-    return launch_edge_feat_fwd(x, pos, pos_c, src, dst, n_edges, channels, out, (hipStream_t)stream);
+    return launch_edge_feat_fwd(x, pos, pos_c, src, dst, n_edges, channels, width, out, (hipStream_t)stream);
 }
-int t2p_edge_features_backward(const float* d_out, const int32_t* src, int64_t n_edges, int32_t channels, float* dx,
+int t2p_edge_features_backward(const float* d_out, const int32_t* src, int64_t n_edges, int32_t channels, int32_t width, float* dx,
                                t2p_stream_t stream) {
     T2P_CHECK_ARG(d_out && src && (dx || channels == 0), "edge_features_backward: NULL argument");
     T2P_CHECK_ARG(n_edges >= 0 && channels >= 0, "edge_features_backward: bad sizes");
-    return launch_edge_feat_bwd(d_out, src, n_edges, channels, dx, (hipStream_t)stream);
+    return launch_edge_feat_bwd(d_out, src, n_edges, channels, width, dx, (hipStream_t)stream);
 }
 int t2p_pair_features_forward(const float* x, const int32_t* tgt, const int32_t* src, int64_t n_edges, int32_t dim, float* out,
                               t2p_stream_t stream) {

@@ -327,8 +327,8 @@ int launch_bn_relu_train_backward(const float* dy, const float* x, const float* 
                                   int64_t rows, int C, const float* mean, const float* invstd, const float* gamma, int relu,
                                   float* dx, float* dgamma_seg, float* dbeta_seg, double* part, hipStream_t st);
 int launch_edge_feat_fwd(const float* x, const float* pos, const float* pos_c, const int32_t* src, const int32_t* dst, int64_t E,
-                         int C, float* out, hipStream_t st);
-int launch_edge_feat_bwd(const float* dout, const int32_t* src, int64_t E, int C, float* dx, hipStream_t st);
+                         int C, int W, float* out, hipStream_t st);
+int launch_edge_feat_bwd(const float* dout, const int32_t* src, int64_t E, int C, int W, float* dx, hipStream_t st);
 int launch_pair_feat_fwd(const float* x, const int32_t* tgt, const int32_t* src, int64_t E, int D, float* out, hipStream_t st);
 int launch_pair_feat_bwd(const float* dout, const int32_t* tgt, const int32_t* src, int64_t E, int D, float* dx, hipStream_t st);
 int launch_segment_mean(const float* x, const int32_t* seg_ptr, int n_seg, int C, float* out, hipStream_t st);

@@ -458,20 +458,23 @@ __global__ __launch_bounds__(256) void k_segment_mean_backward(const float* __re
 // PointConv message input of every edge: out[e] = [x[src[e]] | pos[src[e]] - pos_c[dst[e]]]  (models/pointcloud/pointnet2.py:31-35:
 // cat([x_j, pos_j - pos_i])); one thread per output element
 __global__ void k_edge_feat_fwd(const float* __restrict__ x, const float* __restrict__ pos, const float* __restrict__ pos_c,
-                                const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E, int C,
+                                const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E, int C, int W,
                                 float* __restrict__ out) {
-    const int W = C + 3;
+    // W >= C + 3: row pitch of out; the columns behind the message are written as zeros (a pitch that is a multiple of 8 hands the
+    // Linear layer behind it an operand it need not pad: the copy of [E, 67] into [E, 72] was 0.1-0.15 ms per level and direction)
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= E * W) return;
     const int64_t e = i / W;
     const int c = (int)(i % W);
     const int s = src[e];
-    out[i] = c < C ? x[(int64_t)s * C + c] : pos[(int64_t)s * 3 + (c - C)] - pos_c[(int64_t)dst[e] * 3 + (c - C)];
+    float v = 0.f;
+    if (c < C) v = x[(int64_t)s * C + c];
+    else if (c < C + 3) v = pos[(int64_t)s * 3 + (c - C)] - pos_c[(int64_t)dst[e] * 3 + (c - C)];
+    out[i] = v;
 }
 // its backward with respect to x (positions are inputs): dx[src[e]] += dout[e][:C]; dx zeroed by the caller
-__global__ void k_edge_feat_bwd(const float* __restrict__ dout, const int32_t* __restrict__ src, int64_t E, int C,
+__global__ void k_edge_feat_bwd(const float* __restrict__ dout, const int32_t* __restrict__ src, int64_t E, int C, int W,
                                 float* __restrict__ dx) {
-    const int W = C + 3;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= E * C) return;
     const int64_t e = i / C;
@@ -525,17 +528,19 @@ __global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ x
 }  // namespace
 
 int launch_edge_feat_fwd(const float* x, const float* pos, const float* pos_c, const int32_t* src, const int32_t* dst, int64_t E,
-                         int C, float* out, hipStream_t st) {
-    const int64_t n = E * (C + 3);
+                         int C, int W, float* out, hipStream_t st) {
+    T2P_CHECK_ARG(W >= C + 3, "edge_features: width %d < channels + 3 = %d", W, C + 3);
+    const int64_t n = E * W;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_edge_feat_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, pos, pos_c, src, dst, E, C, out);
+    hipLaunchKernelGGL(k_edge_feat_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, pos, pos_c, src, dst, E, C, W, out);
     T2P_CHECK_LAUNCH("edge_feat_fwd");
     return 0;
 }
-int launch_edge_feat_bwd(const float* dout, const int32_t* src, int64_t E, int C, float* dx, hipStream_t st) {
+int launch_edge_feat_bwd(const float* dout, const int32_t* src, int64_t E, int C, int W, float* dx, hipStream_t st) {
+    T2P_CHECK_ARG(W >= C + 3, "edge_features: width %d < channels + 3 = %d", W, C + 3);
     const int64_t n = E * C;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_edge_feat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, src, E, C, dx);
+    hipLaunchKernelGGL(k_edge_feat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, src, E, C, W, dx);
     T2P_CHECK_LAUNCH("edge_feat_bwd");
     return 0;
 }

@@ -148,24 +148,27 @@ class _EdgeFeaturesFn(torch.autograd.Function):
     def forward(ctx, x, pos, pos_c, src, dst):
         dev = pos.device
         e, c = src.numel(), x.shape[1]
-        out = torch.empty((e, c + 3), dtype=torch.float32, device=dev)
-        L.check(L.lib().t2p_edge_features_forward(_ptr(x), _ptr(pos), _ptr(pos_c), _ptr(src), _ptr(dst), e, c, _ptr(out),
+        w = (c + 3 + 7) // 8 * 8                           # row pitch: the GEMM's granule, zero columns behind the message
+        out = torch.empty((e, w), dtype=torch.float32, device=dev)
+        L.check(L.lib().t2p_edge_features_forward(_ptr(x), _ptr(pos), _ptr(pos_c), _ptr(src), _ptr(dst), e, c, w, _ptr(out),
                                                   _stream(dev)), "t2p_edge_features_forward")
         ctx.save_for_backward(src)
         ctx.shape = tuple(x.shape)
+        ctx.width = w
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (src,) = ctx.saved_tensors
         dx = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
-        L.check(L.lib().t2p_edge_features_backward(_ptr(dout.contiguous()), _ptr(src), src.numel(), ctx.shape[1], _ptr(dx),
+        L.check(L.lib().t2p_edge_features_backward(_ptr(dout.contiguous()), _ptr(src), src.numel(), ctx.shape[1], ctx.width, _ptr(dx),
                                                    _stream(dout.device)), "t2p_edge_features_backward")
         return dx, None, None, None, None
 
 
 def edge_features(x, pos, pos_c, src, dst):
-    """[x[src] | pos[src] - pos_c[dst]] per edge; src / dst int32 (device); gradient to x only (positions are inputs)."""
+    """[x[src] | pos[src] - pos_c[dst] | 0 ...] per edge, C + 3 columns zero-padded to a multiple of 8 (linear() pairs the pad
+    columns with zero weight columns); src / dst int32 (device); gradient to x only (positions are inputs)."""
     return _EdgeFeaturesFn.apply(x.contiguous(), pos.contiguous(), pos_c.contiguous(), src, dst)
 
 
@@ -222,11 +225,14 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         k, n = x.shape[1], weight.shape[0]
+        kw = weight.shape[1]                               # k > kw: x arrives with zero columns behind its kw inputs (edge_features)
         pad = (-k) % 8                                     # the GEMM wants K % 4 == 0 and N % 8 == 0: zero columns
         xp = torch.nn.functional.pad(x.detach(), (0, pad)).contiguous() if pad else x.detach().contiguous()
-        wp = torch.nn.functional.pad(weight.detach(), (0, pad)).contiguous() if pad else weight.detach().contiguous()
+        wp = (torch.nn.functional.pad(weight.detach(), (0, k + pad - kw)).contiguous() if k + pad != kw
+              else weight.detach().contiguous())
         ctx.save_for_backward(xp, wp)
         ctx.k = k
+        ctx.kw = kw
         ctx.has_bias = bias is not None
         b = bias.detach().contiguous() if bias is not None else None
         pad_n = (-n) % 8                                   # e.g. --embed_dim 300 (training/args.py:19): zero output columns, cut off
@@ -247,7 +253,7 @@ class _LinearFn(torch.autograd.Function):
         want_b = bool(need_b and ctx.has_bias)
         if need_w:                                         # frozen layers (--pointnet_freeze) skip it
             dw, db = ops.linear_wgrad(dy, xp, want_colsum=want_b)
-            dw = dw[:, : ctx.k]
+            dw = dw[:, : ctx.kw]
         elif want_b:
             db = dy.sum(0)
         return dx, dw, db
