@@ -24,7 +24,7 @@ namespace {
 template <int TPW>
 __global__ __launch_bounds__(512) void k_wgrad_f32(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                    float* __restrict__ part, float* __restrict__ psum, int64_t M, int K1, int N,
-                                                   int n_blocks_n, int64_t rows_per_split, int n_phase, int tiles_pow2, int rows_chunk) {
+                                                   int n_blocks_n, int64_t rows_per_split, int n_phase, int ktp, int ntp, int rows_chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][rows_chunk][kw + nw]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -38,66 +38,72 @@ __global__ __launch_bounds__(512) void k_wgrad_f32(const float* __restrict__ A, 
     const int64_t m_lo = (int64_t)blockIdx.x * rows_per_split;
     const int64_t m_hi = (m_lo + rows_per_split) < M ? (m_lo + rows_per_split) : M;
 
-    // tiles of this wave: n_tiles >= 8: wave, wave + 8, ... ; fewer: tile = wave % tiles_pow2, the other waves of the same tile
-    // take every n_phase-th row pair (their partial blocks are separate summands of the reduction)
-    const int phase = (n_phase > 1) ? wave / tiles_pow2 : 0;
-    int tk[TPW], tn[TPW];
+    // Tiles of this wave.  The eight waves form ktp row groups (ktp = 1, 2, 4, 8 >= the block's tile rows): wave w works in tile
+    // row kt = w % ktp, so ONE read of dY per row pair serves all its tiles; the G = 8 / ktp waves of a tile row share its nt_n
+    // tiles: wave g of them takes nt = g, g + G, ...  With fewer tile columns than waves (ntp = pow2 >= nt_n < G) the surplus
+    // waves split the row pairs instead: phase = g / ntp of n_phase = G / ntp (their partial blocks are separate summands).
+    const int kt = wave % ktp, grp = wave / ktp, G = 8 / ktp;
+    const int phase = (n_phase > 1) ? grp / ntp : 0;
+    const bool a_live = kt < kt_n;
+    int boff[TPW];                                        // LDS column of tile i's X operand (0 for a tile that does not exist)
+    int tn[TPW];
     bool live[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; i++) {
-        const int t = (n_phase > 1) ? wave % tiles_pow2 : wave + 8 * i;
-        live[i] = t < n_tiles && (n_phase == 1 || i == 0);
-        tk[i] = live[i] ? t / nt_n : 0;
-        tn[i] = live[i] ? t % nt_n : 0;
+        const int nt = (n_phase > 1) ? grp % ntp : grp + G * i;
+        live[i] = a_live && nt < nt_n && (n_phase == 1 || i == 0);
+        tn[i] = live[i] ? nt : 0;
+        boff[i] = kw4 + tn[i] * 32 + l31;
     }
+    const int aoff = (a_live ? kt : 0) * 32 + l31;
+    const bool sums_here = a_live && tn[0] == 0 && live[0];   // this wave holds tile (kt, 0): it adds dY's column sums of its rows
+    (void)n_tiles;
     f32x16 acc[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; i++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
-    float colsum[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; i++) colsum[i] = 0.f;
+    float colsum = 0.f;
 
-    // staging plan of this thread: up to 8 float4 pieces of a chunk; (row in chunk, source column) do not change from chunk to chunk
+    // staging plan of this thread: up to 8 float4 pieces of a chunk; (row in chunk, source column) do not change from chunk to
+    // chunk and are kept as ONE packed word per piece (the accumulators leave no room for more):
+    //   bits 0-9 row in chunk | 10-16 float4 column inside the operand | 17-19 live elements (0 = no piece, 4 = whole) | 20 operand X
     const int pieces_row = ldl / 4;                       // float4 pieces per staged row
     const int n_pieces = rows_chunk * pieces_row;         // <= 4096 (the host's choice of rows_chunk)
     constexpr int MAXP = 8;
-    int prow[MAXP], pcnt[MAXP];                           // row inside the chunk; live elements of the piece (0 = no piece, 4 = whole)
-    const float* psrc[MAXP];                              // source of the piece in row 0 of the operand
-    int ppitch[MAXP];
+    uint32_t plan[MAXP];
 #pragma unroll
     for (int p = 0; p < MAXP; p++) {
         const int idx = p * 512 + tid;
-        prow[p] = 0;
-        pcnt[p] = 0;
-        psrc[p] = A;
-        ppitch[p] = lda;
+        plan[p] = 0u;
         if (idx < n_pieces) {
             const int r = idx / pieces_row, q = idx % pieces_row;
-            prow[p] = r;
             if (q * 4 < kw4) {                            // (a piece never straddles the two operands: kw4 is a multiple of 4)
-                psrc[p] = A + k_base + q * 4;
-                pcnt[p] = (kw - q * 4) < 4 ? (kw - q * 4) : 4;
+                const int cnt = (kw - q * 4) < 4 ? (kw - q * 4) : 4;
+                plan[p] = (uint32_t)r | ((uint32_t)q << 10) | ((uint32_t)cnt << 17);
             } else {
-                const int c = q * 4 - kw4;
-                psrc[p] = B + n_base + c;
-                ppitch[p] = ldb;
-                pcnt[p] = (nw - c) < 4 ? (nw - c) : 4;
+                const int qb = q - kw4 / 4;
+                const int cnt = (nw - qb * 4) < 4 ? (nw - qb * 4) : 4;
+                plan[p] = (uint32_t)r | ((uint32_t)qb << 10) | ((uint32_t)cnt << 17) | (1u << 20);
             }
         }
     }
+    const float* const a_blk = A + k_base;
+    const float* const b_blk = B + n_base;
     f32x4 stage[MAXP];
     auto load = [&](int64_t m) {
 #pragma unroll
         for (int p = 0; p < MAXP; p++) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            const int64_t row = m + prow[p];
-            if (pcnt[p] > 0 && row < m_hi) {
-                const float* src = psrc[p] + row * (int64_t)ppitch[p];
-                if (pcnt[p] == 4) v = *(const f32x4*)src;
+            const uint32_t w = plan[p];
+            const int cnt = (int)((w >> 17) & 7u);
+            const int64_t row = m + (int)(w & 1023u);
+            if (cnt > 0 && row < m_hi) {
+                const bool is_b = (w >> 20) & 1u;
+                const float* src = (is_b ? b_blk + row * (int64_t)ldb : a_blk + row * (int64_t)lda) + ((w >> 10) & 127u) * 4;
+                if (cnt == 4) v = *(const f32x4*)src;
                 else
-                    for (int e = 0; e < 4; e++) v[e] = e < pcnt[p] ? src[e] : 0.f;   // tail columns of a block no multiple of 4 wide
+                    for (int e = 0; e < 4; e++) v[e] = e < cnt ? src[e] : 0.f;   // tail columns of a block no multiple of 4 wide
             }
             stage[p] = v;
         }
@@ -117,16 +123,23 @@ __global__ __launch_bounds__(512) void k_wgrad_f32(const float* __restrict__ A, 
         __syncthreads();
         if (m + rows_chunk < m_hi) load(m + rows_chunk);
         const float* t0 = lds + buf * rows_chunk * ldl;
-        for (int rp = phase; rp < rows_chunk / 2; rp += n_phase) {
-            const float* rowp = t0 + (2 * rp + h) * ldl;
+        // one row pair: the dY operand once, the wave's X operands, then the MFMAs (the first form of this loop read two operands,
+        // waited and multiplied, tile by tile behind a branch each: 41 % of the fp32 matrix rate)
+        if (a_live) {                                         // (uniform)
+            // one row pair: the dY operand once, the wave's X operands, then the MFMAs.  (The first form of this loop read two
+            // operands, waited and multiplied, tile by tile behind a branch each: 41 % of the fp32 matrix rate; reading the next
+            // pair's operands ahead by hand on top of this form changed nothing.)
+            for (int rp = phase; rp < rows_chunk / 2; rp += n_phase) {
+                const float* rowp = t0 + (2 * rp + h) * ldl;
+                const float a = rowp[aoff];               // columns past kw / nw of a tile hold zeros or the other operand:
+                float b[TPW];                             // masked at the write-out
 #pragma unroll
-            for (int i = 0; i < TPW; i++) {
-                if (live[i]) {                                   // (uniform)
-                    const float a = rowp[tk[i] * 32 + l31];      // columns past kw / nw of the tile hold zeros or the other operand:
-                    const float b = rowp[kw4 + tn[i] * 32 + l31];   // masked at the write-out
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-                    if (tn[i] == 0) colsum[i] += a;
-                }
+                for (int i = 0; i < TPW; i++) b[i] = rowp[boff[i]];
+                // (a tile slot past the block's last tile column multiplies the operand of column 0 into an accumulator that
+                // is never written out: no branch in this loop - with one around each MFMA hipcc spilled the accumulators)
+#pragma unroll
+                for (int i = 0; i < TPW; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[i], acc[i], 0, 0, 0);
+                if (sums_here) colsum += a;
             }
         }
         buf ^= 1;
@@ -139,13 +152,13 @@ __global__ __launch_bounds__(512) void k_wgrad_f32(const float* __restrict__ A, 
         if (!live[i]) continue;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-            const int kl = tk[i] * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, nl = tn[i] * 32 + l31;
+            const int kl = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, nl = tn[i] * 32 + l31;
             if (kl < kw && nl < nw) out[(int64_t)(k_base + kl) * N + n_base + nl] = acc[i][e];
         }
-        if (psum != nullptr && nb == 0 && tn[i] == 0) {
-            const int kl = tk[i] * 32 + l31;
-            if (kl < kw) psum[(slot * 2 + h) * (int64_t)K1 + k_base + kl] = colsum[i];
-        }
+    }
+    if (psum != nullptr && nb == 0 && sums_here) {
+        const int kl = kt * 32 + l31;
+        if (kl < kw) psum[(slot * 2 + h) * (int64_t)K1 + k_base + kl] = colsum;
     }
 }
 
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_wave(const float* __restri
 }
 
 struct WgradPlan {
-    int blocks_k, blocks_n, tpw, n_phase, tiles_pow2, splits, rows_chunk;
+    int blocks_k, blocks_n, tpw, n_phase, ktp, ntp, splits, rows_chunk;
     int64_t rows_per_split;
     size_t lds_bytes;
 };
@@ -200,14 +213,17 @@ WgradPlan wgrad_plan(int64_t M, int K1, int N) {
     p.blocks_k = (K1 + 255) / 256;
     p.blocks_n = (N + 255) / 256;
     const int kw = K1 < 256 ? K1 : 256, nw = N < 256 ? N : 256;
-    const int tiles = ((kw + 31) / 32) * ((nw + 31) / 32);           // of the largest block
+    const int kt_n = (kw + 31) / 32, nt_n = (nw + 31) / 32;          // tile rows / columns of the largest block
+    p.ktp = kt_n <= 1 ? 1 : (kt_n <= 2 ? 2 : (kt_n <= 4 ? 4 : 8));
+    const int G = 8 / p.ktp;                                          // waves per tile row
     p.n_phase = 1;
-    p.tiles_pow2 = 8;
-    if (tiles >= 8) p.tpw = tiles <= 8 ? 1 : (tiles <= 16 ? 2 : (tiles <= 32 ? 4 : 8));
-    else {
+    p.ntp = 1;
+    if (nt_n >= G) {
+        p.tpw = (nt_n + G - 1) / G;                                   // tiles per wave: 1 .. 8
+    } else {
         p.tpw = 1;
-        p.tiles_pow2 = tiles <= 1 ? 1 : (tiles <= 2 ? 2 : 4);
-        p.n_phase = 8 / p.tiles_pow2;
+        p.ntp = nt_n <= 1 ? 1 : (nt_n <= 2 ? 2 : 4);
+        p.n_phase = G / p.ntp;
     }
     // rows per staged chunk: as many as 8 float4 pieces per thread carry (narrow operands: a barrier per 32 rows would be all
     // the kernel does), at most 512
@@ -259,12 +275,18 @@ int launch_linear_wgrad_f32(const float* dY, int lda, const float* X, int ldb, f
     {                                                                                                                              \
         T2P_TRY(reserve_lds((const void*)k_wgrad_f32<T>, p.lds_bytes, "wgrad_f32"));                                               \
         hipLaunchKernelGGL(k_wgrad_f32<T>, grid, dim3(512), p.lds_bytes, st, dY, lda, X, ldb, part, psum, M, K1, N, p.blocks_n,    \
-                           p.rows_per_split, p.n_phase, p.tiles_pow2, p.rows_chunk);                                               \
+                           p.rows_per_split, p.n_phase, p.ktp, p.ntp, p.rows_chunk);                                               \
     }
-        if (p.tpw == 1) WGRAD_CASE(1)
-        else if (p.tpw == 2) WGRAD_CASE(2)
-        else if (p.tpw == 4) WGRAD_CASE(4)
-        else WGRAD_CASE(8)
+        switch (p.tpw) {
+            case 1: WGRAD_CASE(1) break;
+            case 2: WGRAD_CASE(2) break;
+            case 3: WGRAD_CASE(3) break;
+            case 4: WGRAD_CASE(4) break;
+            case 5: WGRAD_CASE(5) break;
+            case 6: WGRAD_CASE(6) break;
+            case 7: WGRAD_CASE(7) break;
+            default: WGRAD_CASE(8) break;
+        }
 #undef WGRAD_CASE
         T2P_CHECK_LAUNCH("linear_wgrad");
     }
