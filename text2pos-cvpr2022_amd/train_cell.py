@@ -3,7 +3,7 @@
 
 Same graph as the inference kernels, but every BatchNorm1d normalises with the statistics of the current rows
 (models/modules.py:21-29 in train mode) - per CELL inside the PointNet++, which the reference runs once per cell
-(models/object_encoder.py:92-95), over the whole batch elsewhere - so nothing is folded.  A first correct path:
+(models/object_encoder.py:92-95), over the whole batch elsewhere - so nothing is folded.  Layer by layer:
   * index-producing stages (FPS, ball query, kNN) are the inference kernels (t2p_sample_group, t2p_knn): no gradient
     flows through them in the reference either;
   * the arithmetic runs on the HIP building blocks of train_ops.py (Linear on the tiled GEMM, batch-statistics
