@@ -6,7 +6,8 @@
 // (k contiguous) so that a 16-byte load is one MFMA B-operand fragment.  A is split on the fly (hi = fp16 to nearest,
 // lo = fp16(a - hi)); hi.hi + hi.lo + lo.hi share one fp32 accumulator (the matrix cores honour fp16 denormals), the
 // epilogue divides by s.  Same error class as an fp32 fma chain (~5e-7), 16/3 x the fp32-MFMA rate.
-// 128 x 128 x 32 tile, 4 waves x (2 x 2) v_mfma_f32_32x32x16_f16 blocks, double-buffered LDS, register-prefetched loads.
+// 128 x 128 x 32 tile (64 x 64 x 32 for calls of few rows), 4 waves x (2 x 2 | 1) v_mfma_f32_32x32x16_f16 blocks, double-buffered LDS,
+// register-prefetched loads.
 #include "t2p_common.h"
 
 namespace t2p {
@@ -16,10 +17,20 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BK = 32;
 constexpr int LDT = BK + 8;               // halves per LDS row: 80 B keeps ds_read_b128 conflict-free
-constexpr int PLANE = BM * LDT;           // halves per plane of one operand tile
-constexpr size_t kLds = (size_t)2 /*buffers*/ * 2 /*A, W*/ * 2 /*hi, lo*/ * PLANE * sizeof(_Float16);
+// TS = tile side (BM = BN): 128 (4 waves x 2 x 2 MFMA blocks) or 64 (4 waves x 1 block) - the small tile for calls with so few rows
+// that 128 x 128 tiles would leave most of the chip idle (a 64-cell call has ~1,000 object rows: 8 x 2..4 tiles on 256 CUs, each
+// walking K alone: 32 us per head layer; the reference's callers use batch_size 64).  Every output element sees the same
+// products in the same order with either tile: bit-identical results.
+template <int TS>
+struct X3Cfg {
+    static constexpr int PLANE = TS * LDT;          // halves per plane of one operand tile
+    static constexpr size_t kLds = (size_t)2 /*buffers*/ * 2 /*A, W*/ * 2 /*hi, lo*/ * PLANE * sizeof(_Float16);
+    static constexpr int TPR = 256 / TS;            // threads per staged row (2 / 4)
+    static constexpr int KPT = BK / TPR;            // k per thread and tile (16 / 8)
+    static constexpr int MI = TS / 64;              // 32 x 32 blocks per wave and dimension (2 / 1)
+};
 
 template <int SEL>
 __device__ __forceinline__ float sub_half(float v, fp16x2 h) {
@@ -31,12 +42,15 @@ __device__ __forceinline__ float sub_half(float v, fp16x2 h) {
     return r;
 }
 
+template <int TS>
 __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A, int lda, const _Float16* __restrict__ Wx,
                                                     int kp /*padded K of the image*/, float inv_scale,
                                                     const float* __restrict__ bias, float* C, int ldc, int c0, int64_t M,
                                                     int K, int N, int relu, const float* R, int ldr, uint32_t* amax_in) {
+    using Cf = X3Cfg<TS>;
+    constexpr int BM = TS, BN = TS, PLANE = Cf::PLANE, KPT = Cf::KPT, MI = Cf::MI;
     extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
-    // buffer b: [A hi | A lo | W hi | W lo], each [128][LDT]
+    // buffer b: [A hi | A lo | W hi | W lo], each [TS][LDT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l31 = lane & 31;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -46,24 +60,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
 
     // staging assignment: A: thread -> row tid/2, 16 consecutive k (4 x f32x4); W: thread -> column n = tid/2,
     // 16 consecutive k of each plane (2 x 16 B per plane)
-    const int s_row = tid >> 1, s_k = (tid & 1) * 16;
+    const int s_row = tid / Cf::TPR, s_k = (tid % Cf::TPR) * KPT;
     const bool a_ok = (m0 + s_row) < M;
     const bool w_ok = (n0 + s_row) < N;
     const float* a_ptr = A + (m0 + s_row) * (int64_t)lda + s_k;
     const _Float16* wh_ptr = Whi + (size_t)(n0 + s_row) * kp + s_k;
     const _Float16* wl_ptr = Wlo + (size_t)(n0 + s_row) * kp + s_k;
-    f32x4 ra[4];
-    uint4 rwh[2], rwl[2];
+    f32x4 ra[KPT / 4];
+    uint4 rwh[KPT / 8], rwl[KPT / 8];
     float gmax = 0.f;  // fp16-range guard: largest |a| split to fp16 by this thread
 
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < KPT / 4; i++) {
             const int k = k0 + s_k + 4 * i;
             ra[i] = (a_ok && k < K) ? *(const f32x4*)(a_ptr + k0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < KPT / 8; i++) {
             rwh[i] = w_ok ? *(const uint4*)(wh_ptr + k0 + 8 * i) : uint4{0, 0, 0, 0};   // the image is zero-padded in k
             rwl[i] = w_ok ? *(const uint4*)(wl_ptr + k0 + 8 * i) : uint4{0, 0, 0, 0};
         }
@@ -71,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
     auto store_tile = [&](int buf) {
         _Float16* base = sm + (size_t)buf * 4 * PLANE;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < KPT / 4; i++) {
             const f32x4 v = ra[i];
             gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             const fp16x2 h01 = cvt_pk_f16(v[0], v[1]), h23 = cvt_pk_f16(v[2], v[3]);
@@ -84,17 +98,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
             *(uint2*)(base + PLANE + s_row * LDT + s_k + 4 * i) = pl;
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < KPT / 8; i++) {
             *(uint4*)(base + 2 * PLANE + s_row * LDT + s_k + 8 * i) = rwh[i];
             *(uint4*)(base + 3 * PLANE + s_row * LDT + s_k + 8 * i) = rwl[i];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < MI; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
@@ -108,20 +122,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
         const _Float16* base = sm + (size_t)buf * 4 * PLANE;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ks++) {
-            half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+            half8 a_hi[MI], a_lo[MI], b_hi[MI], b_lo[MI];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const _Float16* p = base + (wr * 64 + i * 32 + l31) * LDT + ks * 16 + h * 8;
+            for (int i = 0; i < MI; i++) {
+                const _Float16* p = base + (wr * (TS / 2) + i * 32 + l31) * LDT + ks * 16 + h * 8;
                 a_hi[i] = *(const half8*)p;
                 a_lo[i] = *(const half8*)(p + PLANE);
-                const _Float16* q = base + 2 * PLANE + (wc * 64 + i * 32 + l31) * LDT + ks * 16 + h * 8;
+                const _Float16* q = base + 2 * PLANE + (wc * (TS / 2) + i * 32 + l31) * LDT + ks * 16 + h * 8;
                 b_hi[i] = *(const half8*)q;
                 b_lo[i] = *(const half8*)(q + PLANE);
             }
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < MI; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
+                for (int j = 0; j < MI; j++) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
@@ -133,15 +147,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3(const float* __restrict__ A,
 
     if (blockIdx.y == 0) guard_publish(amax_in, gmax);  // every column block stages the same rows
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int col = n0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < MI; j++) {
+        const int col = n0 + wc * (TS / 2) + j * 32 + l31;
         if (col >= N) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < MI; i++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const int64_t row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int64_t row = m0 + wr * (TS / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row < M) {
                     float v = fmaf(acc[i][j][e], inv_scale, bv);
                     if (relu) v = fmaxf(v, 0.f);
@@ -161,12 +175,20 @@ int launch_gemm_x3(const float* A, int lda, const void* Wx, float scale, const f
     T2P_CHECK_ARG(K % 4 == 0 && N % 8 == 0 && lda % 4 == 0 && scale > 0.f, "gemm_x3: K=%d %% 4, N=%d %% 8, lda=%d %% 4", K, N, lda);
     T2P_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)Wx) & 15) == 0, "gemm_x3: A and W must be 16-byte aligned");
     if (M == 0) return 0;
-    T2P_TRY(reserve_lds((const void*)k_gemm_x3, kLds, "gemm_x3"));
     const int kp = (K + 31) / 32 * 32;
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     ProfScope ps_("tg_gemm_x3", st);
-    hipLaunchKernelGGL(k_gemm_x3, grid, dim3(256), kLds, st, A, lda, (const _Float16*)Wx, kp, 1.0f / scale, bias, C, ldc, c0,
-                       M, K, N, relu, resid, ldr, amax_in);
+    const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles128 * 2 <= num_cus()) {                      // too few big tiles to fill the chip: 64 x 64 tiles (same bits out)
+        T2P_TRY(reserve_lds((const void*)k_gemm_x3<64>, X3Cfg<64>::kLds, "gemm_x3"));
+        dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
+        hipLaunchKernelGGL(k_gemm_x3<64>, grid, dim3(256), X3Cfg<64>::kLds, st, A, lda, (const _Float16*)Wx, kp, 1.0f / scale, bias, C, ldc,
+                           c0, M, K, N, relu, resid, ldr, amax_in);
+    } else {
+        T2P_TRY(reserve_lds((const void*)k_gemm_x3<128>, X3Cfg<128>::kLds, "gemm_x3"));
+        dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
+        hipLaunchKernelGGL(k_gemm_x3<128>, grid, dim3(256), X3Cfg<128>::kLds, st, A, lda, (const _Float16*)Wx, kp, 1.0f / scale, bias, C, ldc,
+                           c0, M, K, N, relu, resid, ldr, amax_in);
+    }
     T2P_CHECK_LAUNCH("gemm_x3");
     return 0;
 }
