@@ -3,20 +3,26 @@
 //   mlp_pointnet, color/pos MLPs, mlp_merge   models/object_encoder.py:98,124-138
 //   DynamicEdgeConv layer-1 tables (P, Q) and the cell `lin` MLP   models/cell_retrieval.py:46-49,97-99
 //   LSTM input projection of the vocabulary (gate table)            models/modules.py:77,89
-// C[M,N] = act(A[M,K] W[K,N] + bias).  128x128x16 tile, 4 waves x (2x2) v_mfma_f32_32x32x2_f32 tiles,
+// C[M,N] = act(A[M,K] W[K,N] + bias).  128x128x16 tile (64x64x16 for products of few rows), 4 waves x (2x2 | 1) v_mfma_f32_32x32x2_f32 tiles,
 // register-prefetched global loads (issue next chunk before the MFMAs of the current one).
 #include "t2p_common.h"
 
 namespace t2p {
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDA_S = BM + 2;  // As[k][m], +2 keeps the transposing ds_write_b32 conflict-free
-constexpr int LDB_S = BN + 4;  // Ws[k][n]
-
+constexpr int BK = 16;
+// TS = tile side (BM = BN): 128, or 64 for products of so few rows that the big tiles would leave most of the chip idle (head
+// layers of a 64-cell call, the training path's per-object layers); every output element sees the same fma chain either way.
+template <int TS>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                               const float* __restrict__ bias, float* C, int ldc, int c0,
                                               int64_t M, int K, int N, int relu, const float* R, int ldr) {
+    constexpr int BM = TS, BN = TS, MI = TS / 64;
+    constexpr int LDA_S = BM + 2;  // As[k][m], +2 keeps the transposing ds_write_b32 conflict-free
+    constexpr int LDB_S = BN + 4;  // Ws[k][n]
+    constexpr int TPR = 256 / TS;  // threads per staged row of A (2 / 4): KA = 16 / TPR consecutive k each
+    constexpr int KA = BK / TPR;   // 8 / 4
+    constexpr int NW = TS / 16;    // consecutive n per thread of one k row of W (8 / 4)
     __shared__ float As[BK * LDA_S];
     __shared__ __attribute__((aligned(16))) float Ws[BK * LDB_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -25,35 +31,38 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     const int n0 = blockIdx.y * BN;
 
     // global -> register staging assignments
-    const int a_row = tid >> 1, a_k = (tid & 1) * 8;  // 8 consecutive k of one row
-    const int w_k = tid >> 4, w_n = (tid & 15) * 8;   // 8 consecutive n of one k
+    const int a_row = tid / TPR, a_k = (tid % TPR) * KA;  // KA consecutive k of one row
+    const int w_k = tid >> 4, w_n = (tid & 15) * NW;      // NW consecutive n of one k
     const bool a_row_ok = (m0 + a_row) < M;
     const float* a_ptr = A + (m0 + a_row) * (int64_t)lda + a_k;
-    f32x4 ra[2], rw[2];
+    f32x4 ra[KA / 4], rw[NW / 4];
 
     auto load_chunk = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < KA / 4; i++) {
             const int k = k0 + a_k + 4 * i;
             ra[i] = (a_row_ok && k < K) ? *(const f32x4*)(a_ptr + k0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NW / 4; i++) {
             const int kk = k0 + w_k, n = n0 + w_n + 4 * i;
             rw[i] = (kk < K && n < N) ? *(const f32x4*)(W + (int64_t)kk * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < KA / 4; i++)
 #pragma unroll
             for (int e = 0; e < 4; e++) As[(a_k + 4 * i + e) * LDA_S + a_row] = ra[i][e];
-            *(f32x4*)(Ws + w_k * LDB_S + w_n + 4 * i) = rw[i];
-        }
+#pragma unroll
+        for (int i = 0; i < NW / 4; i++) *(f32x4*)(Ws + w_k * LDB_S + w_n + 4 * i) = rw[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < MI; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
@@ -64,30 +73,30 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
         if (k0 + BK < K) load_chunk(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[2], b[2];
+            float a[MI], b[MI];
 #pragma unroll
-            for (int i = 0; i < 2; i++) a[i] = As[(kk + h) * LDA_S + wr * 64 + i * 32 + l31];
+            for (int i = 0; i < MI; i++) a[i] = As[(kk + h) * LDA_S + wr * (TS / 2) + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < 2; j++) b[j] = Ws[(kk + h) * LDB_S + wc * 64 + j * 32 + l31];
+            for (int j = 0; j < MI; j++) b[j] = Ws[(kk + h) * LDB_S + wc * (TS / 2) + j * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < MI; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int j = 0; j < MI; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int col = n0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < MI; j++) {
+        const int col = n0 + wc * (TS / 2) + j * 32 + l31;
         if (col >= N) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < MI; i++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const int64_t row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int64_t row = m0 + wr * (TS / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row < M) {
                     float v = acc[i][j][e] + bv;
                     if (relu) v = fmaxf(v, 0.f);
@@ -179,9 +188,15 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
                   K, N, lda);
     T2P_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm: A and W must be 16-byte aligned");
     if (M == 0) return 0;
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     ProfScope ps_("tg_gemm", st);
-    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, c0, M, K, N, relu, resid, ldr);
+    const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles128 * 2 <= num_cus()) {                      // too few big tiles to fill the chip: 64 x 64 tiles (same bits out)
+        dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
+        hipLaunchKernelGGL(k_gemm<64>, grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, c0, M, K, N, relu, resid, ldr);
+    } else {
+        dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
+        hipLaunchKernelGGL(k_gemm<128>, grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, c0, M, K, N, relu, resid, ldr);
+    }
     T2P_CHECK_LAUNCH("gemm");
     return 0;
 }
