@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 25
+#define T2P_ABI_VERSION 26
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
@@ -231,6 +231,27 @@ int t2p_encode_cells(const float* xyz, const float* rgb, const float* center, co
 int t2p_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
                      const float* rot_cos_sin, int64_t n_obj, int32_t n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
                      t2p_stream_t stream);
+
+/* The dataloader of a scene that is RESIDENT in HBM - what evaluation/pipeline.py:282-342 builds per batch on the host
+ * (Kitti360CoarseDatasetMulti / Kitti360TopKDataset -> batch_object_points, dataloading/kitti360pose/utils.py:89-110,
+ * dataloading/kitti360pose/eval.py:117-189) for every cell of the database and again for every (query, candidate cell)
+ * pair of the fine stage.  The raw points of all objects of the scene are uploaded once (raw_xyz, raw_rgb [n_points][3]
+ * fp32, obj_ptr [n_scene_obj + 1] int32 CSR) together with the per-object means scene_center / scene_color
+ * [n_scene_obj][3] fp32 (Object3d.get_center() / get_color_rgb(): the reference's float64 NumPy means, cast); a call then
+ * packs any list of them: output slot s takes scene object obj_id[s] (int32 [n_out]; the same object may fill many slots:
+ * a cell retrieved for several queries, the padding object of dataloading/kitti360pose/eval.py:147-149).
+ * T.FixedPoints(n_pts) is counter-based: point p of slot s is raw point
+ *       ((mix64(key[s] ^ p * 0xD6E8FEB86659FD93) >> 32) * m) >> 32      of the object's m points, with
+ *       mix64(x): x += 0x9E3779B97F4A7C15; x = (x ^ x >> 30) * 0xBF58476D1CE4E5B9; x = (x ^ x >> 27) * 0x94D049BB133111EB;
+ *                 x ^ x >> 31   (64-bit wrap-around),
+ * key [n_out] uint64 chosen by the host (pipeline.PerCellTransform: a hash of (seed, global cell index, slot in the cell),
+ * so a cell's sample does not depend on the rank, batch or stream that packs it).  T.NormalizeScale follows, bit for bit
+ * as ATen computes it on the host (csrc/small_kernels.hip).  n_pts <= 1024.
+ * Outputs: xyz, rgb [n_out][n_pts][3], center, mean_rgb [n_out][3] = the inputs of t2p_encode_cells; rgb, center, mean_rgb
+ * and sample_idx_out (int32 [n_out][n_pts]: the draws, for checking) may each be NULL (not written). */
+int t2p_pack_scene_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* obj_id,
+                           const uint64_t* key, const float* scene_center, const float* scene_color, int64_t n_out, int32_t n_pts,
+                           float* xyz, float* rgb, float* center, float* mean_rgb, int32_t* sample_idx_out, t2p_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fine stage: hint <-> object matching + offset regression.

@@ -643,30 +643,42 @@ def test_pipeline_config4_scale_vs_oracle(tmp_path, oracle_model, vocab):
     assert len(sc.all_cells) == n_cells and len(sc.all_poses) == n_poses
     tf = PL.PerCellTransform(256, 5)
 
-    # ---- the product pipeline, with a spy on the fine model's first call
+    # ---- the product pipeline (input side on the GPU: scene.DeviceScene), with a spy on the fine model's first call
     seen = {}
+    n_spy = 64 * kmax
 
     class Spy(torch.nn.Module):
+        """Stands in for SuperGlueMatch on the packed entry point the on-device pipeline calls; keeps what the first call was
+        fed (its first 64 queries x kmax candidates) and everything it returned."""
         device = _dev()
+        args, object_encoder, encode_hints = prod_fine.args, prod_fine.object_encoder, prod_fine.encode_hints
 
-        def forward(self, objects, hints, points):
-            out = prod_fine(objects, hints, points)
+        def forward_packed(self, xyz, rgb, center, mean_rgb, cell_ptr, hints, class_idx=None, color_idx=None):
+            out = prod_fine.forward_packed(xyz, rgb, center, mean_rgb, cell_ptr, hints, class_idx, color_idx)
             if "in" not in seen:
-                seen["in"] = (objects, hints, points)
-                seen["out"] = {k: out[k].cpu().numpy() for k in ("matches0", "offsets", "P")}
+                seen["in"] = [t[: n_spy * pad].cpu().numpy() for t in (xyz, rgb, center, mean_rgb)] + [np.asarray(cell_ptr)[: n_spy + 1]]
+                seen["out"] = {k: out[k][:n_spy].cpu().numpy() for k in ("matches0", "offsets", "P")}
             seen.setdefault("m0", []).append(out.matches0.cpu().numpy())
             seen.setdefault("off", []).append(out.offsets.cpu().numpy())
             return out
     np.random.seed(2022)
     torch.cuda.synchronize()
+    timings = {}
     t0 = time.perf_counter()
-    out = PL.evaluate(hip, Spy(), sc, tf, top_k, threshs, pad, queries_per_call=64)
+    out = PL.evaluate(hip, Spy(), sc, tf, top_k, threshs, pad, queries_per_call=64, timings=timings)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     t0 = time.perf_counter()
-    out2 = PL.run_coarse(hip, sc, tf, top_k, threshs)        # second pass: the per-cell object means come from the cache
+    out2 = PL.run_coarse(hip, sc, tf, top_k, threshs)        # the coarse stage alone (uploads the scene again)
     wall_coarse2 = time.perf_counter() - t0
     assert out2[0] == out["retrievals"]
+    np.random.seed(2022)
+    t0 = time.perf_counter()
+    out3 = PL.evaluate(hip, Spy(), sc, tf, top_k, threshs, pad, queries_per_call=64)
+    torch.cuda.synchronize()
+    wall_again = time.perf_counter() - t0
+    assert out3["retrievals"] == out["retrievals"] and out3["fine_offset"] == out["fine_offset"]
+    assert "in" in seen, "the pipeline did not take the on-device input path"
 
     # ---- oracle coarse stage on the same draws
     oc = _OracleCoarse(om)
@@ -678,6 +690,10 @@ def test_pipeline_config4_scale_vs_oracle(tmp_path, oracle_model, vocab):
         with torch.no_grad():
             hip_enc.append(hip.encode_objects(objs, pts).cpu())
     cell_enc, text_enc = torch.cat(enc).numpy(), oc.encode_text(sc.texts).numpy()
+    # the on-device input path produced the very embeddings of the host chain (same draws, same packed bits)
+    from text2pos_amd.scene import DeviceScene
+    with torch.no_grad():
+        assert torch.equal(hip.encode_scene_cells(DeviceScene(sc.all_cells, _dev()), tf).cpu(), torch.cat(hip_enc))
     per_cell = np.abs(torch.cat(hip_enc).numpy() - cell_enc).max(axis=1)
     flipped = per_cell >= TOL
     assert flipped.sum() <= n_cells // 200, f"{int(flipped.sum())} of {n_cells} cells differ from the oracle by >= 1e-4"
@@ -696,10 +712,20 @@ def test_pipeline_config4_scale_vs_oracle(tmp_path, oracle_model, vocab):
     assert out["hit"] == w_hit and out["close"] == w_close
     assert out["localisation"] == E.localisation_accuracies(sc.all_poses, out["retrievals"], sc.cells_dict, list(top_k), list(threshs))
 
-    # ---- fine stage: the first call's inputs through the oracle
-    objects, hints, points = seen["in"]
-    assert len(objects) == 64 * kmax
-    want = _OracleFine(orc_fine)(objects, hints, points)
+    # ---- fine stage: what the first call packed on the GPU for its first 64 queries, through the oracle
+    from text2pos_amd.superglue_matcher import MatchOutputs
+    fx, fr, fc, fm, fcp = seen["in"]
+    assert fx.shape == (n_spy * pad, 256, 3) and fcp[-1] == n_spy * pad
+    hints = [E.create_hint_description(sc.all_poses[b // kmax]) for b in range(n_spy)]
+    want = MatchOutputs(**orc_fine.forward_packed(fx, fr, fc, fm, fcp, hints))
+    # ... and those packed samples are the host chain's: sample q * kmax + c = cell retrievals[q][c], cut / padded to 16
+    for b in (0, 7, n_spy - 1):
+        cell = sc.cells_dict[out["retrievals"][b // kmax][b % kmax]]
+        objs = list(cell.objects)[:pad]
+        hp = D.batch_object_points(objs, tf.for_cell(b))
+        assert np.array_equal(fx[b * pad: b * pad + len(objs)].reshape(-1, 3), hp.pos.numpy())
+        assert np.array_equal(fr[b * pad: b * pad + len(objs)].reshape(-1, 3), hp.x.numpy())
+        assert np.array_equal(fc[b * pad: b * pad + len(objs)], np.stack([o.get_center() for o in objs]).astype(np.float32))
     wP, woff, wm0 = want.P.numpy(), want.offsets.numpy(), want.matches0.numpy()
     assert np.abs(seen["out"]["P"] - wP).max() < TOL and np.abs(seen["out"]["offsets"] - woff).max() < TOL
     m0 = seen["out"]["matches0"]
@@ -713,15 +739,23 @@ def test_pipeline_config4_scale_vs_oracle(tmp_path, oracle_model, vocab):
         margin = min(top2[1] - top2[0], col[1] - col[0], abs(top2[1] - 0.2))
         assert margin < 1e-3, f"sample {b}, object {o}: matches differ although the oracle's margin is {margin:.2e}"
     assert (m0 >= 0).any() and (m0 < 0).any()
-    # the fine tables from the per-sample outputs the spy saw, through localisation_accuracies
-    from text2pos_amd.superglue_matcher import get_pos_in_cell
-    m_all, off_all = np.concatenate(seen["m0"]), np.concatenate(seen["off"])
-    assert m_all.shape[0] == n_poses * kmax
-    print(f"[configs[4] at 2,048 cells / 1,024 poses] pipeline.evaluate (coarse + fine + metrics) {wall:.1f} s wall "
-          f"(host transforms included); coarse pass again with cached object means {wall_coarse2:.1f} s; "
+    # the fine tables are the metric functions applied to the per-sample outputs the spy saw (first evaluate call)
+    k_all, o_all = np.concatenate(seen["m0"])[: n_poses * kmax], np.concatenate(seen["off"])[: n_poses * kmax]
+    assert k_all.shape[0] == n_poses * kmax
+    np.random.seed(2022)
+    twin = DeviceScene(sc.all_cells, "cpu", n_pad=pad)          # (host side only: same padding objects as evaluate's scene)
+    rows = np.array([[twin.row_of[c] for c in r] for r in out["retrievals"]]).reshape(-1)
+    cxy = twin.center64[twin.padded_object_ids(pad)[rows]][:, :, 0:2]
+    for name, offs in (("fine_offset", o_all), ("fine_mean", np.zeros_like(o_all))):
+        pos = E.positions_in_cell(cxy, k_all, offs).reshape(n_poses, kmax, 2)
+        assert out[name] == E.localisation_accuracies(sc.all_poses, out["retrievals"], sc.cells_dict, list(top_k), list(threshs), pos)
+    print(f"[configs[4] at 2,048 cells / 1,024 poses] pipeline.evaluate (upload + coarse + fine + metrics) {wall:.2f} s wall "
+          f"first pass (scene upload {timings['scene_s']:.2f}, coarse {timings['coarse_s']:.2f}, fine {timings['fine_s']:.2f}), "
+          f"{wall_again:.2f} s again; run_coarse alone (with its own upload) {wall_coarse2:.2f} s; "
           f"{int(clear.sum())} / {n_poses} queries with clear oracle rankings: identical lists; "
           f"{int(flipped.sum())} / {n_cells} cells with a kNN near-tie flip; fine stage: {len(diff)} / {m0.size} match entries "
           f"at a sub-1e-3 margin differ; hit@k {out['hit']}")
+    assert wall_again < 3.0, "the end-to-end pipeline should be GPU-bound (about half a second), not host-bound"
 
 
 def test_bench_exchange_runs_through_rccl_at_world_size_one():

@@ -388,6 +388,89 @@ def test_embed_dim_300_vs_oracle(vocab, d, precision):
     assert out_t.shape == (9, d) and out_t.requires_grad
 
 
+def _raw_scene(n_cells, seed, scene="s"):
+    from text2pos_amd import data as D, synthetic as S
+    rng = np.random.default_rng(seed)
+    cells = []
+    for i in range(n_cells):
+        objs = []
+        for j in range(int(rng.integers(1, 24))):
+            m = int(rng.integers(2, 3000)) if j else int(rng.integers(2, 5))     # tiny objects included (a single point would
+            # normalise to 0 * inf = NaN, on the host as on the GPU, and trip the encoder's NaN guard)
+            col = rng.random(3)
+            objs.append(D.Object3d(j, 100 * i + j, rng.standard_normal((m, 3)) * np.array([4.0, 1.5, 0.4]) + rng.random(3) * 30.0,
+                                   np.clip(col + 0.05 * rng.standard_normal((m, 3)), 0, 1), S.LABELS[int(rng.integers(0, len(S.LABELS)))]))
+        cells.append(D.Cell(i, scene, objs, 30.0, np.array([0.0, 0.0, 0.0, 30.0, 30.0, 10.0])))
+    return cells
+
+
+def test_pack_scene_objects_is_the_host_chain_bit_for_bit():
+    """t2p_pack_scene_objects (the dataloader of a scene resident in HBM) against the chain it replaces -
+    dataloading/kitti360pose/utils.py:89-110 (Data -> FixedPoints -> NormalizeScale -> Batch) + the per-object float64 means of
+    models/object_encoder.py:121-131 - on raw float64 objects of 1 ... 3,000 points: identical draws, and xyz, rgb, centre and
+    mean colour EQUAL bit for bit (the kernel sums NormalizeScale's mean in ATen's CPU order; the means come from the host's
+    exact pass).  Also: a sample depends on its (cell, slot) key only - any sub-range, order or repetition packs the same."""
+    from text2pos_amd import data as D, pipeline as PL
+    from text2pos_amd.scene import DeviceScene
+    cells = _raw_scene(48, 31)
+    tf = PL.PerCellTransform(256, 7)
+    sc = DeviceScene(cells, _dev(), n_pad=4)
+    (xyz, rgb, center, mean_rgb, idx), cp, ids = sc.pack_cells(tf, 0, 48, want_idx=True)
+    objs = [c.objects for c in cells]
+    hx, hr, hc, hm, hcp = D.pack_cells(objs, [D.batch_object_points(o, tf.for_cell(i)) for i, o in enumerate(objs)], 256)
+    assert np.array_equal(cp, hcp)
+    flat = [o for c in cells for o in c.objects]
+    sizes = np.array([len(o.xyz) for o in flat])
+    slot = np.concatenate([np.arange(len(o)) for o in objs])
+    cell_of = np.repeat(np.arange(48), [len(o) for o in objs])
+    assert np.array_equal(idx.cpu().numpy(), D.keyed_draws(tf.keys(cell_of, slot), sizes, 256))
+    assert torch.equal(xyz.cpu(), hx) and torch.equal(rgb.cpu(), hr)
+    assert torch.equal(center.cpu(), hc) and torch.equal(mean_rgb.cpu(), hm)
+    # sub-range with a global offset, reversed order, repeated slots
+    (x2, r2, c2, m2), cp2, _ = sc.pack_cells(PL.PerCellTransform(256, 7), 10, 20)
+    o0, o1 = int(sc.cell_ptr[10]), int(sc.cell_ptr[20])
+    assert torch.equal(x2, xyz[o0:o1]) and torch.equal(r2, rgb[o0:o1]) and torch.equal(c2, center[o0:o1])
+    block = DeviceScene(cells[10:20], _dev())
+    (x3, r3, c3, m3), _, _ = block.pack_cells(tf, 0, 10, cell_offset=10)
+    assert torch.equal(x3, x2) and torch.equal(r3, r2) and torch.equal(m3, m2)
+    pick = np.array([o1 - 1, o0, o0, o0 + 3])
+    keys = tf.keys(cell_of[pick], slot[pick])
+    x4, r4, c4, m4 = sc.pack(pick, keys, 256)
+    assert torch.equal(x4, xyz[pick]) and torch.equal(r4, rgb[pick]) and torch.equal(c4, center[pick])
+    x5, r5, _, _ = sc.pack(pick, keys, 256, want_rgb=False)
+    assert r5 is None and torch.equal(x5, x4)
+    # the padding objects (8 points within a millimetre of the origin, black)
+    xp, rp, cpad, _ = sc.pack(sc.pad_ids, tf.keys(0, np.arange(4)), 256)
+    assert float(rp.abs().max()) == 0.0 and float(cpad.abs().max()) < 1e-3 and abs(float(xp.abs().max()) - 0.999999) < 1e-6
+
+
+def test_scene_path_encodes_like_the_host_path(hip_model):
+    """CellRetrievalNetwork.encode_scene_cells (raw scene in HBM -> pack kernel -> encoder) == encode_objects on the host
+    chain's batches of the same PerCellTransform: torch.equal, also when the scene is cut into blocks of other sizes, and for
+    a model without the colour feature (rgb never packed)."""
+    import text2pos_amd as t2p
+    from text2pos_amd import data as D, pipeline as PL, synthetic as S
+    from text2pos_amd.scene import DeviceScene
+    cells = _raw_scene(40, 5)
+    tf = PL.PerCellTransform(256, 3)
+    objs = [c.objects for c in cells]
+    pts = [D.batch_object_points(o, tf.for_cell(i)) for i, o in enumerate(objs)]
+    sc = DeviceScene(cells, _dev())
+    with torch.no_grad():
+        want = hip_model.encode_objects(objs, pts)
+        got, (xyz, rgb, center, mean_rgb, cp) = hip_model.encode_scene_cells(sc, tf, want_inputs=True)
+        assert torch.equal(got, want)
+        assert torch.equal(hip_model.encode_scene_cells(sc, tf, cells_per_call=7), want)
+        assert torch.equal(hip_model.encode_scene_cells(sc, tf, 12, 30), want[12:30])
+        assert torch.equal(hip_model.encode_objects_packed(xyz, rgb, center, mean_rgb, cp), want)
+        assert hip_model.encode_scene_cells(sc, tf, 5, 5).shape == (0, 256)
+    m = t2p.CellRetrievalNetwork(S.LABELS + ["pad"], S.COLOR_NAMES, S.known_words(), S.default_args(use_features=["class", "position"]))
+    m.load_state_dict({k: v for k, v in hip_model.state_dict().items() if k in m.state_dict()}, strict=False)
+    m = m.to(_dev()).eval()
+    with torch.no_grad():
+        assert torch.equal(m.encode_scene_cells(sc, tf), m.encode_objects(objs, pts))
+
+
 def test_pack_objects_matches_host_transform_chain(hip_model, oracle_model):
     """On-device FixedPoints gather + NormalizeScale + means == the host chain of dataloading/kitti360pose/utils.py:99-109
     (restated in oracle/pyg_restated.py) given the same draw; and the raw-object entry point encodes like the packed one."""
@@ -408,7 +491,7 @@ def test_pack_objects_matches_host_transform_chain(hip_model, oracle_model):
         d = P.Data(x=torch.tensor(o.rgb, dtype=torch.float)[sample_idx[i].astype(np.int64)],
                    pos=torch.tensor(o.xyz, dtype=torch.float)[sample_idx[i].astype(np.int64)])
         d = P.NormalizeScale()(d)
-        assert np.abs(got[0][i] - d.pos.numpy()).max() < 2e-6
+        assert np.array_equal(got[0][i], d.pos.numpy())      # bit for bit: the kernel sums the mean in ATen's CPU order
         assert np.array_equal(got[1][i], d.x.numpy())
         assert np.abs(got[2][i] - o.get_center()).max() < 1e-6 and np.abs(got[3][i] - o.get_color_rgb()).max() < 1e-6
     # training transform: FixedPoints -> RandomRotate(120, axis=2) -> NormalizeScale (training/coarse.py:192-198)

@@ -558,3 +558,183 @@ def test_draw_rotations_and_oracle_rotate_z():
     assert (out[:, :2].norm(dim=1) - pos[:, :2].norm(dim=1)).abs().max() < 1e-5
     q = P.RotateZ(0.0, 1.0)(P.Data(pos=torch.tensor([[1.0, 0.0, 0.0]]))).pos   # +90 degrees: x axis -> (0, 1, 0)
     assert torch.allclose(q, torch.tensor([[0.0, 1.0, 0.0]]))
+
+
+# ---- on-device input path: host statements (the GPU side is tests/test_gpu_parity.py::test_pack_scene_*) -----------------
+def _aten_mean_order(x: np.ndarray) -> np.ndarray:
+    """Column sums of an fp32 [P, 3] array in the order csrc/small_kernels.hip::aten_column_sums uses (its comment cites
+    ATen's SumKernel.cpp): four interleaved partial sums per column, each folding into a second level every 16 items, the
+    P % 4 tail rows on partial sum 0, then ((p0 + p1) + p2) + p3."""
+    f = np.float32
+    n = x.shape[0]
+    size_ilp = n // 4
+    out = np.zeros(3, f)
+    for c in range(3):
+        part = []
+        for k in range(4):
+            acc = [f(0)] * 4
+            i = 0
+            while i + 16 <= size_ilp:
+                for _ in range(16):
+                    acc[0] = f(acc[0] + x[4 * i + k, c])
+                    i += 1
+                for j in range(1, 4):
+                    acc[j] = f(acc[j] + acc[j - 1])
+                    acc[j - 1] = f(0)
+                    if i & (0xF << (4 * j)):
+                        break
+            while i < size_ilp:
+                acc[0] = f(acc[0] + x[4 * i + k, c])
+                i += 1
+            for j in range(1, 4):
+                acc[0] = f(acc[0] + acc[j])
+            if k == 0:
+                for r in range(size_ilp * 4, n):
+                    acc[0] = f(acc[0] + x[r, c])
+            part.append(acc[0])
+        out[c] = f(f(f(part[0] + part[1]) + part[2]) + part[3])
+    return out
+
+
+@pytest.mark.parametrize("n_pts", [256, 64, 100, 1024, 1023])
+def test_pack_kernel_summation_order_is_this_torch_builds_cpu_mean(n_pts):
+    """The pack kernels reproduce T.NormalizeScale bit for bit by summing `pos.mean(dim=-2)` in ATen's CPU order.  That order
+    is a property of the torch build: this test pins it where it can run (CPU), so that a torch upgrade that changes it fails
+    HERE with a clear message instead of in the GPU bit-equality tests."""
+    rng = np.random.default_rng(n_pts)
+    for scale in (1.0, 30.0, 1e-3):
+        x = (rng.standard_normal((n_pts, 3)) * scale + rng.random(3) * scale).astype(np.float32)
+        want = torch.from_numpy(x).mean(dim=-2).numpy()
+        got = _aten_mean_order(x) / np.float32(n_pts)
+        assert np.array_equal(got, want), "torch's CPU sum order changed: update aten_column_sums in csrc/small_kernels.hip"
+
+
+def test_counter_based_fixed_points_draw():
+    """pipeline.PerCellTransform: for_cell(i)'s host chain draws exactly data.keyed_draws(keys(i, slot), m) - the statement
+    the pack kernel executes - and the draw of a cell depends on (seed, cell, slot) only."""
+    from text2pos_amd import pipeline as PL
+    rng = np.random.default_rng(3)
+    tf = PL.PerCellTransform(256, 5)
+    objs = [D.Object3d(i, i, rng.random((m, 3)) * 7, rng.random((m, 3)), "box") for i, m in enumerate((1, 25, 300, 4000, 77))]
+    sizes = np.array([len(o.xyz) for o in objs])
+    idx = D.keyed_draws(tf.keys(41, np.arange(5)), sizes, 256)
+    assert idx.shape == (5, 256) and (idx >= 0).all() and (idx < sizes[:, None]).all() and (idx[0] == 0).all()
+    b = D.batch_object_points(objs, tf.for_cell(41))
+    for i, o in enumerate(objs):
+        want = D.NormalizeScale()(D.Data(x=torch.tensor(o.rgb, dtype=torch.float)[idx[i]], pos=torch.tensor(o.xyz, dtype=torch.float)[idx[i]]))
+        assert torch.equal(b.pos[i * 256:(i + 1) * 256], want.pos) and torch.equal(b.x[i * 256:(i + 1) * 256], want.x)
+    again = D.batch_object_points(objs, tf.for_cell(41))
+    assert torch.equal(again.pos, b.pos)
+    assert not torch.equal(D.batch_object_points(objs, tf.for_cell(42)).pos, b.pos)
+    assert not torch.equal(D.batch_object_points(objs, PL.PerCellTransform(256, 6).for_cell(41)).pos, b.pos)
+    # uniformity of the multiply-shift map: every point of a 1000-point object is drawn about 256 * n / 1000 times
+    hits = np.bincount(D.keyed_draws(tf.keys(np.arange(4000), 0), np.full(4000, 1000), 256).ravel(), minlength=1000)
+    assert abs(hits.mean() - 1024.0) < 1e-9 and hits.std() < 1.25 * np.sqrt(1024.0)
+
+
+def test_object_sums_helper_one_walk_and_float32_image():
+    """_t2p_host.object_sums: .xyz and .rgb of a whole scene in one walk, the float32 upload image beside the sums, on the
+    persistent thread pool (used repeatedly, with changing thread counts)."""
+    ext = D.host_ext()
+    assert ext is not None
+    rng = np.random.default_rng(21)
+    cells = [[D.Object3d(j, j, rng.standard_normal((m, 3)) * 20, rng.random((m, 3)), "box")
+              for j, m in enumerate(rng.integers(1, 3000, size=int(rng.integers(1, 20))))] for _ in range(300)]
+    flat = [o for c in cells for o in c]
+    n = len(flat)
+    rows = np.empty(n, dtype=np.int64)
+    assert ext.point_rows(cells, rows) == n and np.array_equal(rows, [len(o.xyz) for o in flat])
+    total = int(rows.sum())
+    for threads in (1, 3, 8, 32, 2):
+        sums, asums, rows2 = np.empty((2, n, 3)), np.empty((2, n, 3)), np.empty((2, n), dtype=np.int64)
+        xyz, rgb = np.zeros((total, 3), np.float32), np.zeros((total, 3), np.float32)
+        assert ext.object_sums(cells, sums, asums, rows2, threads, xyz, rgb) == n
+        assert np.array_equal(rows2[0], rows) and np.array_equal(rows2[1], rows)
+        assert np.array_equal(xyz, np.concatenate([o.xyz for o in flat]).astype(np.float32))
+        assert np.array_equal(rgb, np.concatenate([o.rgb for o in flat]).astype(np.float32))
+        want = np.stack([o.xyz.sum(0) for o in flat])
+        assert np.allclose(sums[0], want, rtol=0, atol=1e-9 * np.abs(want).max())
+        assert np.allclose(asums[1], np.stack([np.abs(o.rgb).sum(0) for o in flat]), rtol=1e-12)
+    flat[5].rgb = flat[5].rgb[:-1] if len(flat[5].rgb) > 1 else np.zeros((2, 3))      # colours and points no longer pair up
+    sums, asums, rows2 = np.empty((2, n, 3)), np.empty((2, n, 3)), np.empty((2, n), dtype=np.int64)
+    assert ext.object_sums(cells, sums, asums, rows2, 4, np.zeros((total + 8, 3), np.float32), np.zeros((total + 8, 3), np.float32)) == -6
+    assert ext.object_sums(cells, sums, asums, rows2, 4) == n          # without the image the two may differ
+    with pytest.raises(ValueError):
+        ext.object_sums(cells, sums, asums, rows2, 4, np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32))
+
+
+def test_device_scene_host_side():
+    """scene.DeviceScene on the CPU device (no kernels): the upload image, the exact per-object means, the padded object ids
+    of the fine stage and the sampling keys of pack_cells agree with the host chain's statements."""
+    from text2pos_amd import pipeline as PL
+    from text2pos_amd.scene import DeviceScene
+    rng = np.random.default_rng(8)
+    cells = []
+    for i in range(40):
+        objs = [D.Object3d(j, j, rng.standard_normal((m, 3)) * 3 + rng.random(3) * 30, rng.random((m, 3)), "box")
+                for j, m in enumerate(rng.integers(25, 600, size=int(rng.integers(1, 22))))]
+        cells.append(D.Cell(i, "s", objs, 30.0, np.arange(6.0)))
+    np.random.seed(3)
+    sc = DeviceScene(cells, "cpu", n_pad=16)
+    flat = [o for c in cells for o in c.objects]
+    assert sc.n_cells == 40 and sc.n_objects == len(flat) + 16 and sc.cell_ids[3] == cells[3].id and sc.row_of[cells[3].id] == 3
+    assert np.array_equal(sc.raw_xyz.numpy()[: sc.obj_ptr[len(flat)]], np.concatenate([o.xyz for o in flat]).astype(np.float32))
+    want_c = torch.tensor(np.stack([o.get_center() for o in flat]), dtype=torch.float).numpy()
+    want_k = torch.tensor(np.stack([o.get_color_rgb() for o in flat]), dtype=torch.float).numpy()
+    assert np.array_equal(sc.center.numpy()[: len(flat)], want_c) and np.array_equal(sc.color.numpy()[: len(flat)], want_k)
+    assert np.abs(sc.center64[: len(flat)] - np.stack([o.get_center() for o in flat])).max() < 1e-12
+    assert (sc.rows[len(flat):] == 8).all() and float(sc.raw_xyz[-8 * 16:].abs().max()) <= 0.001       # padding objects
+    ids = sc.padded_object_ids(16)
+    for i in (0, 7, 39):
+        n = len(cells[i].objects)
+        lo = int(sc.cell_ptr[i])
+        assert ids[i, : min(n, 16)].tolist() == list(range(lo, lo + min(n, 16)))
+        assert ids[i, min(n, 16):].tolist() == sc.pad_ids[min(n, 16): 16].tolist()
+    with pytest.raises(RuntimeError, match="n_pad"):
+        sc.padded_object_ids(17)
+    # keys of pack_cells = the keys the host chain of that (global) cell uses, slot by slot
+    tf = PL.PerCellTransform(256, 9)
+    seen = {}
+    sc.pack = lambda obj_ids, keys, n_pts, **kw: seen.update(ids=obj_ids, keys=keys) or (None, None, None, None)
+    _, cp, _ = sc.pack_cells(tf, 5, 9, cell_offset=100)
+    want = np.concatenate([tf.keys(100 + c, np.arange(len(cells[c].objects))) for c in range(5, 9)])
+    assert np.array_equal(seen["keys"], want) and cp[0] == 0 and cp[-1] == len(want)
+    assert seen["ids"].tolist() == list(range(int(sc.cell_ptr[5]), int(sc.cell_ptr[9])))
+
+
+def test_positions_in_cell_is_get_pos_in_cell_for_a_batch():
+    from text2pos_amd import evaluation as E
+    from text2pos_amd.superglue_matcher import get_pos_in_cell
+    rng = np.random.default_rng(1)
+    objs = [[D.Object3d(j, j, rng.random((30, 3)), rng.random((30, 3)), "box") for j in range(16)] for _ in range(12)]
+    m0 = rng.integers(-1, 6, size=(12, 16))
+    m0[3] = -1
+    off = rng.standard_normal((12, 6, 2)).astype(np.float32)
+    cxy = np.array([[o.get_center()[0:2] for o in row] for row in objs])
+    got = E.positions_in_cell(cxy, m0, off)
+    for b in range(12):
+        assert np.abs(got[b] - get_pos_in_cell(objs[b], m0[b], off[b])).max() < 1e-12
+    assert got[3].tolist() == [0.5, 0.5]
+
+
+def test_every_cells_batch_vector_is_checked():
+    """data.pack_cells verifies EVERY cell's batch vector (a sampled check let a permuted vector in any other
+    cell through)."""
+    rng = np.random.default_rng(0)
+    objects, points = [], []
+    for c in range(40):
+        objs = [D.Object3d(i, i, rng.random((30, 3)), rng.random((30, 3)), "box") for i in range(3 + c % 4)]
+        objects.append(objs)
+        points.append(D.batch_object_points(objs, D.Compose([D.FixedPoints(256, rng), D.NormalizeScale()])))
+    D.pack_cells(objects, points, 256)
+    for bad_cell in (1, 17, 38):
+        saved = points[bad_cell].batch
+        b = saved.clone()
+        b[256], b[255] = b[255].item(), b[256].item()          # two entries of neighbouring objects swapped
+        points[bad_cell].batch = b
+        with pytest.raises(RuntimeError, match=f"cell {bad_cell}: batch vector"):
+            D.pack_cells(objects, points, 256)
+        points[bad_cell].batch = saved
+    points[5].batch = points[5].batch[:-1]
+    with pytest.raises(RuntimeError, match="cell 5: batch vector"):
+        D.pack_cells(objects, points, 256)

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -100,6 +100,8 @@ SYMBOLS = {
     "t2p_pairwise_ranking": (C.c_int, [c_void, C.c_int32, C.c_float, c_void, c_void, c_void, c_void]),
     "t2p_pack_objects": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, c_void, c_void, c_void, c_void,
                                    c_void]),
+    "t2p_pack_scene_objects": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int64, C.c_int32, c_void, c_void,
+                                         c_void, c_void, c_void, c_void]),
     "t2p_match_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "t2p_match": (C.c_int, [c_void, c_void, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(MatchWeights),
                             C.c_int32, C.c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void, C.c_size_t,

@@ -129,6 +129,31 @@ class CellRetrievalNetwork(nn.Module):
                                     class_idx=class_idx, color_idx=color_idx, tuning=self.tuning,
                                     overflow_flag=self._overflow_word() if (precision or self.precision) == "f16x3" else None)
 
+    _GUARD_BITS = ("bits 0-2 = SA level 1-3 edge inputs, 3 = SA output rows, 4 = GA hidden planes, 5 = GEMM rows past fp16's "
+                   "largest value; 6 = NaN among the input points / colours; 7 = a level's activations too SMALL for the fp16 "
+                   "pieces (largest magnitude below 2^-7: their low parts would underflow)")
+
+    def _with_guard(self, run):
+        """run() -> result of an encode on the CURRENT precision.  On the f16x3 path the sticky guard word is read after the
+        launch (one host synchronisation) and acted on as `on_overflow` says: raise, or warn and call run() again with the
+        model switched to the exact fp32 path.  The one place this logic lives: every entry point (single stream, several
+        streams, pinned-host blocks, the two pipelined halves of encode_objects, the scene path) goes through it."""
+        out = run()
+        if self.precision != "f16x3":
+            return out
+        code = self.overflow_detected()
+        if not code:
+            return out
+        msg = f"f16x3 path: an activation left the range its fp16 pieces cover (guard code {code:#x}: {self._GUARD_BITS})"
+        if self.on_overflow != "fp32":
+            raise FloatingPointError(msg + "; construct the model with precision=\"fp32\" or on_overflow=\"fp32\"")
+        warnings.warn(msg + "; recomputing this call on the exact fp32 path", RuntimeWarning)
+        saved, self.precision = self.precision, "fp32"
+        try:
+            return run()
+        finally:
+            self.precision = saved
+
     def _trim(self, out):
         """Cuts the zero padding of kernel_dim off an [n, kernel_dim] result (or an (embeddings, trace) pair)."""
         if self.kernel_dim == self.embed_dim:
@@ -175,25 +200,16 @@ class CellRetrievalNetwork(nn.Module):
             rgb = torch.zeros_like(rgb)   # models/object_encoder.py:86-90: the PointNet++ then sees x = 0
         if streams is None:
             streams = self.cell_streams if self.cell_streams else (2 if cp.shape[0] - 1 >= 2048 else 1)
-        if streams > 1 and not want_trace and cp.shape[0] - 1 >= streams:
-            return self._trim(self._encode_multi_stream(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx,
-                                                        color_idx, check_overflow, int(streams)))
-        cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx)
-        out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
-        if check_overflow and self.precision == "f16x3" and cp.shape[0] > 1:
-            code = self.overflow_detected()
-            if code:
-                msg = (f"f16x3 path: an activation left fp16's range (guard code {code:#x}: bits 0-2 = SA level 1-3 edge "
-                       "inputs, 3 = dense table rows, 4 = GA hidden planes, 5 = GEMM rows, 6 = NaN among the input points / colours)")
-                if self.on_overflow != "fp32":
-                    raise FloatingPointError(msg + "; construct the model with precision=\"fp32\" or on_overflow=\"fp32\"")
-                warnings.warn(msg + "; recomputing this call on the exact fp32 path", RuntimeWarning)
-                cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx, precision="fp32")
-                out = ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
-        return self._trim(out)
 
-    def _encode_multi_stream(self, xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx, color_idx,
-                             check_overflow, n_streams):
+        def run():
+            if streams > 1 and not want_trace and cp.shape[0] - 1 >= streams:
+                return self._encode_multi_stream(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx, color_idx,
+                                                 int(streams))
+            cfg = self._cell_config(xyz.shape[1], chunk_objects, class_idx, color_idx)
+            return ops.encode_cells(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, self._cell_pack(), cfg, want_trace)
+        return self._trim(self._with_guard(run) if check_overflow and cp.shape[0] > 1 else run())
+
+    def _encode_multi_stream(self, xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx, color_idx, n_streams):
         dev = self.device
         n_cells = cp.shape[0] - 1
         # part boundaries: first cell whose start lies past k / n of the objects (whole cells, at least one per part)
@@ -230,17 +246,6 @@ class CellRetrievalNetwork(nn.Module):
                         t.record_stream(st)
         for st in aux[: n_streams - 1]:
             main.wait_stream(st)
-        if check_overflow and self.precision == "f16x3" and self.overflow_detected():
-            if self.on_overflow != "fp32":
-                raise FloatingPointError("f16x3 path: an activation left fp16's range; construct the model with "
-                                         "precision=\"fp32\" or on_overflow=\"fp32\"")
-            warnings.warn("f16x3 path: an activation left fp16's range; recomputing on the exact fp32 path", RuntimeWarning)
-            saved, self.precision = self.precision, "fp32"
-            try:
-                return self._encode_multi_stream(xyz, rgb, center, mean_rgb, cp, cell_ptr_dev, chunk_objects, class_idx,
-                                                 color_idx, False, n_streams)
-            finally:
-                self.precision = saved
         return out
 
     def encode_objects_packed_host(self, xyz, rgb, center, mean_rgb, cell_ptr, cells_per_chunk=2048):
@@ -259,7 +264,6 @@ class CellRetrievalNetwork(nn.Module):
         if getattr(self, "_copy_stream", None) is None:
             self._copy_stream = torch.cuda.Stream(device=dev)
         copy = self._copy_stream
-        copy.wait_stream(main)
 
         def stage(b):
             lo, hi = int(cp[bounds[b]]), int(cp[bounds[b + 1]])
@@ -270,27 +274,20 @@ class CellRetrievalNetwork(nn.Module):
                 ev.record(copy)
             return d, ev, cp[bounds[b]: bounds[b + 1] + 1] - lo
 
-        outs = []
-        nxt = stage(0)
-        for b in range(len(bounds) - 1):
-            d, ev, cpb = nxt
-            if b + 2 < len(bounds):
-                nxt = stage(b + 1)
-            main.wait_event(ev)
-            for t in d:
-                t.record_stream(main)
-            outs.append(self.encode_objects_packed(d[0], d[1], d[2], d[3], cpb, d[4], check_overflow=False))
-        if self.precision == "f16x3" and self.overflow_detected():   # one check for all blocks (keeps the copies overlapped)
-            if self.on_overflow != "fp32":
-                raise FloatingPointError("f16x3 path: an activation left fp16's range; construct the model with "
-                                         "precision=\"fp32\" or on_overflow=\"fp32\"")
-            warnings.warn("f16x3 path: an activation left fp16's range; recomputing on the exact fp32 path", RuntimeWarning)
-            saved, self.precision = self.precision, "fp32"
-            try:
-                return self.encode_objects_packed_host(xyz, rgb, center, mean_rgb, cell_ptr, cells_per_chunk)
-            finally:
-                self.precision = saved
-        return outs[0] if len(outs) == 1 else torch.cat(outs)
+        def run():
+            copy.wait_stream(main)
+            outs = []
+            nxt = stage(0)
+            for b in range(len(bounds) - 1):
+                d, ev, cpb = nxt
+                if b + 2 < len(bounds):
+                    nxt = stage(b + 1)
+                main.wait_event(ev)
+                for t in d:
+                    t.record_stream(main)
+                outs.append(self.encode_objects_packed(d[0], d[1], d[2], d[3], cpb, d[4], check_overflow=False))
+            return outs[0] if len(outs) == 1 else torch.cat(outs)
+        return self._with_guard(run)     # one check for all blocks (keeps the copies overlapped)
 
     def encode_objects(self, objects, object_points):
         """objects: List[List[Object3d]], object_points: List[Batch] (one PyG-style batch per cell)
@@ -301,30 +298,19 @@ class CellRetrievalNetwork(nn.Module):
             # two halves: the kernels of the first half run while the host packs the second (packing a 512-cell batch - two
             # 25 MB concatenations into pinned memory plus the per-cell bookkeeping - takes about as long as encoding it)
             half = n_cells // 2
-            outs = [self._encode_objects_once(objects[a:b], object_points[a:b], n_pts, check_overflow=False)
-                    for a, b in ((0, half), (half, n_cells))]
-            out = torch.cat(outs)
-            if self.precision == "f16x3":
-                code = self.overflow_detected()
-                if code:
-                    if self.on_overflow != "fp32":
-                        raise FloatingPointError(f"f16x3 path: an activation left fp16's range (guard code {code:#x}); construct "
-                                                 "the model with precision=\"fp32\" or on_overflow=\"fp32\"")
-                    warnings.warn("f16x3 path: an activation left fp16's range; recomputing on the exact fp32 path", RuntimeWarning)
-                    saved, self.precision = self.precision, "fp32"
-                    try:
-                        return self.encode_objects(objects, object_points)
-                    finally:
-                        self.precision = saved
-            return out
+            return self._with_guard(lambda: torch.cat([
+                self._encode_objects_once(objects[a:b], object_points[a:b], n_pts, check_overflow=False)
+                for a, b in ((0, half), (half, n_cells))]))
         return self._encode_objects_once(objects, object_points, n_pts)
 
     def _encode_objects_once(self, objects, object_points, n_pts, check_overflow=True):
         dev = self.device
         # models/object_encoder.py:86-90: without the "color" feature the PointNet++ sees x = 0 - the colours then never travel
         skip_rgb = "color" not in self.args.use_features
+        # (the means memo serves evaluation, where the same cell lists come back; training loaders hand over fresh copies)
         xyz, rgb, center, mean_rgb, cell_ptr = pack_cells(objects, object_points, n_pts, staging=self._staging,
-                                                          means_cache=self.object_means_cache, skip_rgb=skip_rgb, device=dev)
+                                                          means_cache=None if self.training else self.object_means_cache,
+                                                          skip_rgb=skip_rgb, device=dev)
         if rgb is None:
             rgb = torch.zeros_like(xyz)
         to = lambda t: t.to(dev, non_blocking=True)
@@ -354,6 +340,39 @@ class CellRetrievalNetwork(nn.Module):
         if "color" not in self.args.use_features:
             rgb.zero_()
         return self.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)
+
+    def encode_scene_cells(self, scene, transform, lo: int = 0, hi: int = None, cell_offset: int = 0, cells_per_call: int = 8192,
+                           want_inputs: bool = False):
+        """Cells [lo, hi) of a scene.DeviceScene (raw objects resident in HBM) -> [hi - lo, D] fp32, L2-normalised: the
+        dataloader chain of evaluation/pipeline.py:303-308 (per object T.FixedPoints -> T.NormalizeScale, the per-object means)
+        runs on the GPU (t2p_pack_scene_objects) and feeds t2p_encode_cells without touching the host.  transform:
+        pipeline.PerCellTransform (its counter-based draw of global cell `cell_offset + i` is what `transform.for_cell` draws on
+        the host: same packed arrays, bit for bit).  want_inputs: also return the packed (xyz, rgb, center, mean_rgb, cell_ptr)
+        of the LAST block (parity tests feed them to the oracle)."""
+        self._check_forward_only()
+        hi = scene.n_cells if hi is None else hi
+        if hi <= lo:
+            return torch.empty((0, self.embed_dim), dtype=torch.float32, device=self.device)
+        want_rgb = "color" in self.args.use_features or bool(getattr(self.args, "class_embed", False))
+        class_all, color_all = scene.feature_indices(self)
+        kept = []
+
+        def run():
+            outs = []
+            for a in range(lo, hi, int(cells_per_call)):
+                b = min(a + int(cells_per_call), hi)
+                (xyz, rgb, center, mean_rgb), cp, ids = scene.pack_cells(transform, a, b, cell_offset, want_rgb=want_rgb)
+                if rgb is None:
+                    rgb = torch.zeros_like(xyz)      # models/object_encoder.py:86-90: the PointNet++ then sees x = 0
+                o0, o1 = int(ids[0]), int(ids[-1]) + 1
+                ci = None if class_all is None else class_all[o0:o1].contiguous()
+                co = None if color_all is None else color_all[o0:o1].contiguous()
+                outs.append(self.encode_objects_packed(xyz, rgb, center, mean_rgb, cp, class_idx=ci, color_idx=co,
+                                                       check_overflow=False))
+                kept[:] = [(xyz, rgb, center, mean_rgb, cp)]
+            return outs[0] if len(outs) == 1 else torch.cat(outs)
+        out = self._with_guard(run)
+        return (out, kept[0]) if want_inputs else out
 
     encode_cells = encode_objects  # the name BASELINE.json uses for the same method
 

@@ -928,6 +928,18 @@ int t2p_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* 
                                (hipStream_t)stream);
 }
 
+int t2p_pack_scene_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* obj_id,
+                           const uint64_t* key, const float* scene_center, const float* scene_color, int64_t n_out, int32_t n_pts,
+                           float* xyz, float* rgb, float* center, float* mean_rgb, int32_t* sample_idx_out, t2p_stream_t stream) {
+    T2P_CHECK_ARG(n_out >= 0 && n_pts >= 1, "pack_scene_objects: bad sizes");
+    T2P_CHECK_ARG(n_out == 0 || (raw_xyz && obj_ptr && obj_id && key && xyz), "pack_scene_objects: NULL argument");
+    T2P_CHECK_ARG(n_out == 0 || rgb == nullptr || raw_rgb != nullptr, "pack_scene_objects: rgb wanted but raw_rgb is NULL");
+    T2P_CHECK_ARG(n_out == 0 || ((center == nullptr || scene_center != nullptr) && (mean_rgb == nullptr || scene_color != nullptr)),
+                  "pack_scene_objects: center / mean_rgb wanted but the scene table is NULL");
+    return launch_pack_scene(raw_xyz, raw_rgb, obj_ptr, obj_id, key, scene_center, scene_color, n_out, n_pts, xyz, rgb, center,
+                             mean_rgb, sample_idx_out, (hipStream_t)stream);
+}
+
 int t2p_dedup_rows(const float* xyz, const float* rgb, int64_t n_obj, int32_t n_pts, uint16_t* rows, uint16_t* n_rows,
                    t2p_stream_t stream) {
     T2P_CHECK_ARG(n_obj >= 0, "dedup_rows: negative size");

@@ -1,21 +1,26 @@
-/* _t2p_host: CPython helper of the drop-in entry point CellRetrievalNetwork.encode_objects (no GPU work).
+/* _t2p_host: CPython helper of the drop-in entry points (no GPU work).
  *
  * The reference takes every object's centre and mean colour as a float64 NumPy mean over the object's RAW points, one
  * Python call per object and per encode_objects call (`obj.get_center()` / `obj.get_color_rgb()`,
  * datapreparation/kitti360pose/imports.py:28-41, called from models/object_encoder.py:121-131): ~20 us per object, 20 x the
- * GPU time of the cell.  column_sums() walks a whole call's objects in C instead: one attribute look-up + one buffer
- * request per object, then the column sums (and the sums of absolute values, the caller's rounding bound) of all [m, 3]
- * float64 arrays with the GIL released, on a few threads.  The caller (data.py::object_means_many) turns sums into means
+ * GPU time of the cell.  object_sums() walks a whole call's objects ONCE in C instead: per object one attribute look-up and
+ * one buffer request for `.xyz` and for `.rgb`, then - with the GIL released, on a persistent pool of worker threads - the
+ * column sums (and the sums of absolute values, the caller's rounding bound) of all [m, 3] float64 arrays and, when asked
+ * for, their float32 copies back to back (the upload image of scene.DeviceScene).  The caller (data.py) turns sums into means
  * and proves each float32 result equal to the reference's bit for bit (or recomputes that row with np.mean itself), so the
  * summation order here is free: four interleaved partial sums per column.
  *
- *   column_sums(cells, attr, sums, abs_sums, rows, threads) -> n_objects
- *     cells      list of lists of objects (a call's `objects` argument, or the part of it that is not cached)
- *     attr       "xyz" or "rgb": the attribute holding a C-contiguous float64 [m, 3] array with m >= 1
- *     sums, abs_sums   writable float64 buffers of >= 3 n_objects items;  rows: writable int64 buffer of >= n_objects items
- *     threads    worker threads for the summation (<= 16)
- *   returns the number of objects, or -(i + 1) if flat object i does not hold such an array (nothing is written then:
+ *   object_sums(cells, sums, abs_sums, rows, threads[, xyz_f32, rgb_f32]) -> n_objects
+ *     cells            list of lists of objects (each with `.xyz` and `.rgb`: C-contiguous float64 [m, 3] arrays, m >= 1)
+ *     sums, abs_sums   writable float64 buffers of >= 2 * 3 * n_objects items: [0] = xyz, [1] = rgb ([2][n][3])
+ *     rows             writable int64 buffer of >= 2 * n_objects items ([2][n]: rows of .xyz, rows of .rgb)
+ *     threads          worker threads (<= 32; the pool grows to the largest count ever asked for)
+ *     xyz_f32, rgb_f32 optional writable float32 buffers of >= 3 * (total rows) items: the points, converted, back to back
+ *                      (then every object must have as many colours as points)
+ *   returns the number of objects, or -(i + 1) if flat object i does not hold such arrays (nothing useful is written then:
  *   the caller falls back to the accessors of the objects).
+ *   column_sums(cells, attr, sums, abs_sums, rows, threads): the same for one attribute (kept for callers that need one).
+ *   point_rows(cells, rows) -> n_objects: rows of every object's `.xyz` (int64 [n]) without touching the points.
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
@@ -25,16 +30,20 @@
 #include <string.h>
 #include <math.h>
 
+#define MAX_THREADS 32
+
 typedef struct {
     const double* p;
     Py_ssize_t rows;
+    Py_ssize_t row0;   /* first row of this array in the float32 image */
+    double* sums;
+    double* asums;
+    float* f32;        /* NULL or the base of the float32 image */
 } arr_t;
 
 typedef struct {
     const arr_t* a;
     Py_ssize_t lo, hi;
-    double* sums;
-    double* asums;
 } job_t;
 
 /* Column sums and sums of absolute values of one [m, 3] array.  The array is read as a flat stream of doubles with TWELVE
@@ -42,19 +51,34 @@ typedef struct {
  * compiler turns into three 4-wide vector adds per 12 elements without re-associating anything; cloned for AVX2 with run-time
  * dispatch (the library is built in one container and runs in another). */
 __attribute__((target_clones("avx2", "default")))
-static void sum_one(const double* p, Py_ssize_t m, double* s, double* t) {
+static void sum_one(const double* p, Py_ssize_t m, double* s, double* t, float* f) {
     double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, b[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const Py_ssize_t n = 3 * m;
     Py_ssize_t i = 0;
-    for (; i + 12 <= n; i += 12)
-        for (int j = 0; j < 12; j++) {
-            const double v = p[i + j];
-            a[j] += v;
-            b[j] += fabs(v);
+    if (f != NULL) {
+        for (; i + 12 <= n; i += 12)
+            for (int j = 0; j < 12; j++) {
+                const double v = p[i + j];
+                a[j] += v;
+                b[j] += fabs(v);
+                f[i + j] = (float)v;
+            }
+        for (int j = 0; i < n; i++, j++) {
+            a[j] += p[i];
+            b[j] += fabs(p[i]);
+            f[i] = (float)p[i];
         }
-    for (int j = 0; i < n; i++, j++) {
-        a[j] += p[i];
-        b[j] += fabs(p[i]);
+    } else {
+        for (; i + 12 <= n; i += 12)
+            for (int j = 0; j < 12; j++) {
+                const double v = p[i + j];
+                a[j] += v;
+                b[j] += fabs(v);
+            }
+        for (int j = 0; i < n; i++, j++) {
+            a[j] += p[i];
+            b[j] += fabs(p[i]);
+        }
     }
     for (int c = 0; c < 3; c++) {
         s[c] = (a[c] + a[3 + c]) + (a[6 + c] + a[9 + c]);
@@ -62,10 +86,213 @@ static void sum_one(const double* p, Py_ssize_t m, double* s, double* t) {
     }
 }
 
-static void* run_job(void* arg) {
-    job_t* j = (job_t*)arg;
-    for (Py_ssize_t i = j->lo; i < j->hi; i++) sum_one(j->a[i].p, j->a[i].rows, j->sums + 3 * i, j->asums + 3 * i);
+static void run_job(const job_t* j) {
+    for (Py_ssize_t i = j->lo; i < j->hi; i++) {
+        const arr_t* a = &j->a[i];
+        sum_one(a->p, a->rows, a->sums, a->asums, a->f32 ? a->f32 + 3 * a->row0 : NULL);
+    }
+}
+
+/* ---- persistent worker pool: threads are started once (a pthread_create per call cost as much as summing ~100 k rows) and
+ * sleep on a condition variable between calls; the calling thread takes jobs too.  One batch of jobs at a time (callers hold
+ * `pool.call` for the length of a batch).  A forked child (DataLoader workers) starts with an empty pool. */
+static struct {
+    pthread_mutex_t mu, call;
+    pthread_cond_t work, done;
+    pthread_t tid[MAX_THREADS];
+    int n_threads;
+    const job_t* jobs;
+    int n_jobs, next, pending;
+} pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, NULL, 0, 0, 0};
+
+static void* worker(void* arg) {
+    (void)arg;
+    pthread_mutex_lock(&pool.mu);
+    for (;;) {
+        while (pool.next >= pool.n_jobs) pthread_cond_wait(&pool.work, &pool.mu);
+        const job_t* j = &pool.jobs[pool.next++];
+        pthread_mutex_unlock(&pool.mu);
+        run_job(j);
+        pthread_mutex_lock(&pool.mu);
+        if (--pool.pending == 0) pthread_cond_signal(&pool.done);
+    }
     return NULL;
+}
+
+static void pool_after_fork_child(void) {
+    pthread_mutex_init(&pool.mu, NULL);
+    pthread_mutex_init(&pool.call, NULL);
+    pthread_cond_init(&pool.work, NULL);
+    pthread_cond_init(&pool.done, NULL);
+    pool.n_threads = 0;
+    pool.jobs = NULL;
+    pool.n_jobs = pool.next = pool.pending = 0;
+}
+
+/* Runs the jobs on up to `threads` threads (the caller included) and returns when all are done.  GIL not needed. */
+static void pool_run(const job_t* jobs, int n_jobs, int threads) {
+    if (threads > MAX_THREADS) threads = MAX_THREADS;
+    if (threads <= 1 || n_jobs <= 1) {
+        for (int i = 0; i < n_jobs; i++) run_job(&jobs[i]);
+        return;
+    }
+    pthread_mutex_lock(&pool.call);
+    pthread_mutex_lock(&pool.mu);
+    while (pool.n_threads < threads - 1) {
+        if (pthread_create(&pool.tid[pool.n_threads], NULL, worker, NULL) != 0) break;   /* fewer helpers: the caller does more */
+        pthread_detach(pool.tid[pool.n_threads]);
+        pool.n_threads++;
+    }
+    pool.jobs = jobs;
+    pool.n_jobs = n_jobs;
+    pool.next = 0;
+    pool.pending = n_jobs;
+    pthread_cond_broadcast(&pool.work);
+    while (pool.next < pool.n_jobs) {
+        const job_t* j = &pool.jobs[pool.next++];
+        pthread_mutex_unlock(&pool.mu);
+        run_job(j);
+        pthread_mutex_lock(&pool.mu);
+        pool.pending--;
+    }
+    while (pool.pending > 0) pthread_cond_wait(&pool.done, &pool.mu);
+    pool.jobs = NULL;
+    pool.n_jobs = pool.next = 0;
+    pthread_mutex_unlock(&pool.mu);
+    pthread_mutex_unlock(&pool.call);
+}
+
+/* Splits [0, n) into contiguous ranges of ~equal row counts (4 per thread, for balance) and runs them. */
+static void sum_all(const arr_t* arrs, Py_ssize_t n, Py_ssize_t total_rows, int threads) {
+    if (threads > MAX_THREADS) threads = MAX_THREADS;
+    if (threads < 1) threads = 1;
+    if ((Py_ssize_t)threads > total_rows / 40000 + 1) threads = (int)(total_rows / 40000 + 1);   /* a wake-up costs ~ 20 k rows */
+    job_t jobs[4 * MAX_THREADS];
+    const int want = threads == 1 ? 1 : 4 * threads;
+    Py_ssize_t lo = 0, acc = 0;
+    int nj = 0;
+    for (Py_ssize_t i = 0; i < n; i++) {
+        acc += arrs[i].rows;
+        if (nj + 1 < want && acc * (Py_ssize_t)want >= total_rows * (Py_ssize_t)(nj + 1)) {
+            jobs[nj].a = arrs; jobs[nj].lo = lo; jobs[nj].hi = i + 1;
+            nj++;
+            lo = i + 1;
+        }
+    }
+    if (lo < n) {
+        jobs[nj].a = arrs; jobs[nj].lo = lo; jobs[nj].hi = n;
+        nj++;
+    }
+    pool_run(jobs, nj, threads);
+}
+
+static int is_f64_points(const Py_buffer* v) {
+    const char* f = v->format ? v->format : "B";
+    if (f[0] == '<' || f[0] == '=' || f[0] == '@') f++;
+    return strcmp(f, "d") == 0 && v->ndim == 2 && v->shape[1] == 3 && v->shape[0] >= 1 && v->itemsize == 8 &&
+           v->strides[1] == 8 && v->strides[0] == 24;
+}
+
+static Py_ssize_t count_objects(PyObject* cells) {
+    Py_ssize_t n = 0;
+    const Py_ssize_t n_cells = PyList_GET_SIZE(cells);
+    for (Py_ssize_t c = 0; c < n_cells; c++) {
+        PyObject* objs = PyList_GET_ITEM(cells, c);
+        if (!PyList_Check(objs)) {
+            PyErr_SetString(PyExc_TypeError, "_t2p_host: every cell must be a list of objects");
+            return -1;
+        }
+        n += PyList_GET_SIZE(objs);
+    }
+    return n;
+}
+
+/* Shared body.  attrs[k] (k < n_attr): attribute names; output planes k of sums / asums / rows. */
+static PyObject* sums_impl(PyObject* cells, PyObject** attrs, int n_attr, Py_buffer* sums, Py_buffer* asums, Py_buffer* rows,
+                           int threads, Py_buffer* f32 /* NULL or n_attr buffers */) {
+    PyObject* result = NULL;
+    Py_buffer* views = NULL;
+    arr_t* arrs = NULL;
+    Py_ssize_t got = 0;
+    const Py_ssize_t n = count_objects(cells);
+    if (n < 0) return NULL;
+    const Py_ssize_t n_cells = PyList_GET_SIZE(cells);
+    if (sums->len < (Py_ssize_t)(n_attr * 3 * n * sizeof(double)) || asums->len < (Py_ssize_t)(n_attr * 3 * n * sizeof(double)) ||
+        rows->len < (Py_ssize_t)(n_attr * n * sizeof(int64_t)) || sums->itemsize != 8 || asums->itemsize != 8 || rows->itemsize != 8) {
+        PyErr_SetString(PyExc_ValueError, "_t2p_host: output buffers are too small (float64 [k][n][3] x 2, int64 [k][n])");
+        return NULL;
+    }
+    views = (Py_buffer*)calloc((size_t)(n_attr * n > 0 ? n_attr * n : 1), sizeof(Py_buffer));
+    arrs = (arr_t*)malloc((size_t)(n_attr * n > 0 ? n_attr * n : 1) * sizeof(arr_t));
+    if (views == NULL || arrs == NULL) {
+        PyErr_NoMemory();
+        goto done;
+    }
+    Py_ssize_t bad = -1, total_rows[2] = {0, 0}, flat = 0;
+    for (Py_ssize_t c = 0; c < n_cells && bad < 0; c++) {
+        PyObject* objs = PyList_GET_ITEM(cells, c);
+        const Py_ssize_t k = PyList_GET_SIZE(objs);
+        for (Py_ssize_t j = 0; j < k && bad < 0; j++, flat++) {
+            for (int t = 0; t < n_attr; t++) {
+                PyObject* a = PyObject_GetAttr(PyList_GET_ITEM(objs, j), attrs[t]);
+                if (a == NULL) {
+                    PyErr_Clear();
+                    bad = flat;
+                    break;
+                }
+                const int rc = PyObject_GetBuffer(a, &views[got], PyBUF_FORMAT | PyBUF_STRIDES);
+                Py_DECREF(a);   /* the view holds its own reference to the exporter */
+                if (rc != 0) {
+                    PyErr_Clear();
+                    bad = flat;
+                    break;
+                }
+                Py_buffer* v = &views[got];
+                got++;          /* (released below whatever the checks say) */
+                if (!is_f64_points(v)) {
+                    bad = flat;
+                    break;
+                }
+                arr_t* e = &arrs[t * n + flat];
+                e->p = (const double*)v->buf;
+                e->rows = v->shape[0];
+                e->row0 = total_rows[t];
+                e->sums = (double*)sums->buf + 3 * (t * n + flat);
+                e->asums = (double*)asums->buf + 3 * (t * n + flat);
+                e->f32 = f32 != NULL ? (float*)f32[t].buf : NULL;
+                total_rows[t] += v->shape[0];
+                ((int64_t*)rows->buf)[t * n + flat] = (int64_t)v->shape[0];
+            }
+        }
+    }
+    if (bad >= 0) {
+        result = PyLong_FromSsize_t(-(bad + 1));
+        goto done;
+    }
+    if (f32 != NULL) {
+        for (int t = 0; t < n_attr; t++)
+            if (f32[t].itemsize != 4 || f32[t].len < (Py_ssize_t)(3 * total_rows[t] * sizeof(float))) {
+                PyErr_SetString(PyExc_ValueError, "_t2p_host: the float32 image is too small (3 x total rows items)");
+                goto done;
+            }
+        if (n_attr == 2)
+            for (Py_ssize_t i = 0; i < n; i++)
+                if (arrs[i].rows != arrs[n + i].rows) {
+                    result = PyLong_FromSsize_t(-(i + 1));    /* colours and points must pair up in the upload image */
+                    goto done;
+                }
+    }
+    Py_BEGIN_ALLOW_THREADS
+    sum_all(arrs, n_attr * n, total_rows[0] + total_rows[1], threads);
+    Py_END_ALLOW_THREADS
+    result = PyLong_FromSsize_t(n);
+done:
+    if (views != NULL) {
+        for (Py_ssize_t i = 0; i < got; i++) PyBuffer_Release(&views[i]);
+        free(views);
+    }
+    free(arrs);
+    return result;
 }
 
 static PyObject* column_sums(PyObject* self, PyObject* args) {
@@ -73,107 +300,88 @@ static PyObject* column_sums(PyObject* self, PyObject* args) {
     Py_buffer sums, asums, rows;
     int threads = 1;
     if (!PyArg_ParseTuple(args, "O!Uw*w*w*i", &PyList_Type, &cells, &attr, &sums, &asums, &rows, &threads)) return NULL;
+    PyObject* result = sums_impl(cells, &attr, 1, &sums, &asums, &rows, threads, NULL);
+    PyBuffer_Release(&sums);
+    PyBuffer_Release(&asums);
+    PyBuffer_Release(&rows);
+    return result;
+}
+
+static PyObject* object_sums(PyObject* self, PyObject* args) {
+    PyObject* cells;
+    Py_buffer sums, asums, rows, f32[2];
+    PyObject *fx = Py_None, *fr = Py_None;
+    int threads = 1;
+    if (!PyArg_ParseTuple(args, "O!w*w*w*i|OO", &PyList_Type, &cells, &sums, &asums, &rows, &threads, &fx, &fr)) return NULL;
     PyObject* result = NULL;
-    Py_buffer* views = NULL;
-    arr_t* arrs = NULL;
-    Py_ssize_t n = 0, got = 0;
+    PyObject* attrs[2] = {PyUnicode_InternFromString("xyz"), PyUnicode_InternFromString("rgb")};
+    int have = 0;
+    if (attrs[0] == NULL || attrs[1] == NULL) goto done;
+    if ((fx == Py_None) != (fr == Py_None)) {
+        PyErr_SetString(PyExc_ValueError, "object_sums: pass both float32 images or neither");
+        goto done;
+    }
+    if (fx != Py_None) {
+        if (PyObject_GetBuffer(fx, &f32[0], PyBUF_WRITABLE) != 0) goto done;
+        if (PyObject_GetBuffer(fr, &f32[1], PyBUF_WRITABLE) != 0) {
+            PyBuffer_Release(&f32[0]);
+            goto done;
+        }
+        have = 1;
+    }
+    result = sums_impl(cells, attrs, 2, &sums, &asums, &rows, threads, have ? f32 : NULL);
+    if (have) {
+        PyBuffer_Release(&f32[0]);
+        PyBuffer_Release(&f32[1]);
+    }
+done:
+    Py_XDECREF(attrs[0]);
+    Py_XDECREF(attrs[1]);
+    PyBuffer_Release(&sums);
+    PyBuffer_Release(&asums);
+    PyBuffer_Release(&rows);
+    return result;
+}
+
+static PyObject* point_rows(PyObject* self, PyObject* args) {
+    PyObject* cells;
+    Py_buffer rows;
+    if (!PyArg_ParseTuple(args, "O!w*", &PyList_Type, &cells, &rows)) return NULL;
+    PyObject* result = NULL;
+    PyObject* attr = PyUnicode_InternFromString("xyz");
+    const Py_ssize_t n = count_objects(cells);
+    if (attr == NULL || n < 0) goto done;
+    if (rows.itemsize != 8 || rows.len < (Py_ssize_t)(n * sizeof(int64_t))) {
+        PyErr_SetString(PyExc_ValueError, "point_rows: rows must be a writable int64 buffer of n_objects items");
+        goto done;
+    }
+    Py_ssize_t flat = 0;
     const Py_ssize_t n_cells = PyList_GET_SIZE(cells);
     for (Py_ssize_t c = 0; c < n_cells; c++) {
         PyObject* objs = PyList_GET_ITEM(cells, c);
-        if (!PyList_Check(objs)) {
-            PyErr_SetString(PyExc_TypeError, "column_sums: every cell must be a list of objects");
-            goto done;
-        }
-        n += PyList_GET_SIZE(objs);
-    }
-    if (sums.len < (Py_ssize_t)(3 * n * sizeof(double)) || asums.len < (Py_ssize_t)(3 * n * sizeof(double)) ||
-        rows.len < (Py_ssize_t)(n * sizeof(int64_t)) || sums.itemsize != 8 || asums.itemsize != 8 || rows.itemsize != 8) {
-        PyErr_SetString(PyExc_ValueError, "column_sums: output buffers are too small (float64 [n, 3] x 2, int64 [n])");
-        goto done;
-    }
-    views = (Py_buffer*)calloc((size_t)(n > 0 ? n : 1), sizeof(Py_buffer));
-    arrs = (arr_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(arr_t));
-    if (views == NULL || arrs == NULL) {
-        PyErr_NoMemory();
-        goto done;
-    }
-    Py_ssize_t bad = -1, total_rows = 0;
-    for (Py_ssize_t c = 0; c < n_cells && bad < 0; c++) {
-        PyObject* objs = PyList_GET_ITEM(cells, c);
         const Py_ssize_t k = PyList_GET_SIZE(objs);
-        for (Py_ssize_t j = 0; j < k; j++) {
+        for (Py_ssize_t j = 0; j < k; j++, flat++) {
             PyObject* a = PyObject_GetAttr(PyList_GET_ITEM(objs, j), attr);
-            if (a == NULL) {
+            Py_buffer v;
+            if (a == NULL || PyObject_GetBuffer(a, &v, PyBUF_FORMAT | PyBUF_STRIDES) != 0) {
                 PyErr_Clear();
-                bad = got;
-                break;
+                Py_XDECREF(a);
+                result = PyLong_FromSsize_t(-(flat + 1));
+                goto done;
             }
-            const int rc = PyObject_GetBuffer(a, &views[got], PyBUF_FORMAT | PyBUF_STRIDES);
-            Py_DECREF(a);   /* the view holds its own reference to the exporter */
-            if (rc != 0) {
-                PyErr_Clear();
-                bad = got;
-                break;
-            }
-            Py_buffer* v = &views[got];
-            got++;          /* (released below whatever the checks say) */
-            const char* f = v->format ? v->format : "B";
-            if (f[0] == '<' || f[0] == '=' || f[0] == '@') f++;
-            if (strcmp(f, "d") != 0 || v->ndim != 2 || v->shape[1] != 3 || v->shape[0] < 1 || v->itemsize != 8 ||
-                v->strides[1] != 8 || v->strides[0] != 24) {
-                bad = got - 1;
-                break;
-            }
-            arrs[got - 1].p = (const double*)v->buf;
-            arrs[got - 1].rows = v->shape[0];
-            total_rows += v->shape[0];
-        }
-    }
-    if (bad >= 0) {
-        result = PyLong_FromSsize_t(-(bad + 1));
-        goto done;
-    }
-    {
-        int64_t* r = (int64_t*)rows.buf;
-        for (Py_ssize_t i = 0; i < n; i++) r[i] = (int64_t)arrs[i].rows;
-        if (threads > 16) threads = 16;
-        if (threads < 1) threads = 1;
-        if ((Py_ssize_t)threads > total_rows / 150000 + 1) threads = (int)(total_rows / 150000 + 1);   /* a thread start costs as much as ~100 k rows */
-        job_t jobs[16];
-        Py_ssize_t lo = 0, acc = 0;
-        int nj = 0;
-        for (Py_ssize_t i = 0; i < n; i++) {     /* contiguous object ranges with ~equal row counts */
-            acc += arrs[i].rows;
-            if (nj + 1 < threads && acc * (Py_ssize_t)threads >= total_rows * (Py_ssize_t)(nj + 1)) {
-                jobs[nj].a = arrs; jobs[nj].lo = lo; jobs[nj].hi = i + 1;
-                jobs[nj].sums = (double*)sums.buf; jobs[nj].asums = (double*)asums.buf;
-                nj++;
-                lo = i + 1;
+            Py_DECREF(a);
+            const int ok = is_f64_points(&v);
+            ((int64_t*)rows.buf)[flat] = ok ? (int64_t)v.shape[0] : 0;
+            PyBuffer_Release(&v);
+            if (!ok) {
+                result = PyLong_FromSsize_t(-(flat + 1));
+                goto done;
             }
         }
-        jobs[nj].a = arrs; jobs[nj].lo = lo; jobs[nj].hi = n;
-        jobs[nj].sums = (double*)sums.buf; jobs[nj].asums = (double*)asums.buf;
-        nj++;
-        Py_BEGIN_ALLOW_THREADS
-        pthread_t tid[16];
-        int started[16];
-        for (int t = 1; t < nj; t++) started[t] = pthread_create(&tid[t], NULL, run_job, &jobs[t]) == 0;
-        run_job(&jobs[0]);
-        for (int t = 1; t < nj; t++) {
-            if (started[t]) pthread_join(tid[t], NULL);
-            else run_job(&jobs[t]);
-        }
-        Py_END_ALLOW_THREADS
-        result = PyLong_FromSsize_t(n);
     }
+    result = PyLong_FromSsize_t(n);
 done:
-    if (views != NULL) {
-        for (Py_ssize_t i = 0; i < got; i++) PyBuffer_Release(&views[i]);
-        free(views);
-    }
-    free(arrs);
-    PyBuffer_Release(&sums);
-    PyBuffer_Release(&asums);
+    Py_XDECREF(attr);
     PyBuffer_Release(&rows);
     return result;
 }
@@ -181,8 +389,14 @@ done:
 static PyMethodDef methods[] = {
     {"column_sums", column_sums, METH_VARARGS,
      "column_sums(cells, attr, sums, abs_sums, rows, threads) -> n_objects (or -(i + 1): flat object i has no float64 [m, 3] array)"},
+    {"object_sums", object_sums, METH_VARARGS,
+     "object_sums(cells, sums[2][n][3], abs_sums[2][n][3], rows[2][n], threads[, xyz_f32, rgb_f32]) -> n_objects (or -(i + 1))"},
+    {"point_rows", point_rows, METH_VARARGS, "point_rows(cells, rows[n]) -> n_objects (or -(i + 1))"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_t2p_host", "host-side helpers of text2pos_amd (no GPU work)", -1, methods};
 
-PyMODINIT_FUNC PyInit__t2p_host(void) { return PyModule_Create(&module); }
+PyMODINIT_FUNC PyInit__t2p_host(void) {
+    pthread_atfork(NULL, NULL, pool_after_fork_child);
+    return PyModule_Create(&module);
+}

@@ -207,11 +207,75 @@ __global__ __launch_bounds__(256) void k_mlp3_norm(const float* __restrict__ in3
     }
 }
 
-// On-device version of dataloading/kitti360pose/utils.py::batch_object_points + the per-object means of
-// models/object_encoder.py:121-131: for every raw object (ragged point list) gather the P sampled points
-// (T.FixedPoints: the indices come from the host's seeded generator), apply T.NormalizeScale (subtract the mean of the
-// SAMPLED points, scale by 0.999999 / max|.|) and emit Object3d.get_center() / get_color_rgb() (means over ALL raw
-// points, accumulated in float64 like NumPy).  One wavefront per object.
+// ---- on-device dataloader ---------------------------------------------------------------------------
+// The per-object transform chain of dataloading/kitti360pose/utils.py:89-110 (Data -> T.FixedPoints(P) [-> T.RandomRotate]
+// -> T.NormalizeScale -> Batch) with one wavefront per object.  The P sampled points are staged in LDS ([P][3] floats per
+// wave); NormalizeScale then reproduces the host chain BIT FOR BIT:
+//   * `pos.mean(dim=-2)` is summed in the order ATen's CPU kernel uses for a [P, 3] fp32 tensor (SumKernel.cpp: row_sum =
+//     multi_row_sum over the row viewed as [P/4, 4]: four interleaved partial sums per column, each a cascade that folds
+//     its running sum into the next level every 16 items (level_power = max(4, CeilLog2(P/4) / 4) = 4 for every P <= 2^18),
+//     the P % 4 tail rows added to partial sum 0, then ((p0 + p1) + p2) + p3), followed by a true division by P;
+//   * `pos - mean`, `abs().max()`, `(1 / max) * 0.999999` and `pos * scale` are single correctly rounded fp32 operations
+//     in both places (the library is built with -ffp-contract=off).
+// tests/test_gpu_parity.py holds the kernel to torch's result with array_equal.
+__device__ __forceinline__ uint64_t pack_mix64(uint64_t x) {   // splitmix64 finaliser (= synthetic._mix on the host)
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// Column sums of the wave's staged points in ATen's order; every lane returns (sx, sy, sz).
+__device__ __forceinline__ void aten_column_sums(const float* __restrict__ pts, int n_pts, int lane, float& sx, float& sy, float& sz) {
+    float part = 0.f;
+    if (lane < 12) {                      // lane = 4 * column + k: partial sum k of that column
+        const int c = lane >> 2, k = lane & 3;
+        const int size_ilp = n_pts >> 2;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int i = 0;
+        while (i + 16 <= size_ilp) {
+            for (int j = 0; j < 16; j++, i++) acc[0] += pts[(4 * i + k) * 3 + c];
+            for (int j = 1; j < 4; j++) {
+                acc[j] += acc[j - 1];
+                acc[j - 1] = 0.f;
+                if ((i & (0xF << (4 * j))) != 0) break;
+            }
+        }
+        for (; i < size_ilp; i++) acc[0] += pts[(4 * i + k) * 3 + c];
+        for (int j = 1; j < 4; j++) acc[0] += acc[j];
+        if (k == 0)
+            for (int r = size_ilp * 4; r < n_pts; r++) acc[0] += pts[r * 3 + c];
+        part = acc[0];
+    }
+    // ((p0 + p1) + p2) + p3 of each column
+    const float p1 = __shfl_down(part, 1, 64), p2 = __shfl_down(part, 2, 64), p3 = __shfl_down(part, 3, 64);
+    const float tot = ((part + p1) + p2) + p3;
+    sx = __shfl(tot, 0, 64);
+    sy = __shfl(tot, 4, 64);
+    sz = __shfl(tot, 8, 64);
+}
+
+// T.NormalizeScale of the wave's staged points, written to q [n_pts][3].
+__device__ __forceinline__ void normalize_scale_store(const float* __restrict__ pts, int n_pts, int lane, float* __restrict__ q) {
+    float sx, sy, sz;
+    aten_column_sums(pts, n_pts, lane, sx, sy, sz);
+    const float mx = sx / (float)n_pts, my = sy / (float)n_pts, mz = sz / (float)n_pts;
+    float amax = 0.f;
+    for (int i = lane; i < n_pts; i += 64)
+        amax = fmaxf(amax, fmaxf(fabsf(pts[i * 3] - mx), fmaxf(fabsf(pts[i * 3 + 1] - my), fabsf(pts[i * 3 + 2] - mz))));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    const float scale = (1.f / amax) * 0.999999f;
+    for (int i = lane; i < n_pts; i += 64) {
+        q[i * 3] = (pts[i * 3] - mx) * scale;
+        q[i * 3 + 1] = (pts[i * 3 + 1] - my) * scale;
+        q[i * 3 + 2] = (pts[i * 3 + 2] - mz) * scale;
+    }
+}
+
+// t2p_pack_objects: ragged raw objects back to back + the host's T.FixedPoints draw (sample_idx) -> packed encoder inputs and
+// the per-object means of models/object_encoder.py:121-131 (Object3d.get_center() / get_color_rgb(): means over ALL raw
+// points, accumulated in float64 like NumPy - from the fp32 copies of the points that were uploaded).
 // rot (optional, [n_obj][2] = cos, sin of the object's angle): T.RandomRotate(deg, axis=2) of the training transform
 // (training/coarse.py:192-198), applied between the resampling and NormalizeScale: pos <- pos @ [[c, s, 0], [-s, c, 0],
 // [0, 0, 1]].  The angle is drawn on the host like the FixedPoints indices.
@@ -221,7 +285,9 @@ __global__ __launch_bounds__(256) void k_pack_objects(const float* __restrict__ 
                                                       const float* __restrict__ rot, int64_t n_obj, int n_pts,
                                                       float* __restrict__ xyz, float* __restrict__ rgb,
                                                       float* __restrict__ center, float* __restrict__ mean_rgb) {
+    extern __shared__ float pack_lds[];
     const int lane = threadIdx.x & 63;
+    float* pts = pack_lds + (threadIdx.x >> 6) * n_pts * 3;
     const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= n_obj) return;
     const int lo = obj_ptr[o], hi = obj_ptr[o + 1], m = hi - lo;
@@ -240,57 +306,68 @@ __global__ __launch_bounds__(256) void k_pack_objects(const float* __restrict__ 
     }
     if (lane < 3) center[o * 3 + lane] = (float)(acc[lane] / (double)m);
     else if (lane < 6) mean_rgb[o * 3 + lane - 3] = (float)(acc[lane] / (double)m);
-    // resample (+ rotate) + NormalizeScale
+    // resample (+ rotate) into LDS, colours straight to the output
     const bool rotate = rot != nullptr;
     const float rc = rotate ? rot[o * 2] : 1.f, rs = rotate ? rot[o * 2 + 1] : 0.f;
-    auto point = [&](int i, float& x, float& y, float& z) {
-        const int j = lo + sample_idx[o * n_pts + i];
-        x = raw_xyz[(int64_t)j * 3];
-        y = raw_xyz[(int64_t)j * 3 + 1];
-        z = raw_xyz[(int64_t)j * 3 + 2];
+    for (int i = lane; i < n_pts; i += 64) {
+        const int64_t j = lo + sample_idx[o * n_pts + i];
+        float x = raw_xyz[j * 3], y = raw_xyz[j * 3 + 1];
         if (rotate) {  // row vector times the matrix, terms added in column order like the fp32 matmul
             const float xr = x * rc + y * -rs, yr = x * rs + y * rc;
             x = xr;
             y = yr;
         }
-    };
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int i = lane; i < n_pts; i += 64) {
-        float x, y, z;
-        point(i, x, y, z);
-        sx += x;
-        sy += y;
-        sz += z;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        sx += __shfl_xor(sx, off, 64);
-        sy += __shfl_xor(sy, off, 64);
-        sz += __shfl_xor(sz, off, 64);
-    }
-    const float mx = sx / (float)n_pts, my = sy / (float)n_pts, mz = sz / (float)n_pts;
-    float amax = 0.f;
-    for (int i = lane; i < n_pts; i += 64) {
-        float x, y, z;
-        point(i, x, y, z);
-        amax = fmaxf(amax, fmaxf(fabsf(x - mx), fmaxf(fabsf(y - my), fabsf(z - mz))));
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
-    const float scale = (1.f / amax) * 0.999999f;
-    for (int i = lane; i < n_pts; i += 64) {
-        const int j = lo + sample_idx[o * n_pts + i];
-        float* q = xyz + (o * n_pts + i) * 3;
+        pts[i * 3] = x;
+        pts[i * 3 + 1] = y;
+        pts[i * 3 + 2] = raw_xyz[j * 3 + 2];
         float* c = rgb + (o * n_pts + i) * 3;
-        float x, y, z;
-        point(i, x, y, z);
-        q[0] = (x - mx) * scale;
-        q[1] = (y - my) * scale;
-        q[2] = (z - mz) * scale;
-        c[0] = raw_rgb[(int64_t)j * 3];
-        c[1] = raw_rgb[(int64_t)j * 3 + 1];
-        c[2] = raw_rgb[(int64_t)j * 3 + 2];
+        c[0] = raw_rgb[j * 3];
+        c[1] = raw_rgb[j * 3 + 1];
+        c[2] = raw_rgb[j * 3 + 2];
     }
+    normalize_scale_store(pts, n_pts, lane, xyz + o * n_pts * 3);
+}
+
+// t2p_pack_scene_objects: the same chain for a scene whose raw points live in HBM (uploaded once): output slot s takes scene
+// object obj_id[s]; its T.FixedPoints draw is counter-based - point p of the slot is raw point
+//     ((mix64(key[s] ^ p * 0xD6E8FEB86659FD93) >> 32) * m) >> 32        (m = points of the object)
+// so a slot's sample depends on its key only (the host derives it from (seed, global cell index, object slot):
+// pipeline.PerCellTransform), whichever rank, batch or stream packs it; centre / mean colour are gathered from the scene's
+// per-object tables (the reference's float64 means, computed once on the host: exact).
+__global__ __launch_bounds__(256) void k_pack_scene(const float* __restrict__ raw_xyz, const float* __restrict__ raw_rgb,
+                                                    const int32_t* __restrict__ obj_ptr, const int32_t* __restrict__ obj_id,
+                                                    const uint64_t* __restrict__ key, const float* __restrict__ scene_center,
+                                                    const float* __restrict__ scene_color, int64_t n_out, int n_pts,
+                                                    float* __restrict__ xyz, float* __restrict__ rgb, float* __restrict__ center,
+                                                    float* __restrict__ mean_rgb, int32_t* __restrict__ idx_out) {
+    extern __shared__ float pack_lds[];
+    const int lane = threadIdx.x & 63;
+    float* pts = pack_lds + (threadIdx.x >> 6) * n_pts * 3;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_out) return;
+    const int64_t o = obj_id[s];
+    const int64_t lo = obj_ptr[o];
+    const uint64_t m = (uint64_t)(obj_ptr[o + 1] - obj_ptr[o]);
+    const uint64_t k = key[s];
+    if (lane < 3) {
+        if (center != nullptr) center[s * 3 + lane] = scene_center[o * 3 + lane];
+        if (mean_rgb != nullptr) mean_rgb[s * 3 + lane] = scene_color[o * 3 + lane];
+    }
+    for (int i = lane; i < n_pts; i += 64) {
+        const uint32_t d = (uint32_t)(((pack_mix64(k ^ ((uint64_t)i * 0xD6E8FEB86659FD93ull)) >> 32) * m) >> 32);
+        const int64_t j = lo + d;
+        pts[i * 3] = raw_xyz[j * 3];
+        pts[i * 3 + 1] = raw_xyz[j * 3 + 1];
+        pts[i * 3 + 2] = raw_xyz[j * 3 + 2];
+        if (rgb != nullptr) {
+            float* c = rgb + (s * n_pts + i) * 3;
+            c[0] = raw_rgb[j * 3];
+            c[1] = raw_rgb[j * 3 + 1];
+            c[2] = raw_rgb[j * 3 + 2];
+        }
+        if (idx_out != nullptr) idx_out[s * n_pts + i] = (int32_t)d;
+    }
+    normalize_scale_store(pts, n_pts, lane, xyz + s * n_pts * 3);
 }
 
 // PairwiseRankingLoss (training/losses.py:126-164) on the score matrix S = im_n s_n^T [B][B]:
@@ -484,11 +561,24 @@ int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const fl
 int launch_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
                         const float* rot, int64_t n_obj, int n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
                         hipStream_t st) {
+    T2P_CHECK_ARG(n_pts <= 1024, "pack_objects: n_pts=%d > 1024 (the sampled points of an object are staged in LDS)", n_pts);
     if (n_obj == 0) return 0;
     ProfScope ps_("pack_objects", st);
-    hipLaunchKernelGGL(k_pack_objects, dim3((unsigned)((n_obj + 3) / 4)), dim3(256), 0, st, raw_xyz, raw_rgb, obj_ptr,
-                       sample_idx, rot, n_obj, n_pts, xyz, rgb, center, mean_rgb);
+    hipLaunchKernelGGL(k_pack_objects, dim3((unsigned)((n_obj + 3) / 4)), dim3(256), (size_t)4 * n_pts * 3 * sizeof(float), st, raw_xyz,
+                       raw_rgb, obj_ptr, sample_idx, rot, n_obj, n_pts, xyz, rgb, center, mean_rgb);
     T2P_CHECK_LAUNCH("pack_objects");
+    return 0;
+}
+
+int launch_pack_scene(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* obj_id, const uint64_t* key,
+                      const float* scene_center, const float* scene_color, int64_t n_out, int n_pts, float* xyz, float* rgb,
+                      float* center, float* mean_rgb, int32_t* idx_out, hipStream_t st) {
+    T2P_CHECK_ARG(n_pts <= 1024, "pack_scene_objects: n_pts=%d > 1024 (the sampled points of an object are staged in LDS)", n_pts);
+    if (n_out == 0) return 0;
+    ProfScope ps_("pack_scene", st);
+    hipLaunchKernelGGL(k_pack_scene, dim3((unsigned)((n_out + 3) / 4)), dim3(256), (size_t)4 * n_pts * 3 * sizeof(float), st, raw_xyz,
+                       raw_rgb, obj_ptr, obj_id, key, scene_center, scene_color, n_out, n_pts, xyz, rgb, center, mean_rgb, idx_out);
+    T2P_CHECK_LAUNCH("pack_scene");
     return 0;
 }
 

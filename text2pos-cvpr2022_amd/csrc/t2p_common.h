@@ -194,6 +194,9 @@ int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const fl
 int launch_pack_objects(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* sample_idx,
                         const float* rot, int64_t n_obj, int n_pts, float* xyz, float* rgb, float* center, float* mean_rgb,
                         hipStream_t st);
+int launch_pack_scene(const float* raw_xyz, const float* raw_rgb, const int32_t* obj_ptr, const int32_t* obj_id, const uint64_t* key,
+                      const float* scene_center, const float* scene_color, int64_t n_out, int n_pts, float* xyz, float* rgb,
+                      float* center, float* mean_rgb, int32_t* idx_out, hipStream_t st);
 int launch_pairwise_ranking(const float* scores, int batch, float margin, float* row_loss, float* d_scores, float* row_cnt,
                             hipStream_t st);
 int launch_hardest_ranking(const float* scores, int batch, float margin, float* best, int32_t* where, float* d_scores,

@@ -123,6 +123,53 @@ class FixedPoints:
         return data
 
 
+# ---- counter-based T.FixedPoints draw (shared with csrc/small_kernels.hip::k_pack_scene; include/t2p.h) ---------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_KEY_MUL = np.uint64(0xD6E8FEB86659FD93)
+
+
+def mix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser, vectorised with wrap-around arithmetic."""
+    with np.errstate(over="ignore"):
+        x = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return x ^ (x >> np.uint64(31))
+
+
+def sample_keys(seed: int, sample_index, slot) -> np.ndarray:
+    """uint64 key of object slot `slot` of sample (cell) `sample_index` under `seed` (arrays broadcast)."""
+    with np.errstate(over="ignore"):
+        k = mix64(np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF))
+        k = mix64(k ^ ((np.asarray(sample_index).astype(np.uint64) * _KEY_MUL) & _M64))
+        return mix64(k ^ ((np.asarray(slot).astype(np.uint64) * _KEY_MUL) & _M64))
+
+
+def keyed_draws(keys, sizes, n_pts: int) -> np.ndarray:
+    """The n_pts indices (with replacement) each key draws from an object of sizes[i] points: int64 [n, n_pts].
+    Point p of key k: ((mix64(k ^ p * 0xD6E8FEB86659FD93) >> 32) * m) >> 32 - the statement the pack kernel executes."""
+    keys = np.atleast_1d(np.asarray(keys, dtype=np.uint64))
+    m = np.atleast_1d(np.asarray(sizes)).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        r = mix64(keys[:, None] ^ ((np.arange(n_pts, dtype=np.uint64) * _KEY_MUL) & _M64)[None, :])
+        return (((r >> np.uint64(32)) * m[:, None]) >> np.uint64(32)).astype(np.int64)
+
+
+class KeyedFixedPoints:
+    """T.FixedPoints(num) whose draw is the counter-based one above: the k-th object this transform is applied to is slot k of
+    sample `sample_index` (batch_object_points applies a cell's transform to its objects in order)."""
+
+    def __init__(self, num: int, seed: int, sample_index: int):
+        self.num, self.seed, self.sample_index, self.slot = num, seed, sample_index, 0
+
+    def __call__(self, data):
+        key = sample_keys(self.seed, self.sample_index, self.slot)
+        self.slot += 1
+        choice = torch.from_numpy(keyed_draws(key, data.pos.shape[0], self.num)[0])
+        data.x, data.pos = data.x[choice], data.pos[choice]
+        return data
+
+
 class NormalizeScale:
     def __call__(self, data):
         data.pos = data.pos - data.pos.mean(dim=-2, keepdim=True)
@@ -172,10 +219,12 @@ class HostStaging:
             self.sets[which][name] = buf
         return buf[:numel]
 
-    def mark_copied(self, which: int, stream=None):
+    def mark_copied(self, which: int, device=None, stream=None):
+        """Records the end of the host-to-device copies out of set `which` - on the current stream of the device the copies
+        went to (t.to(device, non_blocking=True) runs there, which need not be the current device)."""
         if torch.cuda.is_available():
             ev = torch.cuda.Event()
-            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            ev.record(stream if stream is not None else torch.cuda.current_stream(device))
             self.events[which] = ev
 
 
@@ -185,9 +234,12 @@ class ObjectMeansCache:
     at 10-20 us per object is 20x the GPU time of the cell.  Keyed by the identity of the cell's object list; an entry keeps the
     list and its objects alive and is used only while the list still holds the very same objects.  The point arrays of an
     Object3d are treated as immutable, as the reference's dataset classes treat them (augmentation happens on the PyG batches):
-    call clear() after editing `obj.xyz` / `obj.rgb` in place.  Bounded (least recently inserted entries leave first)."""
+    call clear() after editing `obj.xyz` / `obj.rgb` in place.  Bounded (least recently inserted entries leave first; 16,384
+    cells by default: a KITTI360Pose evaluation database).  The models consult it in eval() mode only: the reference's TRAINING
+    loaders hand over fresh lists every step (deep copies under flip_poses, dataloading/kitti360pose/utils.py:32-33; unpickled
+    batches from DataLoader workers), which could never hit and would only be kept alive here."""
 
-    def __init__(self, max_cells: int = 1 << 17):
+    def __init__(self, max_cells: int = 1 << 14):
         self.max_cells = max_cells
         self.d = {}
 
@@ -282,18 +334,28 @@ def _means_from_sums(sums, abs_sums, rows, arrays_of):
     return out
 
 
-def object_means_many(cells, cache: ObjectMeansCache = None, threads: int = 8):
+def host_threads(cap: int = 32) -> int:
+    """Worker threads of the C helper: the cores this process may run on, at most `cap` (the pool's size)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(int(cap), n))
+
+
+def object_means_many(cells, cache: ObjectMeansCache = None, threads: int = None):
     """object_means for a list of cells in ONE pass of the C helper (cells that are not in the cache: the first epoch, or
-    evaluation.pipeline's single pass over the database).  Returns a list of (centre [n, 3], colour [n, 3]) fp32 pairs."""
+    evaluation.pipeline's single pass over the database): one walk of the object list for `.xyz` and `.rgb` together, the sums on
+    the helper's persistent thread pool.  Returns a list of (centre [n, 3], colour [n, 3]) fp32 pairs."""
     ext = host_ext()
     if ext is None or not cells or not all(type(objs) is list and _plain_objects(objs) for objs in cells):
         return [object_means(objs, cache) for objs in cells]
     n = sum(len(objs) for objs in cells)
     sums, asums = np.empty((2, n, 3), dtype=np.float64), np.empty((2, n, 3), dtype=np.float64)
     rows = np.empty((2, n), dtype=np.int64)
-    for k, attr in enumerate(("xyz", "rgb")):
-        if ext.column_sums(cells, attr, sums[k], asums[k], rows[k], int(threads)) != n:
-            return [object_means(objs, cache) for objs in cells]    # some array is not float64 [m, 3]: the NumPy route decides
+    if ext.object_sums(cells, sums, asums, rows, int(threads or host_threads())) != n:
+        return [object_means(objs, cache) for objs in cells]    # some array is not float64 [m, 3]: the NumPy route decides
     flat = [o for objs in cells for o in objs]
     center = _means_from_sums(sums[0], asums[0], rows[0], lambda i: flat[i].xyz)
     color = _means_from_sums(sums[1], asums[1], rows[1], lambda i: flat[i].rgb)
@@ -325,7 +387,6 @@ def object_means(objs, cache: ObjectMeansCache = None):
     return center, color
 
 
-_EXPECT_BATCH = {}
 _CAT_POOL = None
 
 
@@ -356,14 +417,29 @@ def _cat_into(tensors, out: torch.Tensor, rows_per_item, threads: int = 4):
         j.result()
 
 
-def _check_batch_vector(pts, n: int, n_pts: int, i: int):
-    key = (n, n_pts)
-    expect = _EXPECT_BATCH.get(key)
-    if expect is None:
-        expect = _EXPECT_BATCH[key] = torch.arange(n).repeat_interleave(n_pts)
-    b = pts.batch
-    if b.shape[0] != n * n_pts or not torch.equal(b.cpu().long(), expect):
-        raise RuntimeError(f"encode_objects: cell {i}: batch vector is not {n} contiguous groups of {n_pts}")
+def _check_batch_vectors(object_points, counts, n_pts: int):
+    """Every cell's batch vector must be `n` contiguous groups of n_pts (Batch.from_data_list of n resampled objects,
+    dataloading/kitti360pose/utils.py:110): a permuted or interleaved vector would pair points with the wrong object without
+    changing any size.  ALL cells are checked, in three large tensor operations (the GIL is released inside them, so the check
+    runs beside the caller's concatenations): the vectors back to back, viewed as [objects, n_pts], must be constant along
+    each row and start with the object's index in its cell."""
+    sel = [i for i, p in enumerate(object_points) if p.batch is not None]
+    if not sel:
+        return
+    vecs = [object_points[i].batch for i in sel]
+    cnt = np.asarray(counts)[sel]
+    for i, b, n in zip(sel, vecs, cnt):
+        if b.dim() != 1 or b.shape[0] != int(n) * n_pts:
+            raise RuntimeError(f"encode_objects: cell {i}: batch vector is not {int(n)} contiguous groups of {n_pts}")
+    g = torch.cat(vecs).view(-1, n_pts)
+    start = np.zeros(len(sel), dtype=np.int64)
+    np.cumsum(cnt[:-1], out=start[1:])
+    local = torch.from_numpy(np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(start, cnt)).to(g.device)
+    bad = (g != local[:, None].to(g.dtype)).any(dim=1)
+    if bool(bad.any()):
+        o = int(torch.nonzero(bad)[0])
+        i = sel[int(np.searchsorted(start, o, side="right")) - 1]
+        raise RuntimeError(f"encode_objects: cell {i}: batch vector is not {int(counts[i])} contiguous groups of {n_pts}")
 
 
 def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_color: bool = False,
@@ -374,7 +450,7 @@ def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_co
     point batches are concatenated straight into `staging`'s pinned buffers (one pass over the bytes, no per-call pinned
     allocation) and copied asynchronously; batches that already live on the device are concatenated there.
     skip_rgb: return rgb = None (the caller zeroes the colours on the device: models/object_encoder.py:86-90).
-    The batch vectors of at most 8 evenly spaced cells are verified element by element, all cells by size."""
+    Every cell's batch vector is verified (on the packing pool, beside the concatenations)."""
     if len(objects) != len(object_points):
         raise RuntimeError(f"encode_objects: {len(objects)} object lists but {len(object_points)} point batches")
     n_cells = len(objects)
@@ -390,10 +466,7 @@ def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_co
         i = int(np.flatnonzero(n_rows != counts * n_pts)[0])
         raise RuntimeError(f"encode_objects: cell {i} has {counts[i]} objects but {n_rows[i]} points; every object "
                            f"must be resampled to {n_pts} points (T.FixedPoints({n_pts}))")
-    step = max(1, n_cells // 8)
-    for i in range(0, n_cells, step):
-        if object_points[i].batch is not None:
-            _check_batch_vector(object_points[i], int(counts[i]), n_pts, i)
+    checking = _pack_pool().submit(_check_batch_vectors, object_points, counts, n_pts) if n_cells else None
     want_rgb = not (skip_rgb or zero_color)
     on_device = n_cells > 0 and pos_list[0].is_cuda
     pin = torch.cuda.is_available()
@@ -448,11 +521,13 @@ def pack_cells(objects: List[List[Object3d]], object_points, n_pts: int, zero_co
         np.concatenate([r[0] for r in rows], axis=0, out=small_np[0])
         np.concatenate([r[1] for r in rows], axis=0, out=small_np[1])
     center, mean_rgb = small[0], small[1]
+    if checking is not None:
+        checking.result()      # (raises here what the check found)
     if device is not None:
         to = lambda t: None if t is None else t.to(device, non_blocking=True)
         xyz, rgb, center, mean_rgb = to(xyz), to(rgb), to(center), to(mean_rgb)
         if staging is not None and which is not None:
-            staging.mark_copied(which)
+            staging.mark_copied(which, device)
     return xyz, rgb, center, mean_rgb, cell_ptr
 
 

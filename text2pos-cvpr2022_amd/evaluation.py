@@ -103,14 +103,31 @@ def create_hint_description(pose) -> List[str]:
     return [f"The pose is {d.direction} of a {d.object_color_text} {d.object_label}." for d in pose.descriptions]
 
 
+def positions_in_cell(center_xy: np.ndarray, matches0: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+    """get_pos_in_cell (models/superglue_matcher.py:139-161) for a batch: center_xy [B, n_obj, 2] object centres, matches0
+    [B, n_obj] (hint index or -1), offsets [B, n_hints, 2] -> [B, 2]: mean over the matched objects of centre + offset of
+    the matched hint; (0.5, 0.5) where nothing matched."""
+    m0 = np.asarray(matches0)
+    mask = m0 >= 0
+    idx = np.broadcast_to(np.clip(m0, 0, None)[:, :, None], m0.shape + (2,))
+    pred = np.asarray(center_xy, dtype=np.float64) + np.take_along_axis(np.asarray(offsets, dtype=np.float64), idx, axis=1)
+    cnt = mask.sum(axis=1)
+    tot = (pred * mask[:, :, None]).sum(axis=1)
+    return np.where(cnt[:, None] > 0, tot / np.maximum(cnt, 1)[:, None], 0.5)
+
+
 def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Sequence[str]], transform, pad_size: int,
-             top_k, threshs, queries_per_call: int = 64, group=None):
+             top_k, threshs, queries_per_call: int = 64, group=None, scene_dev=None):
     """Fine localisation of every query against its max(top_k) retrieved cells (evaluation/pipeline.py:172-279).
     `model(objects, hints, object_points)` is SuperGlueMatch (or anything returning .matches0 [B, pad] / .offsets
     [B, hints, 2]); unlike the reference, which calls the model once per query (10 samples), `queries_per_call` queries
     share a call.  Returns (accuracies_mean, accuracies_offset, accuracies_mean_conf).
     With an initialised torch.distributed process group the queries are split over the ranks in contiguous blocks
-    (samples are independent) and the per-query estimates are all-gathered: every rank returns the same tables."""
+    (samples are independent) and the per-query estimates are all-gathered: every rank returns the same tables.
+    scene_dev (scene.DeviceScene holding every cell of `retrievals` and >= pad_size padding objects) + a counter-based
+    transform (pipeline.PerCellTransform) + a model with forward_packed: the samples are packed on the GPU straight from the
+    resident scene (sample q * kmax + c draws what `transform.for_cell(q * kmax + c)` draws on the host), a query's hints are
+    encoded once for all its candidates, and the pose estimates are computed for a whole call at once."""
     from . import distributed as TD
     from .data import Object3d, batch_object_points
     from .superglue_matcher import get_pos_in_cell
@@ -132,7 +149,38 @@ def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Seque
     pos_mean = np.zeros((nq, kmax, 2))
     pos_off = np.zeros((nq, kmax, 2))
     conf = np.zeros((nq, kmax), dtype=np.int64)
-    for q0 in range(q_lo, q_hi, queries_per_call):
+    on_dev = scene_dev is not None and hasattr(transform, "keys") and hasattr(model, "forward_packed")
+    if on_dev:
+        ids_of_cell = scene_dev.padded_object_ids(pad_size)                                  # [n_cells, pad]
+        cell_rows = np.array([[scene_dev.row_of[cid] for cid in r] for r in retrievals], dtype=np.int64).reshape(nq, kmax)
+        class_all, color_all = scene_dev.feature_indices(model)
+        want_rgb = "color" in model.args.use_features or bool(getattr(model.args, "class_embed", False))
+        per_call = max(int(queries_per_call), 256)          # 256 queries x kmax candidates x pad objects fill the GPU
+        slot = np.arange(pad_size, dtype=np.int64)
+        for q0 in range(q_lo, q_hi, per_call):
+            q1 = min(q0 + per_call, q_hi)
+            nb = (q1 - q0) * kmax
+            ids = ids_of_cell[cell_rows[q0:q1].reshape(-1)]                                  # [nb, pad]
+            sample = (np.arange(q0, q1, dtype=np.int64)[:, None] * kmax + np.arange(kmax, dtype=np.int64)[None, :]).reshape(-1)
+            keys = transform.keys(sample[:, None], slot[None, :])
+            xyz, rgb, center, mean_rgb = scene_dev.pack(ids.reshape(-1), keys.reshape(-1), transform.n_pts, want_rgb=want_rgb)
+            if rgb is None:
+                rgb = torch.zeros_like(xyz)
+            hint_enc = model.encode_hints([create_hint_description(poses[q]) for q in range(q0, q1)])
+            hint_enc = hint_enc.repeat_interleave(kmax, dim=0)
+            ci = co = None
+            if class_all is not None or color_all is not None:
+                flat_ids = torch.from_numpy(ids.reshape(-1)).to(scene_dev.device)
+                ci = None if class_all is None else class_all[flat_ids].contiguous()
+                co = None if color_all is None else color_all[flat_ids].contiguous()
+            cp = np.arange(nb + 1, dtype=np.int32) * pad_size
+            out = model.forward_packed(xyz, rgb, center, mean_rgb, cp, hint_enc, ci, co)
+            m0, off = out.matches0.cpu().numpy(), out.offsets.cpu().numpy()
+            cxy = scene_dev.center64[ids][:, :, 0:2]
+            pos_mean[q0:q1] = positions_in_cell(cxy, m0, np.zeros_like(off)).reshape(q1 - q0, kmax, 2)
+            pos_off[q0:q1] = positions_in_cell(cxy, m0, off).reshape(q1 - q0, kmax, 2)
+            conf[q0:q1] = (m0 >= 0).sum(axis=1).reshape(q1 - q0, kmax)
+    for q0 in (range(q_lo, q_hi, queries_per_call) if not on_dev else ()):
         q1 = min(q0 + queries_per_call, q_hi)
         objects, hints, points = [], [], []
         for q in range(q0, q1):

@@ -440,6 +440,36 @@ def pack_objects(raw_xyz, raw_rgb, obj_ptr, sample_idx, rot=None):
     return xyz, rgb, center, mean_rgb
 
 
+def pack_scene_objects(raw_xyz, raw_rgb, obj_ptr, obj_id, key, scene_center, scene_color, n_pts: int = 256, want_rgb: bool = True,
+                       want_idx: bool = False):
+    """The dataloader of a scene resident in HBM (t2p_pack_scene_objects, include/t2p.h): output slot s = scene object
+    obj_id[s] (int32 [n_out]) resampled to n_pts points by the counter-based draw of key[s] (int64 / uint64 bit pattern
+    [n_out]), NormalizeScale'd bit for bit like the host chain; centre / mean colour gathered from the scene's tables.
+    Returns (xyz, rgb | None, center, mean_rgb[, sample_idx])."""
+    _need(raw_xyz, "raw_xyz", torch.float32, 2)
+    dev = raw_xyz.device
+    _need(raw_rgb, "raw_rgb", torch.float32, 2, dev)
+    _need(obj_ptr, "obj_ptr", torch.int32, 1, dev)
+    _need(obj_id, "obj_id", torch.int32, 1, dev)
+    _need(key, "key", torch.int64, 1, dev)
+    _need(scene_center, "scene_center", torch.float32, 2, dev)
+    _need(scene_color, "scene_color", torch.float32, 2, dev)
+    n_out = obj_id.shape[0]
+    if key.shape[0] != n_out or tuple(raw_rgb.shape) != tuple(raw_xyz.shape) or raw_xyz.shape[1] != 3 or \
+            scene_center.shape[0] != obj_ptr.shape[0] - 1 or tuple(scene_color.shape) != tuple(scene_center.shape):
+        raise RuntimeError("pack_scene_objects: inconsistent shapes")
+    xyz = torch.empty((n_out, n_pts, 3), dtype=torch.float32, device=dev)
+    rgb = torch.empty((n_out, n_pts, 3), dtype=torch.float32, device=dev) if want_rgb else None
+    center = torch.empty((n_out, 3), dtype=torch.float32, device=dev)
+    mean_rgb = torch.empty((n_out, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((n_out, n_pts), dtype=torch.int32, device=dev) if want_idx else None
+    L.check(L.lib().t2p_pack_scene_objects(_ptr(raw_xyz), _ptr(raw_rgb), _ptr(obj_ptr), _ptr(obj_id), _ptr(key), _ptr(scene_center),
+                                           _ptr(scene_color), n_out, n_pts, _ptr(xyz), _ptr(rgb) if want_rgb else None,
+                                           _ptr(center), _ptr(mean_rgb), _ptr(idx) if want_idx else None, _stream(dev)),
+            "t2p_pack_scene_objects")
+    return (xyz, rgb, center, mean_rgb, idx) if want_idx else (xyz, rgb, center, mean_rgb)
+
+
 def make_match_weights(packed: Dict[str, object]) -> L.MatchWeights:
     """packed: packing.pack_match_weights(...)"""
     w = L.MatchWeights()

@@ -31,8 +31,10 @@ def default_transform(n_pts: int = 256, seed: Optional[int] = None):
 
 
 class PerCellTransform:
-    """FixedPoints + NormalizeScale whose random draw depends on (seed, global cell index) only, so that a cell gets the same
-    256 points whichever rank encodes it: the sharded pipeline then reproduces the single-process result bit for bit.
+    """FixedPoints + NormalizeScale whose random draw depends on (seed, global cell index, object slot) only - a counter-based
+    hash (data.sample_keys / data.keyed_draws), not a sequential generator - so that a cell gets the same 256 points whichever
+    rank, batch or device packs it: the sharded pipeline reproduces the single-process result bit for bit, and the on-device
+    dataloader (scene.DeviceScene, csrc/small_kernels.hip::k_pack_scene) draws exactly what `for_cell`'s host chain draws.
     (`default_transform` keeps one sequential generator, like the reference's dataloader; its draws depend on the order in
     which a process walks the cells.)"""
 
@@ -40,12 +42,26 @@ class PerCellTransform:
         self.n_pts, self.seed = n_pts, seed
 
     def for_cell(self, cell_index: int):
-        return default_transform(self.n_pts, self.seed * 1_000_003 + cell_index)
+        """The host chain for one cell / sample (applied to its objects in order)."""
+        return D.Compose([D.KeyedFixedPoints(self.n_pts, self.seed, cell_index), D.NormalizeScale()])
+
+    def keys(self, sample_index, slot) -> np.ndarray:
+        """uint64 sampling keys of (sample, slot) pairs (arrays broadcast): the `key` argument of t2p_pack_scene_objects."""
+        return D.sample_keys(self.seed, sample_index, slot)
+
+
+def on_device_input(model, transform) -> bool:
+    """True when the input side can run on the GPU: a counter-based per-cell transform (PerCellTransform) and a model with
+    the scene entry points on a GPU.  Anything else (a sequential generator like default_transform, an arbitrary callable,
+    the gloo tests' stand-in models) takes the reference's host chain."""
+    dev = getattr(model, "device", None)
+    return hasattr(transform, "keys") and hasattr(transform, "n_pts") and dev is not None and torch.device(dev).type == "cuda" and \
+        (hasattr(model, "encode_scene_cells") or hasattr(model, "forward_packed"))
 
 
 @torch.no_grad()
 def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], threshs: Sequence[int], cells_per_call: int = 512,
-               texts_per_call: int = 1024, group=None, topk_fn=None):
+               texts_per_call: int = 1024, group=None, topk_fn=None, scene_dev=None, timings: Optional[dict] = None):
     """Encode every cell and every query, rank in float64, report hit@k / close-by@k and recall within the thresholds
     when the retrieved cell's centre is the estimate.  Returns (retrievals, accuracies dict).
 
@@ -54,16 +70,29 @@ def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], thresh
     all-gather exchanges the cell embeddings, every rank ranks its query block against the full database, and the [Nq, k]
     index lists are gathered, so every rank returns the same tables; without a process group it is the single-GPU path
     (BASELINE configs[4]; evaluation/pipeline.py:60-137).
-    cells_per_call: the reference's loader hands over 64 cells per batch (evaluation/pipeline.py:303-308); cells are
-    independent, so the batch size does not change a bit of the result, and 64 cells (about a thousand objects) fill a
-    third of the GPU: 512 by default.  The host-side transform of every object (FixedPoints + NormalizeScale in NumPy)
-    is what bounds this loop either way; model.encode_raw_objects runs that chain on the GPU.
-    topk_fn(queries, cells, k): the ranking kernel (default retrieval.retrieve_topk; the gloo CPU test injects the oracle's)."""
+    Input side: with a PerCellTransform and the product model the cells' raw objects are uploaded once (scene.DeviceScene;
+    `scene_dev` = one that already holds the WHOLE scene, else this rank's block is built here) and every cell is resampled,
+    normalised and encoded on the GPU (model.encode_scene_cells) - the same packed inputs, bit for bit, as the host chain
+    `transform.for_cell(i)` + encode_objects, which remains the path of every other transform / model (cells_per_call cells per
+    call there: the reference's loader hands over 64, evaluation/pipeline.py:303-308; cells are independent).
+    topk_fn(queries, cells, k): the ranking kernel (default retrieval.retrieve_topk; the gloo CPU test injects the oracle's).
+    timings: optional dict that receives the wall time of the upload (`scene_s`)."""
+    import time
     from . import distributed as TD
     cells, poses = scenes.all_cells, scenes.all_poses
     texts = scenes.texts
+    on_dev = (scene_dev is not None or on_device_input(model, transform)) and hasattr(model, "encode_scene_cells")
 
     def encode_cells(lo, hi):
+        if on_dev:
+            if scene_dev is not None:
+                return model.encode_scene_cells(scene_dev, transform, lo, hi)
+            from .scene import DeviceScene
+            t0 = time.perf_counter()
+            block = DeviceScene(cells[lo:hi], model.device)
+            if timings is not None:
+                timings["scene_s"] = time.perf_counter() - t0
+            return model.encode_scene_cells(block, transform, 0, hi - lo, cell_offset=lo)
         enc = []
         for a in range(lo, hi, cells_per_call):
             b = min(a + cells_per_call, hi)
@@ -96,15 +125,30 @@ def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], thresh
 
 @torch.no_grad()
 def evaluate(model_coarse, model_fine, scenes: IO.Scenes, transform, top_k=(1, 5, 10), threshs=(5, 10, 15), pad_size=16,
-             queries_per_call: int = 64, group=None, topk_fn=None) -> Dict[str, object]:
+             queries_per_call: int = 64, group=None, topk_fn=None, timings: Optional[dict] = None) -> Dict[str, object]:
     """Coarse retrieval + fine localisation.  `group`: torch.distributed process group (None = the default group when one
-    is initialised, else single GPU); every rank returns the same tables."""
-    retrievals, out = run_coarse(model_coarse, scenes, transform, top_k, threshs, group=group, topk_fn=topk_fn)
+    is initialised, else single GPU); every rank returns the same tables.
+    With a PerCellTransform and the product models the whole scene is uploaded once (scene.DeviceScene, with the fine stage's
+    padding objects) and serves both stages: the coarse stage resamples and encodes its cells from it, the fine stage packs its
+    (query, candidate cell) samples from it - no per-object host work after the upload.
+    timings: optional dict that receives wall times (`scene_s` upload, `coarse_s`, `fine_s`)."""
+    import time
+    scene_dev = None
+    t0 = time.perf_counter()
+    if on_device_input(model_coarse, transform) and hasattr(model_coarse, "encode_scene_cells"):
+        from .scene import DeviceScene
+        fine_on_dev = model_fine is not None and on_device_input(model_fine, transform) and hasattr(model_fine, "forward_packed")
+        scene_dev = DeviceScene(scenes.all_cells, model_coarse.device, n_pad=pad_size if fine_on_dev else 0)
+    t1 = time.perf_counter()
+    retrievals, out = run_coarse(model_coarse, scenes, transform, top_k, threshs, group=group, topk_fn=topk_fn, scene_dev=scene_dev)
     out["retrievals"] = retrievals
+    t2 = time.perf_counter()
     if model_fine is not None:
         mean, off, conf = E.run_fine(model_fine, scenes.all_poses, scenes.cells_dict, retrievals, transform, pad_size,
-                                     list(top_k), list(threshs), queries_per_call, group=group)
+                                     list(top_k), list(threshs), queries_per_call, group=group, scene_dev=scene_dev)
         out.update(fine_mean=mean, fine_offset=off, fine_mean_conf=conf)
+    if timings is not None:
+        timings.update(scene_s=t1 - t0, coarse_s=t2 - t1, fine_s=time.perf_counter() - t2)
     return out
 
 

@@ -147,13 +147,19 @@ class SuperGlueMatch(nn.Module):
         """Device-resident packed objects (see CellRetrievalNetwork.encode_objects_packed); every sample must hold the
         same number of objects (the dataset pads to args.pad_size, dataloading/kitti360pose/eval.py:147-149) and the
         same number of hints.  hints: List[List[str]], or pre-tokenised (tokens int32 [B * num_hints, T],
-        lengths int32 [B * num_hints]) device tensors (modules.tokenize) to keep the host out of the call."""
+        lengths int32 [B * num_hints]) device tensors (modules.tokenize) to keep the host out of the call, or the hint
+        encodings themselves ([B, num_hints, D] fp32 from encode_hints: a query's sentences are encoded once although it is
+        matched against every one of its retrieved cells)."""
         self._check_forward_only()
         cp = np.ascontiguousarray(np.asarray(cell_ptr), dtype=np.int32)
         b = cp.shape[0] - 1
         sizes = cp[1:] - cp[:-1]
+        encoded = isinstance(hints, torch.Tensor)
         tokenised = isinstance(hints, tuple)
-        if tokenised:
+        if encoded:
+            if hints.dim() != 3 or hints.shape[0] != b or hints.shape[2] != self.embed_dim:
+                raise RuntimeError("SuperGlueMatch: hint encodings must be [samples, hints, embed_dim]")
+        elif tokenised:
             if hints[0].shape[0] % b != 0:
                 raise RuntimeError("SuperGlueMatch: token rows must be a multiple of the number of samples")
         elif len(hints) != b or any(len(h) != len(hints[0]) for h in hints):
@@ -162,7 +168,7 @@ class SuperGlueMatch(nn.Module):
             raise RuntimeError("SuperGlueMatch: samples must agree in their number of objects and of hints "
                                "(torch.stack / reshape in models/superglue_matcher.py:94-102 need it too)")
         n_obj, d = int(sizes[0]), self.embed_dim
-        n_hints = hints[0].shape[0] // b if tokenised else len(hints[0])
+        n_hints = hints.shape[1] if encoded else (hints[0].shape[0] // b if tokenised else len(hints[0]))
         a = self.args
         if bool(getattr(a, "class_embed", False)) != (class_idx is not None) or \
                 bool(getattr(a, "color_embed", False)) != (color_idx is not None):
@@ -185,7 +191,9 @@ class SuperGlueMatch(nn.Module):
             self._side = torch.cuda.Stream(device=dev)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            if tokenised:
+            if encoded:
+                hint = hints.contiguous()
+            elif tokenised:
                 hint = self.language_encoder.encode_tokens(hints[0], hints[1], normalize=True).view(b, n_hints, d)
             else:
                 flat = [s for h in hints for s in h]
@@ -201,6 +209,14 @@ class SuperGlueMatch(nn.Module):
         return MatchOutputs(P=out["P"], matches0=out["matches0"], matches1=out["matches1"], offsets=out["offsets"],
                             matching_scores0=out["matching_scores0"], matching_scores1=out["matching_scores1"],
                             object_encodings=obj, hint_encodings=hint)
+
+    def encode_hints(self, hints: List[List[str]]) -> torch.Tensor:
+        """List[List[str]] (samples x num_hints sentences) -> [samples, num_hints, D] L2-normalised hint encodings
+        (models/superglue_matcher.py:94-97)."""
+        if any(len(h) != len(hints[0]) for h in hints):
+            raise RuntimeError("SuperGlueMatch: every sample needs the same number of hints")
+        flat = [s for h in hints for s in h]
+        return self.language_encoder(flat, normalize=True).view(len(hints), len(hints[0]), self.embed_dim)
 
     def forward(self, objects, hints, object_points):
         """objects: List[List[Object3d]] (B samples x pad_size objects), hints: List[List[str]] (B x num_hints),
