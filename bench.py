@@ -333,6 +333,86 @@ def executed_flops(e, e1_dedup, n_obj, n_cells, knn_edges, sa1_per_edge=True):
             "total": sa2 + tables + ga + heads + graph}
 
 
+def self_launch_command(n_gpus, argv, port=None):
+    """The command `python bench.py --gpus N` turns itself into when it is NOT already running under a launcher: one process
+    per GPU on this node through torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from it), rendezvous on
+    127.0.0.1 (the container's hostname may not resolve).  Returns (argv list, environment additions)."""
+    if port is None:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--self-launch"]
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),   # dmabuf IPC: RCCL needs it on this driver
+           "T2P_BENCH_LAUNCHED": "self"}
+    return cmd, env
+
+
+def needs_self_launch(n_gpus, force=False, environ=None):
+    """True when this process must start the ranks itself: --gpus N > 1 (or the --self-launch test hook) and no launcher's
+    environment (torch.distributed.run exports RANK and WORLD_SIZE to every rank)."""
+    environ = os.environ if environ is None else environ
+    under_launcher = "RANK" in environ and "WORLD_SIZE" in environ
+    return (n_gpus > 1 or force) and not under_launcher
+
+
+def pipeline_rates(model, torch, n_cells=2048, n_poses=1024, top_k=(1, 5, 10), pad=16):
+    """BASELINE configs[4]'s shape on one GPU, end to end from RAW Python scenes: `pipeline.evaluate` (evaluation/pipeline.py:
+    282-342: every cell of the database through the dataloader chain + the coarse model, every query through the text branch,
+    float64 ranking, then every (query, top-10 cell) pair through the dataloader chain + SuperGlueMatch, accuracy tables) over a
+    synthetic scene of Object3d cells with raw float64 points (m ~ U{30..400} per object, 6..19 objects per cell) and 6-hint
+    poses.  The input side runs on the GPU (scene.DeviceScene + t2p_pack_scene_objects); the wall times include the one pass over
+    the raw points on the host (conversion + exact means), the upload, and the metric tables.  Random-init fine model.  Never `value`."""
+    import text2pos_amd as t2p
+    from text2pos_amd import data as D, io as IO, pipeline as PL, synthetic as S
+    rng = np.random.default_rng(SEED + 5)
+    dirs = ["north", "south", "east", "west", "on-top"]
+    cells, poses = [], []
+    for i in range(n_cells):
+        objs = []
+        for j in range(int(rng.integers(6, 20))):
+            c = rng.random(3) * np.array([1.0, 1.0, 0.3])
+            n = int(rng.integers(30, 400))
+            col = np.clip(rng.random(3), 0, 1)
+            objs.append(D.Object3d(j, 1000 * i + j, c + 0.05 * rng.standard_normal((n, 3)),
+                                   np.clip(col + 0.05 * rng.standard_normal((n, 3)), 0, 1), S.LABELS[int(rng.integers(0, len(S.LABELS)))]))
+        x, y = 30.0 * (i % 64), 30.0 * (i // 64)
+        cells.append(D.Cell(i, "syn1", objs, 30.0, np.array([x, y, 0.0, x + 30.0, y + 30.0, 10.0])))
+    for q in range(n_poses):
+        c = cells[int(rng.integers(0, n_cells))]
+        descs = [D.DescriptionBestCell(dirs[int(rng.integers(0, 5))], o.get_color_text(), o.label, o.id, True)
+                 for o in [c.objects[int(k)] for k in rng.choice(len(c.objects), 6, replace=False)]]
+        poses.append(D.Pose(rng.random(3), c.bbox_w[0:3] + rng.random(3) * 30.0, c.id, "syn1", descs))
+    scenes = IO.Scenes(cells, poses)
+    torch.manual_seed(4321)
+    fine = t2p.SuperGlueMatch(S.LABELS + ["pad"], S.COLOR_NAMES, S.known_words(),
+                              PL._model_args(128, num_layers=6, sinkhorn_iters=50)).to(model.device).eval()
+    tf = PL.PerCellTransform(256, 5)
+    raw_points = int(sum(len(o.xyz) for c in cells for o in c.objects))
+    out = {"cells": n_cells, "poses": n_poses, "objects": int(sum(len(c.objects) for c in cells)), "raw_points": raw_points,
+           "top_k": list(top_k), "pad_size": pad, "fine_model": "SuperGlueMatch embed_dim 128, 6 x (self, cross), 50 Sinkhorn iterations, random init"}
+    passes = []
+    for rep in range(3):
+        tm = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = PL.evaluate(model, fine, scenes, tf, top_k, (5, 10, 15), pad, timings=tm)
+        torch.cuda.synchronize()
+        tm["wall_s"] = time.perf_counter() - t0
+        passes.append({k: round(v, 4) for k, v in tm.items()})
+    best = min(passes[1:], key=lambda t: t["wall_s"])
+    out["first_pass"] = passes[0]
+    out["later_pass"] = best
+    out["e2e_cells_per_s"] = n_cells / (best["scene_s"] + best["coarse_s"])
+    out["e2e_queries_per_s"] = n_poses / best["wall_s"]
+    out["first_pass_queries_per_s"] = n_poses / passes[0]["wall_s"]
+    out["note"] = ("e2e_cells_per_s = cells / (host pass over the raw points + upload + on-device resampling + encoding + ranking + "
+                   "coarse tables); e2e_queries_per_s = poses / wall of the whole evaluate() (coarse + fine + tables).  first_pass also "
+                   "pays the allocator's first workspaces.  hit@k is meaningless with random weights and is not reported.")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,7 +453,19 @@ def main():
                     help="N = 1: no process group, no collective (the plain single-GPU path of distributed.sharded_retrieval)")
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="arithmetic of the MFMA-heavy layers: f16x3 split-precision (default) or exact fp32 MFMA")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks through torch.distributed.run even at --gpus 1 (what --gpus N > 1 does by itself when "
+                         "it is not already running under a launcher; test hook)")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end evaluate() measurement from raw scenes")
     args = ap.parse_args()
+
+    if needs_self_launch(args.gpus, args.self_launch):
+        # `python bench.py --gpus N`: this process becomes the launcher; rank 0's JSON line is the last line of the ranks'
+        # stdout (inherited), and the exit code is the launcher's (non-zero when any rank failed)
+        import subprocess
+        cmd, env_add = self_launch_command(args.gpus, sys.argv[1:])
+        log("self-launch: " + " ".join(cmd))
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, **env_add)))
 
     import torch
     import torch.distributed as dist
@@ -768,6 +860,8 @@ def main():
                                   "algorithmic FLOP, so its ceiling on this metric is peak/3 = 833 TFLOP/s"
                                   if args.precision == "f16x3" else "exact fp32 MFMA path")},
             "host_generation_s": round(gen_s, 2),
+            "launched": ("self: python bench.py --gpus N re-executed under torch.distributed.run" if os.environ.get("T2P_BENCH_LAUNCHED") == "self"
+                         else ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "plain process")),
             "fp16_range_guard": "clear" if args.precision == "f16x3" else "n/a (fp32)",
         }
         if exchange_error:
@@ -781,6 +875,9 @@ def main():
         if not args.no_dropin and world == 1 and args.cell_variant == "ragged":
             log("drop-in caller shape: encode_objects(objects, object_points) at batch 64 / 512")
             out["dropin"] = dropin_rates(model, S, torch)
+        if not args.no_pipeline and world == 1 and args.cell_variant == "ragged":
+            log("pipeline: evaluate() end to end from raw Object3d scenes (configs[4] shape, 2,048 cells / 1,024 poses)")
+            out["pipeline"] = pipeline_rates(model, torch)
         if not args.no_extras and world == 1 and args.cell_variant == "ragged":
             # report-only measurements, all outside the timed region: on-box peaks, SURVEY 8(d)'s two other cell shapes
             # (the cost is per object, so objects/s is the comparable figure), the fine stage (BASELINE configs[3])

@@ -787,6 +787,32 @@ def test_bench_exchange_runs_through_rccl_at_world_size_one():
     assert line["n_gpus"] == 1 and line["value"] > 0
 
 
+def test_bench_starts_its_own_ranks_from_the_plain_command():
+    """`python bench.py --gpus N` - the form the driver uses - with no launcher around it: bench.py re-executes itself under
+    torch.distributed.run (one rank per GPU), rank 0 prints the ONE JSON line last, the exit code is the launcher's.  On the one
+    GPU there is, --self-launch forces that route at N = 1; the line carries the RCCL exchange block and says how it started."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--self-launch", "--steps", "2", "--warmup", "1", "--cells", "768",
+           "--queries", "128", "--no-cpu-baseline", "--no-extras", "--no-dropin", "--no-fp32-pass", "--no-pipeline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "self-launch:" in r.stderr and "torch.distributed.run" in r.stderr
+    last = [l for l in r.stdout.splitlines() if l.strip()][-1]
+    line = json.loads(last)                                    # the JSON line is the LAST line of stdout
+    assert line["launched"].startswith("self") and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["exchange"]["backend"] == "nccl" and line["exchange"]["world_size"] == 1
+    # a rank that dies makes the plain command exit non-zero (here: an argument the ranks reject)
+    bad = subprocess.run(cmd[:2] + ["--gpus", "1", "--self-launch", "--cells", "0", "--steps", "1"], cwd=root, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert bad.returncode != 0
+
+
 def test_all_gather_rows_on_device_tensors_through_rccl():
     """distributed.all_gather_rows / sharded_retrieval with the "nccl" backend (RCCL) in a one-rank group, in this process:
     device tensors in, device tensors out, the forced collective returns the rows unchanged and t2p_sim_topk ranks them."""

@@ -738,3 +738,43 @@ def test_every_cells_batch_vector_is_checked():
     points[5].batch = points[5].batch[:-1]
     with pytest.raises(RuntimeError, match="cell 5: batch vector"):
         D.pack_cells(objects, points, 256)
+
+
+# ---- bench.py launch form ----------------------------------------------------------------------------------------------
+def test_bench_self_launch_argv_and_conditions():
+    """`python bench.py --gpus N` (the driver's command form) starts its own ranks: the re-exec argv / environment, and when it
+    happens (N > 1 or --self-launch, and no launcher environment).  The launched ranks then see RANK / WORLD_SIZE and run."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd, env = bench.self_launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "3", "--self-launch"], port=29555)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "3"]          # same arguments, minus the hook
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["T2P_BENCH_LAUNCHED"] == "self"
+    port = int(bench.self_launch_command(2, [])[0][bench.self_launch_command(2, [])[0].index("--master-port") + 1])
+    assert 1024 < port < 65536
+    assert bench.needs_self_launch(8, environ={}) and bench.needs_self_launch(2, environ={"WORLD_SIZE": "1"})
+    assert not bench.needs_self_launch(1, environ={})
+    assert bench.needs_self_launch(1, force=True, environ={})
+    assert not bench.needs_self_launch(8, environ={"RANK": "3", "WORLD_SIZE": "8"})       # already under a launcher
+    assert not bench.needs_self_launch(1, force=True, environ={"RANK": "0", "WORLD_SIZE": "1"})
+
+
+def test_bench_plain_multi_gpu_command_launches_ranks_and_propagates_failure():
+    """End to end on this GPU-less container: `python bench.py --gpus 2` re-executes under torch.distributed.run, the ranks
+    start (rank 0 logs its generation step), fail at the first GPU call, and the plain command exits non-zero with no JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cells", "4",
+                        "--queries", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0
+        return
+    assert r.returncode != 0
+    assert "self-launch:" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert "generated " in r.stderr, r.stderr[-2000:]           # the ranks came up and did their host-side work (rank 0 logs it)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
