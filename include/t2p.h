@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2P_ABI_VERSION 26
+#define T2P_ABI_VERSION 27
 #define T2P_DEFAULT_CHUNK_OBJECTS 65000 /* t2p_cell_config.chunk_objects == 0 */
 #define T2P_MAX_CHUNK_OBJECTS 65535     /* 32-bit table offsets / 16-bit local indices: chunk_objects and the largest single
                                            cell may not exceed it (T2P_E_ARG otherwise).  The caller-provided workspace holds
@@ -174,7 +174,9 @@ typedef struct t2p_cell_config {
      * sticky OR of a non-zero code whenever a conversion site of the call may have left fp16's range (bits 0-2: SA level
      * 1-3 edge inputs, judged by max|A_l| + max|B_l|; bit 3: SA output rows split by the dense table kernels; bit 4: GA
      * hidden planes, judged by a norm bound; bit 5: rows of the LDS-tiled GEMMs; bit 6: a NaN among the input points / colours -
-     * the float-max aggregation of the f16x3 kernels would drop it where the reference's scatter-max propagates it).  The tests are conservative: they may
+     * the float-max aggregation of the f16x3 kernels would drop it where the reference's scatter-max propagates it; bit 7: LOW side - the
+     * largest hidden activation or the largest output of an SA level is below 2^-7, where the fp16 pieces keep an absolute 2^-25
+     * instead of a relative 2^-22 and a later BatchNorm that rescales would expose the loss).  The tests are conservative: they may
      * fire for a checkpoint that would just have fitted, never the other way round.  The caller clears it, reads it after the stream has drained, and must
      * not trust the call's output when it is set (the Python host raises or re-runs with precision = 0).  NULL: no check. */
     int32_t* overflow_flag;
@@ -328,6 +330,11 @@ int t2p_sim_topk(const float* queries, const float* cells, int64_t nq, int64_t n
  * ---------------------------------------------------------------------------------------------------------- */
 void t2p_profile_enable(int on);
 int t2p_profile_report(char* buf, size_t buf_bytes);
+/* Measurement hook for the per-kernel energy table (profiles/energy_table.py): from now on every launch the report above
+ * lists under `scope` (the ten largest kernels of the cell branch have the hook) is issued `reps` times back to back with
+ * the same arguments - each of them rewrites its outputs from its inputs, so results do not change - which holds ONE kernel
+ * on the chip long enough for a power sampler.  reps <= 1 or scope == NULL: off (the default). */
+void t2p_profile_repeat(const char* scope, int32_t reps);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Training-mode text branch (first part): one step of the LSTM recurrence of

@@ -332,6 +332,102 @@ def test_f16x3_activation_overflow_is_caught(oracle_model, vocab):
     assert (got_w.cpu() - want_w).abs().max().item() < TOL
 
 
+def test_overflow_guard_fires_through_every_entry_point(oracle_model, vocab):
+    """The overflow -> raise / fp32-recompute logic lives in ONE helper (CellRetrievalNetwork._with_guard); every entry point
+    goes through it.  With the hot checkpoint: the multi-stream path (2,048 cells: the product default from that size up), the
+    pinned-host block pipeline, encode_objects' two pipelined halves (256 cells of Python objects) and the scene path each
+    raise under on_overflow="raise" and return exactly the fp32 model's result under on_overflow="fp32"."""
+    import text2pos_amd as t2p
+    from text2pos_amd import data as D, pipeline as PL, synthetic as S
+    from text2pos_amd.scene import DeviceScene
+
+    def build(**kw):
+        m = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(), **kw)
+        m.load_state_dict(_hot_checkpoint(oracle_model, 3.0e5), strict=True)
+        return m.to(_dev()).eval()
+    raising, redoing, exact = build(), build(on_overflow="fp32"), build(precision="fp32")
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(93, 2048)
+    dargs = _to_dev(xyz, rgb, center, mean_rgb)
+    n256 = int(cell_ptr[256])
+    objects, points = [], []
+    for c in range(256):
+        lo, hi = int(cell_ptr[c]), int(cell_ptr[c + 1])
+        objs = [D.Object3d(i, i, xyz[i].astype(np.float64), rgb[i].astype(np.float64), "box") for i in range(lo, hi)]
+        objects.append(objs)
+        points.append(D.Batch.from_data_list([D.Data(x=torch.from_numpy(rgb[i]), pos=torch.from_numpy(xyz[i])) for i in range(lo, hi)]))
+    cells = [D.Cell(c, "s", objs, 30.0, np.arange(6.0)) for c, objs in enumerate(objects)]
+    tf = PL.PerCellTransform(256, 1)
+    host = [torch.from_numpy(a[:n256]).pin_memory() for a in (xyz, rgb, center, mean_rgb)]
+    entries = {
+        "multi-stream (2,048 cells)": lambda m: m.encode_objects_packed(*dargs, cell_ptr),
+        "single stream": lambda m: m.encode_objects_packed(*[t[:n256] for t in dargs], cell_ptr[:257], streams=1),
+        "pinned-host blocks": lambda m: m.encode_objects_packed_host(*host, cell_ptr[:257], cells_per_chunk=100),
+        "encode_objects, two halves": lambda m: m.encode_objects(objects, points),
+        "scene path": lambda m: m.encode_scene_cells(DeviceScene(cells, _dev()), tf, cells_per_call=100),
+    }
+    with torch.no_grad():
+        for name, call in entries.items():
+            with pytest.raises(FloatingPointError, match="0x"):
+                call(raising)
+            assert raising.overflow_detected() == 0, name                      # the check consumed the sticky word
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                redo = call(redoing)
+            assert any("recomputing" in str(x.message) for x in w), name
+            assert redoing.precision == "f16x3", name                          # switched back after the recompute
+            assert torch.equal(redo, call(exact)), name
+
+
+def _cold_checkpoint(oracle_model, s):
+    """The golden weights with SA3's hidden layer scaled DOWN by s and the scale taken back behind it: BatchNorm 1's weight and
+    bias x s (the hidden activations relu(.) shrink by s), Linear 2's bias and BatchNorm 2's running mean x s, BatchNorm 2's weight
+    / s.  Mathematically the same network; its SA3 hidden activations are s times smaller."""
+    import copy
+    sd = copy.deepcopy(oracle_model.state_dict())
+    nn_ = "object_encoder.pointnet.sa3.point_conv.local_nn."
+    for k in (nn_ + "0.1.weight", nn_ + "0.1.bias", nn_ + "1.0.bias", nn_ + "1.1.running_mean"):
+        sd[k] = sd[k] * s
+    sd[nn_ + "1.1.weight"] = sd[nn_ + "1.1.weight"] / s
+    return sd
+
+
+def test_f16x3_cold_activations_are_caught(oracle_model, vocab):
+    """LOW side of the fp16-range guard.  A checkpoint whose SA3 hidden activations sit 1e-5 below their usual scale (and whose
+    next BatchNorm takes the factor back): the fp16 pieces of such activations fall into fp16's subnormals - the hi piece keeps
+    a few bits, the lo piece underflows - and the following rescale would expose the loss.  The guard's bit 7 (an SA level's
+    largest hidden activation / output below 2^-7) must fire: raise, or recompute on the exact fp32 path, which meets the oracle.
+    A merely cool checkpoint (x 1/16) passes the guard and still meets the oracle at 1e-4 on the f16x3 path."""
+    import text2pos_amd as t2p
+    from oracle import model as OM
+    from text2pos_amd import synthetic as S
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(91, 6)
+    dargs = _to_dev(xyz, rgb, center, mean_rgb)
+
+    def build(sd, **kw):
+        m = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(), **kw)
+        m.load_state_dict(sd, strict=True)
+        return m.to(_dev()).eval()
+    om = OM.OracleCellRetrieval(vocab["classes"], vocab["colors"], vocab["words"], OM.default_args()).eval()
+    cold = _cold_checkpoint(oracle_model, 1.0e-5)
+    om.load_state_dict(cold, strict=True)
+    want = om.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)
+    base = oracle_model.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)
+    assert (want - base).abs().max().item() < 1e-5            # the same network as the golden one, in fp32
+    with torch.no_grad():
+        with pytest.raises(FloatingPointError, match="0x80"):
+            build(cold).encode_objects_packed(*dargs, cell_ptr)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            redo = build(cold, on_overflow="fp32").encode_objects_packed(*dargs, cell_ptr)
+        assert any("fp32" in str(x.message) for x in w)
+        assert torch.equal(redo, build(cold, precision="fp32").encode_objects_packed(*dargs, cell_ptr))
+        assert (redo.cpu() - want).abs().max().item() < TOL
+        cool = _cold_checkpoint(oracle_model, 1.0 / 16.0)
+        om.load_state_dict(cool, strict=True)
+        got = build(cool).encode_objects_packed(*dargs, cell_ptr)            # guard silent
+        assert (got.cpu() - om.encode_objects_packed(xyz, rgb, center, mean_rgb, cell_ptr)).abs().max().item() < TOL
+
+
 def test_f16x3_weight_out_of_range_is_refused(oracle_model, vocab):
     """A folded weight past fp16's range cannot enter the f16x3 images: packing raises and names precision="fp32"."""
     import copy

@@ -465,7 +465,8 @@ def test_scene_path_encodes_like_the_host_path(hip_model):
         assert torch.equal(hip_model.encode_objects_packed(xyz, rgb, center, mean_rgb, cp), want)
         assert hip_model.encode_scene_cells(sc, tf, 5, 5).shape == (0, 256)
     m = t2p.CellRetrievalNetwork(S.LABELS + ["pad"], S.COLOR_NAMES, S.known_words(), S.default_args(use_features=["class", "position"]))
-    m.load_state_dict({k: v for k, v in hip_model.state_dict().items() if k in m.state_dict()}, strict=False)
+    own = m.state_dict()      # (the merge layer's input width depends on the feature set: keep its own initialisation)
+    m.load_state_dict({k: v for k, v in hip_model.state_dict().items() if k in own and own[k].shape == v.shape}, strict=False)
     m = m.to(_dev()).eval()
     with torch.no_grad():
         assert torch.equal(m.encode_scene_cells(sc, tf), m.encode_objects(objs, pts))

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2P_LIB") or os.path.join(_HERE, "libt2p_hip.so")  # T2P_LIB: A/B builds of the same ABI
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p
@@ -108,6 +108,7 @@ SYMBOLS = {
                             c_void]),
     "t2p_profile_enable": (None, [C.c_int]),
     "t2p_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "t2p_profile_repeat": (None, [C.c_char_p, C.c_int32]),
     "t2p_sample_group": (C.c_int, [c_void, C.c_int64, C.c_int32, c_float_p, C.POINTER(c_void), C.POINTER(c_void),
                                    C.POINTER(c_void), c_void]),
     "t2p_group_rows": (C.c_int, [c_void, C.c_int64, C.c_int32, c_float_p, C.c_int32, C.POINTER(c_void), C.POINTER(c_void),

@@ -73,7 +73,11 @@ static volatile bool g_prof_on = false;
 static ProfRec g_prof[8192];
 static int g_prof_n = 0;
 
-ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), st(s) {
+static char g_repeat_name[64] = {0};
+static volatile int g_repeat_n = 1;
+
+ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), st(s), reps(1) {
+    if (g_repeat_n > 1 && strncmp(name, g_repeat_name, sizeof(g_repeat_name)) == 0) reps = g_repeat_n;
     if (!g_prof_on) return;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess) return;
@@ -538,6 +542,17 @@ int t2p_abi_version(void) { return T2P_ABI_VERSION; }
 void t2p_profile_enable(int on) {
     std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof_on = on != 0;
+}
+
+// Measurement hook (profiles/energy_table.py): launches recorded under `scope` are issued `reps` times back to back.
+void t2p_profile_repeat(const char* scope, int reps) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_repeat_n = 1;
+    if (scope != nullptr && reps > 1) {
+        strncpy(g_repeat_name, scope, sizeof(g_repeat_name) - 1);
+        g_repeat_name[sizeof(g_repeat_name) - 1] = 0;
+        g_repeat_n = reps;
+    }
 }
 
 // Waits for the recorded launches, writes one line per kernel name: "<name> <launches> <total_ms>\n", clears.

@@ -161,7 +161,7 @@ int launch_ga2(const WsParams& p_in, hipStream_t st) {
     if (streams > p.n_groups) streams = p.n_groups;
     if (streams >= 8) streams -= streams % 8;
     ProfScope ps_("ws_groupmax_k512_n1024", st);
-    hipLaunchKernelGGL(k_ga2, dim3((unsigned)(streams * n_slices)), dim3(NT), kLds, st, p, n_slices);
+    T2P_REPEAT(ps_) hipLaunchKernelGGL(k_ga2, dim3((unsigned)(streams * n_slices)), dim3(NT), kLds, st, p, n_slices);
     T2P_CHECK_LAUNCH("ga2");
     return 0;
 }

@@ -449,7 +449,7 @@ int launch_sa3(const SaParams& p, hipStream_t st) {
     int tr, n_wg;
     T2P_TRY(sa3_launch_shape(p.n_obj, &tr, &n_wg));
     ProfScope ps_("ws_edge_sa_k256_n256", st);
-    hipLaunchKernelGGL(k_sa3, dim3(n_wg), dim3(NT), LDS_BYTES, st, p);
+    T2P_REPEAT(ps_) hipLaunchKernelGGL(k_sa3, dim3(n_wg), dim3(NT), LDS_BYTES, st, p);
     T2P_CHECK_LAUNCH("sa3");
     return 0;
 }

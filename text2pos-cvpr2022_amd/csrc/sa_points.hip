@@ -484,7 +484,7 @@ int launch_sa_points(int H, int Cout, const SaParams& p, hipStream_t st) {
     sa_points_launch_shape(p.n_obj, &tr, &n_wg);
     if (!p.balanced) T2P_TRY(launch_sa_balance(p, tr, n_wg, st));
     ProfScope ps_("ws_edge_sa_k32_n64", st);
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(C::NT), C::lds_bytes(), st, p);
+    T2P_REPEAT(ps_) hipLaunchKernelGGL(kern, dim3(n_wg), dim3(C::NT), C::lds_bytes(), st, p);
     T2P_CHECK_LAUNCH("sa_points");
     return 0;
 }

@@ -509,7 +509,7 @@ int launch_dedup_rows(const float* xyz, const float* rgb, int64_t n_obj, int n_p
     if (n_obj == 0) return 0;
     const int64_t grid = n_obj < (int64_t)num_cus() * 32 ? n_obj : (int64_t)num_cus() * 32;
     ProfScope ps_("dedup_rows", st);
-    hipLaunchKernelGGL(k_dedup_rows, dim3((unsigned)grid), dim3(64), 0, st, xyz, rgb, n_obj, rows, n_rows,
+    T2P_REPEAT(ps_) hipLaunchKernelGGL(k_dedup_rows, dim3((unsigned)grid), dim3(64), 0, st, xyz, rgb, n_obj, rows, n_rows,
                        n_cent * (kMaxNbr + 1));
     T2P_CHECK_LAUNCH("dedup_rows");
     return 0;
@@ -539,7 +539,7 @@ int launch_sample_group(const float* xyz, int64_t n_obj, int n_pts, const float 
     const bool fast = n_pts == kMaxPts && !want_nbr && gt.rows[0] && gt.rows[1] && gt.rows[2] &&
                       gt.n_dense[0] == kMaxPts && gt.n_dense[1] == kMaxPts / 2 && gt.n_dense[2] == kMaxPts / 4;
     if (fast)
-        hipLaunchKernelGGL(k_sample_group<true>, dim3((unsigned)grid), dim3(64), lds, st, xyz, n_obj, n_pts, radius[0],
+        T2P_REPEAT(ps_) hipLaunchKernelGGL(k_sample_group<true>, dim3((unsigned)grid), dim3(64), lds, st, xyz, n_obj, n_pts, radius[0],
                            radius[1], radius[2], gt);
     else
         hipLaunchKernelGGL(k_sample_group<false>, dim3((unsigned)grid), dim3(64), lds, st, xyz, n_obj, n_pts, radius[0],

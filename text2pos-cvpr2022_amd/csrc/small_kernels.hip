@@ -489,7 +489,8 @@ __global__ void k_cell_index(const int32_t* __restrict__ cell_ptr, int n_cells, 
 
 // fp16-range verdict of one chunk (t2p_common.h GuardSlot): bit 0..2 = SA level l may have staged relu(A_j - B_i) past
 // fp16's largest finite value, bit 3 = an SA output row (split by the next dense kernel) did, bit 4 = the GA hidden planes
-// may have (bound ||W1||_1 max(F_3, 1) + max|b1|), bit 5 = a row of the LDS-tiled GEMMs did, bit 6 = NaN in the input points / colours
+// may have (bound ||W1||_1 max(F_3, 1) + max|b1|), bit 5 = a row of the LDS-tiled GEMMs did, bit 6 = NaN in the input points / colours,
+// bit 7 = an SA level's hidden activations or outputs are all below kGuardTiny (too small for the fp16 pieces)
 __global__ void k_guard_check(const uint32_t* __restrict__ guard, int32_t* flag, GuardBounds gb) {
     if (threadIdx.x != 0) return;
     const float lim = 65504.f;
@@ -504,6 +505,11 @@ __global__ void k_guard_check(const uint32_t* __restrict__ guard, int32_t* flag,
         const float b = gb.wp_l1[l] * in_max;
         if (!(a + b < lim)) code |= 1 << l;   // also catches inf patterns
         if (!(__uint_as_float(guard[G_F1 + l]) < lim)) code |= 8;
+        // low side (bit 7): every hidden activation relu(A_j - B_i) of the level is below kGuardTiny (a_lo: exact maximum of
+        // the point table at levels 1 and 2, the input bound at level 0), or the level's whole OUTPUT is (exact maximum)
+        const float a_lo = l == 0 ? a : __uint_as_float(guard[l == 1 ? G_A2 : G_A3]);
+        const float f_lo = __uint_as_float(guard[G_F1 + l]);
+        if ((a_lo + b > 0.f && a_lo + b < kGuardTiny) || (f_lo > 0.f && f_lo < kGuardTiny)) code |= 128;
     }
     if (!(fmaxf(__uint_as_float(guard[G_F3]), 1.f) * gb.ga1_l1 + gb.ga1_bmax < lim)) code |= 16;
     if (!(__uint_as_float(guard[G_GEMM_IN]) < lim)) code |= 32;

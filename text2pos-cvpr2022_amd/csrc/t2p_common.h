@@ -91,6 +91,10 @@ struct GuardBounds {   // host-side norms of the folded weights (packing.py), pa
 // Magnitudes below kGuardFloor are never published (no atomic traffic in the normal case: activations of a trained,
 // batch-normalised network are O(1..100)); k_guard_check counts an unpublished word as kGuardFloor.
 constexpr float kGuardFloor = 16384.f;
+// Low side: fp16 pieces hi = fp16(v), lo = fp16(v - hi) carry an ABSOLUTE error of ~2^-25 (fp16's subnormal spacing) once
+// |v| < 2^-3; harmless while a layer's largest activations are O(1), but a layer whose LARGEST magnitude is below 2^-7 keeps
+// fewer than ~18 bits of its own scale (and below 2^-14 the hi piece itself goes subnormal).  k_guard_check sets bit 7 then.
+constexpr float kGuardTiny = 0.0078125f;
 #ifdef __HIPCC__
 // m >= 0 (a magnitude; NaN compares false everywhere and is caught by the table producers' own inputs); at most one
 // atomic per wavefront, and only when some lane saw a magnitude at or above the floor
@@ -119,6 +123,19 @@ __device__ __forceinline__ void guard_publish_bits_above(uint32_t* slot, uint32_
     }
     if ((threadIdx.x & 63) == 0) atomicMax(slot, bits);
 }
+// Exact running maximum without a floor, for sites that report once per wave (or rarely): the wave's maximum goes to the slot
+// only when it exceeds what the slot already holds (a relaxed load first: after the first few waves almost no atomic is left).
+// The exact maxima also serve the LOW side of the guard (k_guard_check: a level whose largest magnitude is below kGuardTiny
+// would put the hi pieces of its activations into fp16's subnormals and lose the lo pieces altogether).
+__device__ __forceinline__ void guard_publish_exact(uint32_t* slot, float m) {
+    if (slot == nullptr) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t b = __float_as_uint(m);
+        if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+    }
+}
 // Exact form for the persistent SA kernels: `acc` is a wave-uniform bit pattern (an SGPR) that lives across the whole
 // launch; guard_flush publishes it once per wave at the end (no floor, no contention: ~2 k atomics per launch).
 __device__ __forceinline__ void guard_track_bits(uint32_t& acc, int lane_bits /* pattern of a non-negative float */) {
@@ -140,7 +157,11 @@ struct ProfScope {
     int slot;
     hipStream_t st;
     void* ev_end;  // hipEvent_t recorded by the destructor
+    int reps;      // 1, or t2p_profile_repeat's count for this scope: the launch sites of the large kernels issue their launch
+                   // `reps` times back to back (same arguments: every one of them rewrites its outputs from its inputs), which
+                   // is how profiles/energy_table.py holds ONE kernel on the chip for seconds under the power sampler
 };
+#define T2P_REPEAT(ps) for (int rep_ = (ps).reps; rep_ > 0; --rep_)
 
 // ---- sample_group.hip -------------------------------------------------------------------------------------
 // Compact per-object group tables produced by the fused FPS + ball-query kernel.

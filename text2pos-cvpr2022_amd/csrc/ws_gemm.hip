@@ -293,6 +293,8 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
             stage_write(0);
         }
         __syncthreads();
+        float gmax_all = 0.f;   // largest magnitude this thread stored over the whole launch (f16x3 table kernels only)
+        (void)gmax_all;
         for (int i = 0; g < p.n_groups; g += n_streams, i++) {
             const int64_t gn = g + n_streams;
             const int n_rows = rows_of(g);
@@ -355,10 +357,12 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
             };
             if (n_rows == C::TR) epilogue(std::true_type{});
             else epilogue(std::false_type{});
-            if constexpr (X3 && MODE == WS_DENSE_STORE && SPLIT_IO != 2) guard_publish(p.amax_out, gmax_out);
+            if constexpr (X3 && MODE == WS_DENSE_STORE && SPLIT_IO != 2) gmax_all = fmaxf(gmax_all, gmax_out);
             if (gn < p.n_groups) stage_write((i + 1) & 1);
             __syncthreads();
         }
+        // the table's exact largest magnitude, once per wave (high AND low side of the guard)
+        if constexpr (X3 && MODE == WS_DENSE_STORE && SPLIT_IO != 2) guard_publish_exact(p.amax_out, gmax_all);
     } else {
         // ---- kNN edge stream: a group = 32 destination objects, rows = their valid neighbours ----------------------
         for (int64_t g = stream; g < p.n_groups; g += n_streams) {
@@ -487,7 +491,7 @@ int launch_cfg(const WsParams& p_in, int n_slices, hipStream_t st) {
     static char name[64];
     if (name[0] == 0) snprintf(name, sizeof(name), "ws_%s_k%d_n%d", kMode[MODE], K, NW * n_slices);
     ProfScope ps_(name, st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTH), C::lds_bytes(), st, p, n_slices);
+    T2P_REPEAT(ps_) hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTH), C::lds_bytes(), st, p, n_slices);
     T2P_CHECK_LAUNCH("ws_gemm");
     return 0;
 }

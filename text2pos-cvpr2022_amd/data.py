@@ -335,12 +335,28 @@ def _means_from_sums(sums, abs_sums, rows, arrays_of):
 
 
 def host_threads(cap: int = 32) -> int:
-    """Worker threads of the C helper: the cores this process may run on, at most `cap` (the pool's size)."""
+    """Worker threads of the C helper: the CPUs this process may USE, at most `cap` (the pool's size) - the smaller of its
+    affinity mask and its cgroup CPU quota (a container on a 256-thread host is typically granted a fraction of it; threads
+    beyond the quota only add wake-ups and throttling)."""
     import os
     try:
         n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError, IndexError):
+            pass
+    try:    # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, q // p))
+    except (OSError, ValueError):
+        pass
     return max(1, min(int(cap), n))
 
 
@@ -431,6 +447,15 @@ def _check_batch_vectors(object_points, counts, n_pts: int):
     for i, b, n in zip(sel, vecs, cnt):
         if b.dim() != 1 or b.shape[0] != int(n) * n_pts:
             raise RuntimeError(f"encode_objects: cell {i}: batch vector is not {int(n)} contiguous groups of {n_pts}")
+    ext = host_ext()
+    if ext is not None and all(b.dtype is torch.int64 and not b.is_cuda and b.is_contiguous() for b in vecs):
+        # one pass in C over the vectors where they lie (GIL released; `vecs` keeps them alive)
+        ptrs = np.fromiter((b.data_ptr() for b in vecs), dtype=np.int64, count=len(vecs))
+        bad = ext.check_groups(ptrs, np.ascontiguousarray(cnt, dtype=np.int64), int(n_pts), 2)
+        if bad >= 0:
+            i = sel[bad]
+            raise RuntimeError(f"encode_objects: cell {i}: batch vector is not {int(counts[i])} contiguous groups of {n_pts}")
+        return
     g = torch.cat(vecs).view(-1, n_pts)
     start = np.zeros(len(sel), dtype=np.int64)
     np.cumsum(cnt[:-1], out=start[1:])

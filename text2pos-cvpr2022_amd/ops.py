@@ -660,6 +660,12 @@ def profile_enable(on: bool):
     L.lib().t2p_profile_enable(int(bool(on)))
 
 
+def profile_repeat(scope: Optional[str], reps: int = 1):
+    """Measurement hook (t2p_profile_repeat): launches reported under `scope` are issued `reps` times back to back (same
+    arguments, same results) - profiles/energy_table.py holds one kernel on the chip for seconds that way.  None / 1: off."""
+    L.lib().t2p_profile_repeat(scope.encode() if scope else None, int(reps))
+
+
 def profile_report() -> Dict[str, tuple]:
     """{kernel name: (launches, total_ms)} of the launches recorded since the last report; waits for them."""
     buf = C.create_string_buffer(1 << 16)
