@@ -472,6 +472,78 @@ def test_scene_path_encodes_like_the_host_path(hip_model):
         assert torch.equal(m.encode_scene_cells(sc, tf), m.encode_objects(objs, pts))
 
 
+def test_scene_path_with_embedding_ablations(vocab, oracle_model):
+    """--class_embed / --color_embed (models/object_encoder.py:74-84) through the scene path: the per-object class / colour
+    index tables are built once per scene and sliced per block; same embeddings as encode_objects, bit for bit."""
+    import text2pos_amd as t2p
+    from text2pos_amd import data as D, pipeline as PL, synthetic as S
+    from text2pos_amd.scene import DeviceScene
+    cells = _raw_scene(24, 17)
+    tf = PL.PerCellTransform(256, 2)
+    objs = [c.objects for c in cells]
+    pts = [D.batch_object_points(o, tf.for_cell(i)) for i, o in enumerate(objs)]
+    for kw in (dict(class_embed=True), dict(color_embed=True), dict(class_embed=True, color_embed=True)):
+        torch.manual_seed(3)
+        m = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(**kw)).to(_dev()).eval()
+        sc = DeviceScene(cells, _dev())
+        with torch.no_grad():
+            want = m.encode_objects(objs, pts)
+            assert torch.equal(m.encode_scene_cells(sc, tf), want), kw
+            assert torch.equal(m.encode_scene_cells(sc, tf, 3, 20, cells_per_call=5), want[3:20]), kw
+
+
+def test_run_fine_device_path_equals_host_path(vocab, fine_pair_gpu):
+    """evaluation.run_fine with a DeviceScene (samples packed on the GPU, hints encoded once per query, poses computed per call)
+    against the same function on the host chain (one Python transform per object, models/superglue_matcher.py:139-161 per sample):
+    on a scene whose cells all hold >= pad_size objects (no padding objects, which the two paths draw separately) the three accuracy
+    tables are equal and every sample's matches / offsets are bit-identical."""
+    from text2pos_amd import data as D, evaluation as E, pipeline as PL, synthetic as S
+    from text2pos_amd.scene import DeviceScene
+    prod, _ = fine_pair_gpu
+    rng = np.random.default_rng(4)
+    pad, kmax = 6, 3
+    cells, poses = [], []
+    for i in range(12):
+        objs = []
+        for j in range(int(rng.integers(pad, pad + 5))):
+            m = int(rng.integers(30, 300))
+            objs.append(D.Object3d(j, 100 * i + j, rng.random(3) * np.array([1.0, 1.0, 0.3]) + 0.05 * rng.standard_normal((m, 3)),
+                                   np.clip(rng.random(3) + 0.05 * rng.standard_normal((m, 3)), 0, 1), S.LABELS[int(rng.integers(0, len(S.LABELS)))]))
+        x = 30.0 * i
+        cells.append(D.Cell(i, "f", objs, 30.0, np.array([x, 0.0, 0.0, x + 30.0, 30.0, 10.0])))
+    dirs = ["north", "south", "east", "west", "on-top"]
+    for q in range(20):
+        c = cells[int(rng.integers(0, 12))]
+        descs = [D.DescriptionBestCell(dirs[int(rng.integers(0, 5))], o.get_color_text(), o.label, o.id, True)
+                 for o in [c.objects[int(k)] for k in rng.choice(len(c.objects), 6, replace=False)]]
+        poses.append(D.Pose(rng.random(3), c.bbox_w[0:3] + rng.random(3) * 30.0, c.id, "f", descs))
+    cells_dict = {c.id: c for c in cells}
+    retr = [[cells[int(k)].id for k in rng.choice(12, kmax, replace=False)] for _ in poses]
+    tf = PL.PerCellTransform(256, 8)
+    seen = {"dev": [], "host": []}
+
+    class Spy(torch.nn.Module):
+        device = _dev()
+        args, object_encoder, encode_hints = prod.args, prod.object_encoder, prod.encode_hints
+
+        def forward_packed(self, *a, **k):
+            out = prod.forward_packed(*a, **k)
+            seen["dev"].append((out.matches0.cpu(), out.offsets.cpu(), out.P.cpu()))
+            return out
+
+        def forward(self, objects, hints, points):
+            out = prod(objects, hints, points)
+            seen["host"].append((out.matches0.cpu(), out.offsets.cpu(), out.P.cpu()))
+            return out
+    dev_tables = E.run_fine(Spy(), poses, cells_dict, retr, tf, pad, [1, kmax], [5, 10, 15], scene_dev=DeviceScene(cells, _dev(), n_pad=pad))
+    host_tables = E.run_fine(Spy(), poses, cells_dict, retr, tf, pad, [1, kmax], [5, 10, 15], queries_per_call=7)
+    assert len(seen["dev"]) == 1 and len(seen["host"]) == 3
+    for k in range(3):
+        assert torch.equal(seen["dev"][0][k], torch.cat([h[k] for h in seen["host"]])), ("matches0", "offsets", "P")[k]
+    assert dev_tables == host_tables
+    assert (seen["dev"][0][0] >= 0).any()
+
+
 def test_pack_objects_matches_host_transform_chain(hip_model, oracle_model):
     """On-device FixedPoints gather + NormalizeScale + means == the host chain of dataloading/kitti360pose/utils.py:99-109
     (restated in oracle/pyg_restated.py) given the same draw; and the raw-object entry point encodes like the packed one."""
