@@ -24,9 +24,6 @@
 #ifndef T2P_SA3_ABL
 #define T2P_SA3_ABL 0
 #endif
-#ifndef T2P_SA3_PKSUB
-#define T2P_SA3_PKSUB 1      // relu(A_j - B_i): the subtraction as two v_pk_add_f32 per staged row instead of four v_sub_f32
-#endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define AS4 __attribute__((address_space(4)))
 
@@ -242,15 +239,9 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
             ph.y = __float_as_uint(sa[k][1]) ^ __float_as_uint(bq[1]);
             vv = sa[k];
         } else {
-#if T2P_SA3_PKSUB
-            const t2p_f32x2 t01 = pk_sub_f32(t2p_f32x2{sa[k][0], sa[k][1]}, t2p_f32x2{bq[0], bq[1]});
-            const t2p_f32x2 t23 = pk_sub_f32(t2p_f32x2{sa[k][2], sa[k][3]}, t2p_f32x2{bq[2], bq[3]});
-            vv = f32x4{relu_f32(t01[0]), relu_f32(t01[1]), relu_f32(t23[0]), relu_f32(t23[1])};
-#else
             const f32x4 t = sa[k] - bq;
 #pragma unroll
             for (int e = 0; e < 4; e++) vv[e] = fmaxf(t[e], 0.f);
-#endif
             vh01 = cvt_pk_f16(vv[0], vv[1]);
             vh23 = cvt_pk_f16(vv[2], vv[3]);
             ph.x = __builtin_bit_cast(uint32_t, vh01);

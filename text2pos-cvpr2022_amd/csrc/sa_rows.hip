@@ -27,9 +27,6 @@
 #define T2P_RABL 0
 #endif
 #include "t2p_common.h"
-#ifndef T2P_ROWS_PKSUB
-#define T2P_ROWS_PKSUB 1     // relu(A_j - B_i): one v_pk_add_f32 per value pair instead of two v_sub_f32
-#endif
 
 namespace t2p {
 int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st);  // ws_sa.hip
@@ -357,14 +354,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                 // first half v = relu(x - b), second half hi = fp16(v) to nearest, lo = fp16(v - hi)
                 auto prep_a = [&](int pr, const f32x4 (&x)[2], const f32x4 (&b)[2], float (&v)[2]) {
                     const int j = pr >> 1, e0 = (pr & 1) * 2;
-#if T2P_ROWS_PKSUB
-                    const t2p_f32x2 t = pk_sub_f32(t2p_f32x2{x[j][e0], x[j][e0 + 1]}, t2p_f32x2{b[j][e0], b[j][e0 + 1]});
-                    v[0] = relu_f32(t[0]);
-                    v[1] = relu_f32(t[1]);
-#else
                     v[0] = fmaxf(x[j][e0] - b[j][e0], 0.f);
                     v[1] = fmaxf(x[j][e0 + 1] - b[j][e0 + 1], 0.f);
-#endif
                 };
                 auto prep_b = [&](const float (&v)[2], uint32_t& wh, uint32_t& wl) {
                     const fp16x2 hh = cvt_pk_f16(v[0], v[1]);

@@ -57,24 +57,6 @@ __device__ __forceinline__ t2p_fp16x2 cvt_pk_f16(float a, float b) {
 #endif
 }
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-#ifdef __HIPCC__
-// a - b on two fp32 lanes in ONE VALU instruction (v_pk_add_f32 with the second operand negated: the same IEEE result as two
-// v_sub_f32).  The SA edge kernels' staging arithmetic relu(A_j - B_i) is issue-bound beside the MFMA stream; hipcc forms packed
-// multiplies / FMAs by itself but not this subtraction.
-typedef float t2p_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ t2p_f32x2 pk_sub_f32(t2p_f32x2 a, t2p_f32x2 b) {
-    t2p_f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// max(v, 0) in one instruction: fmaxf() on a value hipcc cannot prove canonical (an inline-asm result) costs a second,
-// canonicalising v_max_f32 v, v in front.  (NaN -> 0 like v_max_f32; the guard's input check catches NaNs before they get here.)
-__device__ __forceinline__ float relu_f32(float v) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
-#endif
 
 int num_cus();  // cached multiProcessorCount of the current device
 int matrix_wgs(); // workgroups of the persistent matrix kernels (= num_cus() unless T2P_MATRIX_WGS says otherwise)
