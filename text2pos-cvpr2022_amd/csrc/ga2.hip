@@ -13,6 +13,8 @@
 // Input: the activations of GA layer 1 as two fp16 planes (hi, lo) [M][512] (written by ws_gemm's split output).
 // Column slices of 128 of one row stream run on the same XCD (block b -> XCD b % 8) and share the rows through its L2.
 #include "t2p_common.h"
+// The products run on v_mfma_f32_16x16x32_f16 (four 16 x 16 blocks per wave and tile; round 5: 14.87-14.92 -> 14.78-14.82 ms per step
+// against v_mfma_f32_32x32x16_f16 in three interleaved A/B pairs - see sa3.hip for the operand layout).
 
 namespace t2p {
 namespace {
@@ -21,7 +23,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int K = 512, NW = 128, NT = 512;
 constexpr int KH = K / 2;            // k range of one wave
-constexpr int S16 = KH / 16;         // 16 MFMA k-steps per wave and tile
 constexpr int S16_FULL = K / 16;     // steps of the packed weight image
 constexpr int LDHH = K + 8;          // plane row stride in halves (16-byte pad: conflict-free ds_read_b128)
 constexpr int PLANE = 32 * LDHH;     // halves
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(NT, 2) void k_ga2(WsParams p, int n_slices) {
     float* xch = (float*)(tile + 2 * TILE_HALVES);    // [4][16][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave & 3, kh = wave >> 2, h = lane >> 5, l31 = lane & 31;
+    const int wn = wave & 3, kh = wave >> 2;
 
     // XCD-aware stream / slice mapping (same as ws_gemm.hip)
     const int lin = blockIdx.x, nblk = gridDim.x;
@@ -53,22 +54,26 @@ __global__ __launch_bounds__(NT, 2) void k_ga2(WsParams p, int n_slices) {
     }
     const int ncol0 = slice * NW + wn * 32;
 
-    // stationary weights: k = kh*256 + h*128 + s*8 .. +8 for lane half h at step s.  In the packed image
-    // (packing.py::pack_f16x3: [plane][n-tile][step][lane half][32 lanes][8 halves] with k = half*256 + step*8) that
-    // is entry (step = h*16 + s, half = kh).
-    half8 w_hi[S16], w_lo[S16];
+    // 16x16x32 operands: lane = 16 q + i holds k = kh*256 + 64 q + 8 s + e of step s (s < 8), column 16 cb + i of the wave's 32;
+    // packed image entry (step = 8 q + s, half = kh)
+    constexpr int S32 = KH / 32;
+    const int q16 = lane >> 4, i16 = lane & 15;
+    half8 w_hi[2][S32], w_lo[2][S32];
     {
         const uint4* wp = (const uint4*)p.W_x3;
         const int plane_u4 = (p.ldw / 32) * S16_FULL * 64;
 #pragma unroll
-        for (int s = 0; s < S16; s++) {
-            const int idx = (((ncol0 / 32) * S16_FULL + (h * 16 + s)) * 2 + kh) * 32 + l31;
-            const uint4 a = wp[idx], b = wp[plane_u4 + idx];
-            w_hi[s] = __builtin_bit_cast(half8, a);
-            w_lo[s] = __builtin_bit_cast(half8, b);
-        }
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+            for (int s = 0; s < S32; s++) {
+                const int idx = (((ncol0 / 32) * S16_FULL + (8 * q16 + s)) * 2 + kh) * 32 + 16 * cb + i16;
+                w_hi[cb][s] = __builtin_bit_cast(half8, wp[idx]);
+                w_lo[cb][s] = __builtin_bit_cast(half8, wp[plane_u4 + idx]);
+            }
     }
-    const float bias = p.bias ? p.bias[ncol0 + l31] : 0.f;
+    float bias2[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) bias2[cb] = p.bias ? p.bias[ncol0 + 16 * cb + i16] : 0.f;
 
     // The next tile travels HBM/L2 -> LDS directly (global_load_lds_dwordx4: one plane row = 1 KB = one wave instruction,
     // 8 per wave and tile; rows are padded, the 64 lanes of an instruction are not): no staging registers, no ds_write
@@ -96,53 +101,65 @@ __global__ __launch_bounds__(NT, 2) void k_ga2(WsParams p, int n_slices) {
         const int64_t gn = g + n_streams;
         const bool more = gn < p.n_groups;
 
-        f32x16 acc, accx;
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const f32x4v kZero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4v acc[4], accx[4];    // [2 rb + cb]: rows 16 rb + 4 q16 + v, column 16 cb + i16
+        const _Float16* hrow = tile + (i & 1) * TILE_HALVES + i16 * LDHH + kh * KH + q16 * 64;
+        half8 a_hi[2], a_lo[2];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            acc[e] = 0.f;
-            accx[e] = 0.f;
+        for (int rb = 0; rb < 2; rb++) {
+            a_hi[rb] = *(const half8*)(hrow + rb * 16 * LDHH);
+            a_lo[rb] = *(const half8*)(hrow + PLANE + rb * 16 * LDHH);
         }
-        const _Float16* hrow = tile + (i & 1) * TILE_HALVES + l31 * LDHH + kh * KH + h * (KH / 2);
-        half8 a_hi = *(const half8*)(hrow), a_lo = *(const half8*)(hrow + PLANE), n_hi = a_hi, n_lo = a_lo;
 #pragma unroll
-        for (int s = 0; s < S16; s++) {
+        for (int sl = 0; sl < 4 * S32; sl++) {
+            const int s = sl >> 2, b = sl & 3, rb = b >> 1, cb = b & 1;
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < S16) {
-                n_hi = *(const half8*)(hrow + (s + 1) * 8);
-                n_lo = *(const half8*)(hrow + PLANE + (s + 1) * 8);
+            // operands of the next step: row block 0 is idle while block 1 multiplies, and the other way round
+            if (s + 1 < S32 && b == 2) {
+                a_hi[0] = *(const half8*)(hrow + (s + 1) * 8);
+                a_lo[0] = *(const half8*)(hrow + PLANE + (s + 1) * 8);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, w_hi[s], acc, 0, 0, 0);
-            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, w_lo[s], accx, 0, 0, 0);
+            if (s > 0 && b == 0) {
+                a_hi[1] = *(const half8*)(hrow + 16 * LDHH + s * 8);
+                a_lo[1] = *(const half8*)(hrow + PLANE + 16 * LDHH + s * 8);
+            }
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[rb], w_hi[cb][s], s == 0 ? kZero4 : acc[b], 0, 0, 0);
+            accx[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[rb], w_lo[cb][s], s == 0 ? kZero4 : accx[b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            // one LDS-DMA piece of the next tile per k-step of the first half: issuing one costs the wave 60-180 cycles
-            // (all 8 at the top of the tile stall both waves of a SIMD at once: 15.4 ms instead of 14.9; spread over all
-            // 16 steps the last pieces land too late for the barrier: 15.9).  Without any tile loads: 12.1 ms; the MFMA
-            // loop and its barrier alone: 11.1 ms (9.5 ms of MFMA time at the sustained clock).
-            if (more && s < CHUNKS) dma_piece(gn, (i + 1) & 1, s);
+            // one LDS-DMA piece of the next tile per two slots of the first half (see the 32x32x16 form below)
+            if (more && (sl & 1) == 0 && (sl >> 1) < CHUNKS) dma_piece(gn, (i + 1) & 1, sl >> 1);
             __builtin_amdgcn_sched_barrier(0);
-            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, w_hi[s], accx, 0, 0, 0);
-            a_hi = n_hi;
-            a_lo = n_lo;
+            accx[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[rb], w_hi[cb][s], accx[b], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = fmaf(accx[e], 1.f / 2048.f, acc[e]);
-        // The two waves of a pair alternate as sender / finisher from tile to tile, so the wave that writes the
-        // (single) exchange area for tile i+1 is the one that read it for tile i: no second barrier, no second buffer.
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[b][v] = fmaf(accx[b][v], 1.f / 2048.f, acc[b][v]);
         float* x = xch + wn * (16 * 64) + lane;
         const bool sender = ((i & 1) != 0) == (kh == 0);
         if (sender) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) x[e * 64] = acc[e];
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) x[(4 * b + v) * 64] = acc[b][v];
         }
         __syncthreads();
         if (!sender) {
-            // partner's partial + bias, ReLU (= starting the max at 0), max over the 32 rows of the object
-            float m = 0.f;
+            // partner's partial + bias, ReLU (= starting the max at 0), max over the 32 rows of the object: per column block
+            // over its two row blocks x four rows in this lane, then over the four lane quarters
 #pragma unroll
-            for (int e = 0; e < 16; e++) m = fmaxf(m, (acc[e] + x[e * 64]) + bias);
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            if (h == 0) p.out[g * (int64_t)p.ldo + ncol0 + l31] = m;
+            for (int cb = 0; cb < 2; cb++) {
+                float m = 0.f;
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) m = fmaxf(m, (acc[2 * rb + cb][v] + x[(4 * (2 * rb + cb) + v) * 64]) + bias2[cb]);
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                if (q16 == 0) p.out[g * (int64_t)p.ldo + ncol0 + 16 * cb + i16] = m;
+            }
         }
     }
 }

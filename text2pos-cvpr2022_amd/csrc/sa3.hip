@@ -1,7 +1,7 @@
 // Set-abstraction level 3 edge kernel (K = N = 256), f16x3 path, SCALAR control.
 // (reference: gnn.PointConv(local_nn)(x, (pos, pos[idx]), edge_index), models/pointcloud/pointnet2.py:31-35).
 //
-// Data flow of ws_sa2.hip (one 8-wave workgroup per CU, wave w owns output columns [32 w, 32 w + 32) with its 256 x 32 weight
+// Data flow of ws_sa2.hip (rounds 1-3; one 8-wave workgroup per CU, wave w owns output columns [32 w, 32 w + 32) with its 256 x 32 weight
 // slice in 128 registers, all waves share one staged 32-row batch, four batches in flight, deferred LDS float-max atomics,
 // centroid table built in LDS per object) - with everything that is the same for all 64 lanes of a wave moved off the vector
 // unit.  At K = 256 one staged row is exactly one wave-wide 16-byte load (64 lanes x 4 floats), so a wave stages WHOLE rows
@@ -24,6 +24,11 @@
 #ifndef T2P_SA3_ABL
 #define T2P_SA3_ABL 0
 #endif
+// The products run on v_mfma_f32_16x16x32_f16: four 16 x 16 blocks (2 row blocks x 2 column blocks) per wave and batch, 96 MFMAs of
+// half the size instead of 48 v_mfma_f32_32x32x16_f16 - the same FLOPs, LDS operand reads and weight registers (a row block's A operand
+// feeds both column blocks), but the smaller shape sustains 3-4 % more at the power cap (profiles/microbench/mfma_shapes.hip), and here:
+// 26.45-26.64 -> 25.40-25.68 ms per step in three interleaved A/B pairs (round 5).  Lane = 16 q + i holds row 16 rb + i of the A
+// operand, column 16 cb + i of the B operand, k = 64 q + 8 s + e of step s (s < 8), and rows 16 rb + 4 q + v of a result block.
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define AS4 __attribute__((address_space(4)))
 
@@ -49,7 +54,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef t2p_fp16x2 fp16x2;
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
 template <typename T>
 __device__ __forceinline__ const AS4 T* as_const(const T* p) {
@@ -89,7 +94,6 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: everything derived from it stays on the scalar unit
-    const int h = lane >> 5, l31 = lane & 31;
 
     // (constant address space = scalar loads: legal because earlier KERNELS wrote these tables - the scalar cache is invalidated at
     // kernel start - and this kernel never writes them.  n_rows holds u16 entries, read as the dword that holds them: the last
@@ -100,18 +104,23 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
     const AS4 int32_t* const bounds_c = as_const(p.bounds_ws);
 
     // ---- stationary weights: columns [32 wave, 32 wave + 32), all K, hi / lo planes (packing.py::pack_f16x3 order) ----
-    half8 w_hi[S16], w_lo[S16];
+    // 16x16x32 operands: lane = 16 q + i holds k = 64 q + 8 s + e of MFMA step s (s < 8), column 16 cb + i of the wave's 32
+    constexpr int S32 = K / 32;
+    const int q16 = lane >> 4, i16 = lane & 15;
+    half8 w_hi[2][S32], w_lo[2][S32];
     {
         const uint4* wp = (const uint4*)p.W_x3;
         constexpr int PLANE_U4 = (N / 32) * S16 * 64;
 #pragma unroll
-        for (int s = 0; s < S16; s++) {
-            const int idx = ((wave * S16 + s) * 2 + h) * 32 + l31;
-            w_hi[s] = __builtin_bit_cast(half8, wp[idx]);
-            w_lo[s] = __builtin_bit_cast(half8, wp[PLANE_U4 + idx]);
-        }
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+            for (int s = 0; s < S32; s++) {
+                const int k0 = 64 * q16 + 8 * s;                       // image: k = half' K/2 + 8 step' + e
+                const int idx = ((wave * S16 + (k0 % (K / 2)) / 8) * 2 + k0 / (K / 2)) * 32 + 16 * cb + i16;
+                w_hi[cb][s] = __builtin_bit_cast(half8, wp[idx]);
+                w_lo[cb][s] = __builtin_bit_cast(half8, wp[PLANE_U4 + idx]);
+            }
     }
-    constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < N; i += NT) biasl[i] = p.bias[i];
     for (int i = tid; i < (NC + 1) * N; i += NT) accl[i] = -__builtin_inff();
     for (int i = tid; i < 3 * K; i += NT) wpl[i] = p.wp[i];
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
     f32x16 rr[2];
 #pragma unroll
     for (int e = 0; e < 16; e++) rr[0][e] = rr[1][e] = -__builtin_inff();
-    float* const acc_col = accl + wave * 32 + l31;       // this lane's column in accumulator row 0
+    float* const acc_col = accl + wave * 32 + i16;       // this lane's column (of column block 0) in accumulator row 0
 
     int t = 0;
     int newest = 0;
@@ -334,32 +343,47 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
             It it_n = it_m;
             f32x16& acc = rr[half ^ 1];
             const f32x16& prev = rr[half];
-            // destination offsets of this lane's 16 rows of batch t-1 (written three batches ago)
-            uint2 four[4];
+            // result element e = 8 rb + 4 cb + v of this lane: row 16 rb + 4 q16 + v, column 16 cb + i16 of the wave's 32
+            uint2 four[2];   // destination offsets of rows 16 rb + 4 q16 + {0..3} of batch t-1 (written three batches ago)
             {
                 const uint16_t* dl = dstl + ((t + 3) & 3) * TR;
 #pragma unroll
-                for (int q = 0; q < 4; q++) four[q] = *(const uint2*)(dl + 8 * q + 4 * h);
+                for (int rb = 0; rb < 2; rb++) four[rb] = *(const uint2*)(dl + 16 * rb + 4 * q16);
             }
-            const _Float16* hrow = tile + buf * 2 * PLANE + l31 * LDHH + h * (K / 2);
-            half8 a_hi = *(const half8*)(hrow), a_lo = *(const half8*)(hrow + PLANE), n_hi = a_hi, n_lo = a_lo;
-            uint2 meta_m{0xFFFFFFFFu, 0xFFFFFFFFu};
+            const _Float16* hrow = tile + buf * 2 * PLANE + i16 * LDHH + q16 * 64;
+            half8 a_hi[2], a_lo[2];
 #pragma unroll
-            for (int j = 0; j < S16; j++) {
+            for (int rb = 0; rb < 2; rb++) {
+                a_hi[rb] = *(const half8*)(hrow + rb * 16 * LDHH);
+                a_lo[rb] = *(const half8*)(hrow + PLANE + rb * 16 * LDHH);
+            }
+            uint2 meta_m{0xFFFFFFFFu, 0xFFFFFFFFu};
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            const f32x4v kZero4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4v blk[4];   // [2 rb + cb]
+#pragma unroll
+            for (int sl = 0; sl < 4 * S32; sl++) {          // slot = (step, block): 3 MFMAs each
+                const int s32 = sl >> 2, b = sl & 3, rb = b >> 1, cb = b & 1;
                 SB();
-                if (j + 1 < S16 && !(T2P_SA3_ABL & 8)) {
-                    n_hi = *(const half8*)(hrow + (j + 1) * 8);
-                    n_lo = *(const half8*)(hrow + PLANE + (j + 1) * 8);
+                // operands of the NEXT step: row block 1 - rb is idle while block rb multiplies (no second operand set)
+                if (s32 + 1 < S32 && !(T2P_SA3_ABL & 8)) {
+                    if (b == 2) {
+                        a_hi[0] = *(const half8*)(hrow + (s32 + 1) * 8);
+                        a_lo[0] = *(const half8*)(hrow + PLANE + (s32 + 1) * 8);
+                    }
+                }
+                if (s32 > 0 && b == 0 && !(T2P_SA3_ABL & 8)) {
+                    a_hi[1] = *(const half8*)(hrow + 16 * LDHH + s32 * 8);
+                    a_lo[1] = *(const half8*)(hrow + PLANE + 16 * LDHH + s32 * 8);
                 }
                 if constexpr (!(T2P_SA3_ABL & 256)) __builtin_amdgcn_s_setprio(1);
-                acc = MFMA16(a_hi, w_hi[j], j == 0 ? kZero16 : acc);
-                acc = MFMA16(a_hi, w_lo[j], acc);
+                blk[b] = MFMA32(a_hi[rb], w_hi[cb][s32], s32 == 0 ? kZero4 : blk[b]);
+                blk[b] = MFMA32(a_hi[rb], w_lo[cb][s32], blk[b]);
                 if constexpr (!(T2P_SA3_ABL & 256)) __builtin_amdgcn_s_setprio(0);
                 SB();
-                if (j == 0) meta_m = load_meta(it_m);          // M(t+3)
-                // 12 staging chunks over the 16 MFMA groups: row k = (stage_a | stage_b | issue + next centroid read)
+                if (sl == 0) meta_m = load_meta(it_m);          // M(t+3)
 #pragma unroll
-                for (int c = (j * 12) / S16; c < ((j + 1) * 12) / S16; c++) {
+                for (int c = (sl * 12) / (4 * S32); c < ((sl + 1) * 12) / (4 * S32); c++) {
                     const int k = c / 3, part = c % 3;
                     if (part == 0) stage_a(sbuf, k);
                     else if (part == 1) stage_b(sbuf, k);
@@ -369,19 +393,23 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
                         else put_dst(dslot, dlo, dhi);
                     }
                 }
-                {                                               // one deferred atomic per group
-                    const int e = j;
-                    const uint32_t pair = (e & 2) ? four[e >> 2].y : four[e >> 2].x;
-                    const uint32_t off = (e & 1) ? (pair >> 16) : (pair & 0xFFFFu);
-                    if constexpr (T2P_SA3_ABL & 1) asm volatile("" ::"v"(prev[e]), "v"(off));   // (keeps the MFMA results alive)
-                    else lds_fmax((float*)((char*)acc_col + off), prev[e]);
+                if ((sl & 1) == 0) {                            // one deferred atomic per two slots: 16 per batch
+                    const int e = sl >> 1, erb = e >> 3, ecb = (e >> 2) & 1, v = e & 3;
+                    const uint32_t pair = (v & 2) ? four[erb].y : four[erb].x;
+                    const uint32_t off = (v & 1) ? (pair >> 16) : (pair & 0xFFFFu);
+                    if constexpr (T2P_SA3_ABL & 1) asm volatile("" ::"v"(prev[e]), "v"(off));
+                    else lds_fmax((float*)((char*)acc_col + off) + 16 * ecb, prev[e]);
                 }
                 SB();
-                if constexpr (!(T2P_SA3_ABL & 16)) acc = MFMA16(a_lo, w_hi[j], acc);
-                a_hi = n_hi;
-                a_lo = n_lo;
-                if (j == S16 / 2 - 1) it_n = advance(it_m);
+                if constexpr (!(T2P_SA3_ABL & 16)) blk[b] = MFMA32(a_lo[rb], w_hi[cb][s32], blk[b]);
+                if (sl == 2 * S32 - 1) it_n = advance(it_m);
             }
+            // (row block 1's operands for step s are fetched at the first slot of step s: see above - the read of step 0 is the
+            // initial one)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) acc[8 * (b >> 1) + 4 * (b & 1) + v] = blk[b][v];
             SB();
             const bool obj_done = it_c.r0 + TR >= it_c.n;
             newest = half ^ 1;
@@ -400,17 +428,18 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
         lds_barrier();
     }
     {   // drain: atomics of the last batch, then its object
-        uint2 four[4];
         const uint16_t* dl = dstl + ((t + 3) & 3) * TR;
-#pragma unroll
-        for (int q = 0; q < 4; q++) four[q] = *(const uint2*)(dl + 8 * q + 4 * h);
         const f32x16& last = rr[newest];
+        uint2 four[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) four[rb] = *(const uint2*)(dl + 16 * rb + 4 * q16);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-            const uint32_t pair = (e & 2) ? four[e >> 2].y : four[e >> 2].x;
-            const uint32_t off = (e & 1) ? (pair >> 16) : (pair & 0xFFFFu);
+            const int erb = e >> 3, ecb = (e >> 2) & 1, v = e & 3;
+            const uint32_t pair = (v & 2) ? four[erb].y : four[erb].x;
+            const uint32_t off = (v & 1) ? (pair >> 16) : (pair & 0xFFFFu);
             if constexpr (T2P_SA3_ABL & 1) asm volatile("" ::"v"(last[e]), "v"(off));
-            else lds_fmax((float*)((char*)acc_col + off), last[e]);
+            else lds_fmax((float*)((char*)acc_col + off) + 16 * ecb, last[e]);
         }
         __syncthreads();
         if (flush_g1 >= 0) flush(flush_g1);

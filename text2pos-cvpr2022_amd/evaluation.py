@@ -166,7 +166,8 @@ def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Seque
             xyz, rgb, center, mean_rgb = scene_dev.pack(ids.reshape(-1), keys.reshape(-1), transform.n_pts, want_rgb=want_rgb)
             if rgb is None:
                 rgb = torch.zeros_like(xyz)
-            hint_enc = model.encode_hints([create_hint_description(poses[q]) for q in range(q0, q1)])
+            with torch.no_grad():  # evaluation/pipeline.py:171
+                hint_enc = model.encode_hints([create_hint_description(poses[q]) for q in range(q0, q1)])
             hint_enc = hint_enc.repeat_interleave(kmax, dim=0)
             ci = co = None
             if class_all is not None or color_all is not None:
@@ -174,7 +175,8 @@ def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Seque
                 ci = None if class_all is None else class_all[flat_ids].contiguous()
                 co = None if color_all is None else color_all[flat_ids].contiguous()
             cp = np.arange(nb + 1, dtype=np.int32) * pad_size
-            out = model.forward_packed(xyz, rgb, center, mean_rgb, cp, hint_enc, ci, co)
+            with torch.no_grad():
+                out = model.forward_packed(xyz, rgb, center, mean_rgb, cp, hint_enc, ci, co)
             m0, off = out.matches0.cpu().numpy(), out.offsets.cpu().numpy()
             cxy = scene_dev.center64[ids][:, :, 0:2]
             pos_mean[q0:q1] = positions_in_cell(cxy, m0, np.zeros_like(off)).reshape(q1 - q0, kmax, 2)
