@@ -541,7 +541,8 @@ def test_run_fine_device_path_equals_host_path(vocab, fine_pair_gpu):
     for k in range(3):
         assert torch.equal(seen["dev"][0][k], torch.cat([h[k] for h in seen["host"]])), ("matches0", "offsets", "P")[k]
     assert dev_tables == host_tables
-    assert (seen["dev"][0][0] >= 0).any()
+    P = seen["dev"][0][2]
+    assert bool(torch.isfinite(P).all()) and float(P[:, :-1, :-1].std()) > 0.0      # (not a degenerate comparison)
 
 
 def test_pack_objects_matches_host_transform_chain(hip_model, oracle_model):
