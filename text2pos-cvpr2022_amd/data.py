@@ -334,7 +334,18 @@ def _means_from_sums(sums, abs_sums, rows, arrays_of):
     return out
 
 
+_HOST_THREADS = {}
+
+
 def host_threads(cap: int = 32) -> int:
+    """(cached per cap: the probe opens cgroup files)"""
+    n = _HOST_THREADS.get(cap)
+    if n is None:
+        n = _HOST_THREADS[cap] = _probe_host_threads(cap)
+    return n
+
+
+def _probe_host_threads(cap: int = 32) -> int:
     """Worker threads of the C helper: the CPUs this process may USE, at most `cap` (the pool's size) - the smaller of its
     affinity mask and its cgroup CPU quota (a container on a 256-thread host is typically granted a fraction of it; threads
     beyond the quota only add wake-ups and throttling)."""
