@@ -105,9 +105,9 @@ def encode_objects_train(model, xyz, rgb, center, mean_rgb, cell_ptr, class_idx=
             cell_edge_ptr = cent_ptr[cell_ptr_dev.long() * nc].contiguous()      # edges per cell = BatchNorm's row segments
             msg = TO.edge_features(x, pos, pos_c, g["src"], g["dst"])
             h = _mlp_train(msg, sa.point_conv.local_nn, cell_edge_ptr, nc)    # >= one self loop / hit per centroid
-            x, pos, nd = TO.segment_max(h, cent_ptr), pos_c, nc
+            x, pos, nd = TO.segment_max(h, cent_ptr, covers_all_rows=True), pos_c, nc    # (cent_ptr is the CSR over ALL edge rows)
         h = _mlp_train(torch.cat([x, pos], dim=1), pn.ga.mlp, _i32(cell_ptr_dev.long() * nd), nd)
-        f0 = TO.segment_max(h, _i32(torch.arange(n_obj + 1, device=dev) * nd))
+        f0 = TO.segment_max(h, _i32(torch.arange(n_obj + 1, device=dev) * nd), covers_all_rows=True)
         f1 = torch.relu(TO.linear(f0, pn.lin1))
         f2 = torch.relu(TO.linear(f1, pn.lin2))
         feats = (f0, f1, f2)[a.pointnet_features]

@@ -87,7 +87,7 @@ def bn_relu_train(x, seg_ptr, bn: torch.nn.BatchNorm1d, relu: bool = True, rows_
 
 class _SegmentMaxFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, seg_ptr):
+    def forward(ctx, x, seg_ptr, covers_all_rows=False):
         _need(x, "x", torch.float32, 2)
         dev = x.device
         _need(seg_ptr, "seg_ptr", torch.int32, 1, dev)
@@ -98,23 +98,27 @@ class _SegmentMaxFn(torch.autograd.Function):
                 "t2p_segment_max_forward")
         ctx.save_for_backward(arg, seg_ptr)
         ctx.rows = x.shape[0]
+        ctx.tiles = bool(covers_all_rows)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         arg, seg_ptr = ctx.saved_tensors
         n_seg, c = arg.shape
-        # (no zero fill: the segments tile the rows - every caller's seg_ptr runs from 0 to the row count - and the kernel writes
-        # every element of every segment's rows, the winner's gradient or 0)
-        dx = torch.empty((ctx.rows, c), dtype=torch.float32, device=dout.device)
+        # The kernel writes every element of every segment's rows (the winner's gradient or 0).  When the caller KNOWS that the
+        # segments tile [0, rows) (the training path's seg_ptr comes from its host plan) the zero fill is skipped; otherwise rows
+        # outside every segment must not leak uninitialised memory into the gradients.
+        alloc = torch.empty if ctx.tiles else torch.zeros
+        dx = alloc((ctx.rows, c), dtype=torch.float32, device=dout.device)
         L.check(L.lib().t2p_segment_max_backward(_ptr(dout.contiguous()), _ptr(arg), _ptr(seg_ptr), n_seg, c, _ptr(dx),
                                                  _stream(dout.device)), "t2p_segment_max_backward")
-        return dx, None
+        return dx, None, None
 
 
-def segment_max(x, seg_ptr):
-    """Row-segment maximum [S, C] of x [M, C] (rows sorted by destination); gradient flows to the winning rows."""
-    return _SegmentMaxFn.apply(x.contiguous(), seg_ptr)
+def segment_max(x, seg_ptr, covers_all_rows: bool = False):
+    """Row-segment maximum [S, C] of x [M, C] (rows sorted by destination); gradient flows to the winning rows.
+    covers_all_rows: the caller guarantees seg_ptr[0] == 0 and seg_ptr[-1] == M (the backward then skips zero-filling dx)."""
+    return _SegmentMaxFn.apply(x.contiguous(), seg_ptr, covers_all_rows)
 
 
 class _SegmentMeanFn(torch.autograd.Function):
