@@ -457,6 +457,10 @@ def main():
                     help="start the ranks through torch.distributed.run even at --gpus 1 (what --gpus N > 1 does by itself when "
                          "it is not already running under a launcher; test hook)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end evaluate() measurement from raw scenes")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="dry run of the N > 1 code paths on a box with ONE GPU: every rank uses cuda:0 and the process group is "
+                         "gloo (RCCL refuses two ranks on one device; gloo's all-gather is staged through the host).  The sharding, the "
+                         "exchange bookkeeping and every rank > 0 branch of this file run as they will on N GPUs; the timing means nothing")
     args = ap.parse_args()
 
     if needs_self_launch(args.gpus, args.self_launch):
@@ -490,6 +494,8 @@ def main():
     n_obj = int(cell_ptr[-1])
     log(f"generated {n_obj} objects / {c_hi - c_lo} cells on the host in {gen_s:.1f}s ({workers} workers)")
 
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     exchanging = world > 1 or args.force_exchange
@@ -502,7 +508,19 @@ def main():
                 s_.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if args.share_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                _agit = dist.all_gather_into_tensor
+
+                def _staged_all_gather(out, inp, group=None):     # gloo has no device all_gather_into_tensor: through the host
+                    if not inp.is_cuda:
+                        return _agit(out, inp, group=group)
+                    o = torch.empty(out.shape, dtype=out.dtype)
+                    _agit(o, inp.cpu(), group=group)
+                    out.copy_(o)
+                dist.all_gather_into_tensor = _staged_all_gather
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         except Exception as e:      # a 1-GPU line must not die of the optional one-rank group (N > 1 cannot run without it)
             if world > 1:
                 raise
@@ -860,6 +878,9 @@ def main():
                                   "algorithmic FLOP, so its ceiling on this metric is peak/3 = 833 TFLOP/s"
                                   if args.precision == "f16x3" else "exact fp32 MFMA path")},
             "host_generation_s": round(gen_s, 2),
+            # rank 0's first queries (global queries 0..15) and the GLOBAL cell rows they retrieved: the same lists at any N with
+            # the same total database and query set (the synthetic data is a function of the global index)
+            "top_k_of_first_queries": idx[:16].cpu().tolist(),
             "launched": ("self: python bench.py --gpus N re-executed under torch.distributed.run" if os.environ.get("T2P_BENCH_LAUNCHED") == "self"
                          else ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "plain process")),
             "fp16_range_guard": "clear" if args.precision == "f16x3" else "n/a (fp32)",

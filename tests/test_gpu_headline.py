@@ -909,6 +909,38 @@ def test_bench_starts_its_own_ranks_from_the_plain_command():
     assert bad.returncode != 0
 
 
+def test_bench_two_ranks_on_one_gpu_retrieve_what_one_rank_retrieves():
+    """The N > 1 branches of bench.py on the one GPU there is: `python bench.py --gpus 2 --share-gpu` starts two ranks (self-launch),
+    both on cuda:0, process group gloo (RCCL refuses two ranks on one device): contiguous cell / query blocks per rank, the one
+    all-gather of the cell embeddings, each rank ranking its query block against the full database, the per-rank exchange
+    bookkeeping.  Same total database and query set as a one-rank run => rank 0's first queries retrieve the same global rows."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-dropin", "--no-fp32-pass", "--no-pipeline"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra + common, cwd=root, env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    two = run(["--gpus", "2", "--share-gpu", "--cells", "384", "--queries", "64"])
+    one = run(["--gpus", "1", "--cells", "768", "--queries", "128"])
+    assert two["n_gpus"] == 2 and two["launched"].startswith("self")
+    assert two["config"]["cells_total"] == 768 == one["config"]["cells_total"] and two["config"]["queries_total"] == 128
+    ex = two["exchange"]
+    assert ex["world_size"] == 2 and ex["backend"] == "gloo" and len(ex["all_gather_ms_per_rank"]) == 2
+    assert ex["bytes_per_rank"] == 384 * 256 * 4 and ex["bytes_gathered"] == 768 * 256 * 4 and ex["events_recorded"] == 2
+    assert all(v > 0.0 for v in ex["all_gather_ms_per_rank"])
+    assert two["top_k_of_first_queries"] == one["top_k_of_first_queries"]
+    rows = np.array(two["top_k_of_first_queries"])
+    assert rows.shape == (16, 10) and rows.max() < 768 and (rows >= 384).any()      # rows of the OTHER rank's block are retrieved too
+
+
 def test_all_gather_rows_on_device_tensors_through_rccl():
     """distributed.all_gather_rows / sharded_retrieval with the "nccl" backend (RCCL) in a one-rank group, in this process:
     device tensors in, device tensors out, the forced collective returns the rows unchanged and t2p_sim_topk ranks them."""
