@@ -941,6 +941,40 @@ def test_bench_two_ranks_on_one_gpu_retrieve_what_one_rank_retrieves():
     assert rows.shape == (16, 10) and rows.max() < 768 and (rows >= 384).any()      # rows of the OTHER rank's block are retrieved too
 
 
+def test_sharded_pipeline_two_ranks_on_one_gpu(tmp_path):
+    """`pipeline.evaluate` with the input side on the GPU under a process group of TWO ranks (both on cuda:0, gloo): every rank
+    uploads the scene, encodes its block of the cells from it (global cell indices key the draws), the embeddings are gathered,
+    each rank ranks and then matches its block of the queries, the estimates are gathered.  Retrieval lists and all accuracy
+    tables equal the single-process run exactly (tests/tools/sharded_pipeline_worker.py)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from text2pos_amd import io as IO
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    np.random.seed(3)
+    cells, poses = _toy_scene(n_cells=50, n_poses=37, seed=21)
+    IO.save_scene(str(tmp_path / "sc"), "toy1", cells, poses)
+    worker = os.path.join(root, "tests", "tools", "sharded_pipeline_worker.py")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, worker, str(tmp_path / "sc"), str(tmp_path / "one.json")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), worker, str(tmp_path / "sc"), str(tmp_path / "two.json")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one, two = json.load(open(tmp_path / "one.json")), json.load(open(tmp_path / "two.json"))
+    assert one["retrievals"] == two["retrievals"] and len(one["retrievals"]) == 37
+    for k in ("hit", "close", "localisation", "fine_mean", "fine_offset", "fine_mean_conf"):
+        assert one[k] == two[k], k
+
+
 def test_all_gather_rows_on_device_tensors_through_rccl():
     """distributed.all_gather_rows / sharded_retrieval with the "nccl" backend (RCCL) in a one-rank group, in this process:
     device tensors in, device tensors out, the forced collective returns the rows unchanged and t2p_sim_topk ranks them."""
