@@ -20,7 +20,8 @@
 
 // T2P_SA3_ABL, development only (results wrong, timing valid): 1 = no atomics, 2 = no row gathers, 4 = no staging stores to LDS,
 // 8 = no operand reads inside the MFMA loop, 16 = no third MFMA, 32 = no per-batch barrier, 64 = no staging arithmetic,
-// 128 = no per-object phases (drain, centroid table); 256 = no s_setprio around the MFMA pairs (results stay right)
+// 128 = no per-object phases (drain, centroid table).  (Round 4 raised the wave priority around the MFMA pairs of the 32x32x16 form
+// with s_setprio; with the 16x16x32 slots that costs 1.5 %: 25.46-25.54 against 25.08-25.15 ms per step in three A/B pairs - removed.)
 #ifndef T2P_SA3_ABL
 #define T2P_SA3_ABL 0
 #endif
@@ -376,10 +377,8 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
                     a_hi[1] = *(const half8*)(hrow + 16 * LDHH + s32 * 8);
                     a_lo[1] = *(const half8*)(hrow + PLANE + 16 * LDHH + s32 * 8);
                 }
-                if constexpr (!(T2P_SA3_ABL & 256)) __builtin_amdgcn_s_setprio(1);
                 blk[b] = MFMA32(a_hi[rb], w_hi[cb][s32], s32 == 0 ? kZero4 : blk[b]);
                 blk[b] = MFMA32(a_hi[rb], w_lo[cb][s32], blk[b]);
-                if constexpr (!(T2P_SA3_ABL & 256)) __builtin_amdgcn_s_setprio(0);
                 SB();
                 if (sl == 0) meta_m = load_meta(it_m);          // M(t+3)
 #pragma unroll
