@@ -363,7 +363,9 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
             const f32x4v kZero4 = {0.f, 0.f, 0.f, 0.f};
             f32x4v blk[4];   // [2 rb + cb]
 #pragma unroll
-            for (int sl = 0; sl < 4 * S32; sl++) {          // slot = (step, block): 3 MFMAs each
+            // slot = (step, block): its 3 MFMAs back to back, then the slot's share of the staging work (round 5 A/B, three pairs each:
+            // [hh, hl | work | lh] 25.28-25.31 ms per step, this order 24.78-24.95, no sched_barrier fences 25.96-26.11)
+            for (int sl = 0; sl < 4 * S32; sl++) {
                 const int s32 = sl >> 2, b = sl & 3, rb = b >> 1, cb = b & 1;
                 SB();
                 // operands of the NEXT step: row block 1 - rb is idle while block rb multiplies (no second operand set)
@@ -379,29 +381,31 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
                 }
                 blk[b] = MFMA32(a_hi[rb], w_hi[cb][s32], s32 == 0 ? kZero4 : blk[b]);
                 blk[b] = MFMA32(a_hi[rb], w_lo[cb][s32], blk[b]);
-                SB();
-                if (sl == 0) meta_m = load_meta(it_m);          // M(t+3)
-#pragma unroll
-                for (int c = (sl * 12) / (4 * S32); c < ((sl + 1) * 12) / (4 * S32); c++) {
-                    const int k = c / 3, part = c % 3;
-                    if (part == 0) stage_a(sbuf, k);
-                    else if (part == 1) stage_b(sbuf, k);
-                    else {
-                        issue(it_g, meta_g, k, dlo, dhi);
-                        if (k + 1 < 4) load_b(k + 1);
-                        else put_dst(dslot, dlo, dhi);
-                    }
-                }
-                if ((sl & 1) == 0) {                            // one deferred atomic per two slots: 16 per batch
-                    const int e = sl >> 1, erb = e >> 3, ecb = (e >> 2) & 1, v = e & 3;
-                    const uint32_t pair = (v & 2) ? four[erb].y : four[erb].x;
-                    const uint32_t off = (v & 1) ? (pair >> 16) : (pair & 0xFFFFu);
-                    if constexpr (T2P_SA3_ABL & 1) asm volatile("" ::"v"(prev[e]), "v"(off));
-                    else lds_fmax((float*)((char*)acc_col + off) + 16 * ecb, prev[e]);
-                }
-                SB();
                 if constexpr (!(T2P_SA3_ABL & 16)) blk[b] = MFMA32(a_lo[rb], w_hi[cb][s32], blk[b]);
-                if (sl == 2 * S32 - 1) it_n = advance(it_m);
+                SB();
+                {
+                    const int w = sl;
+                    if (w == 0) meta_m = load_meta(it_m);          // M(t+3)
+#pragma unroll
+                    for (int c = (w * 12) / (4 * S32); c < ((w + 1) * 12) / (4 * S32); c++) {
+                        const int k = c / 3, part = c % 3;
+                        if (part == 0) stage_a(sbuf, k);
+                        else if (part == 1) stage_b(sbuf, k);
+                        else {
+                            issue(it_g, meta_g, k, dlo, dhi);
+                            if (k + 1 < 4) load_b(k + 1);
+                            else put_dst(dslot, dlo, dhi);
+                        }
+                    }
+                    if ((w & 1) == 0) {                            // one deferred atomic per two slots: 16 per batch
+                        const int e = w >> 1, erb = e >> 3, ecb = (e >> 2) & 1, v = e & 3;
+                        const uint32_t pair = (v & 2) ? four[erb].y : four[erb].x;
+                        const uint32_t off = (v & 1) ? (pair >> 16) : (pair & 0xFFFFu);
+                        if constexpr (T2P_SA3_ABL & 1) asm volatile("" ::"v"(prev[e]), "v"(off));
+                        else lds_fmax((float*)((char*)acc_col + off) + 16 * ecb, prev[e]);
+                    }
+                    if (w == 2 * S32 - 1) it_n = advance(it_m);
+                }
             }
             // (row block 1's operands for step s are fetched at the first slot of step s: see above - the read of step 0 is the
             // initial one)
