@@ -126,11 +126,11 @@ __global__ __launch_bounds__(NT, 2) void k_ga2(WsParams p, int n_slices) {
             }
             acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[rb], w_hi[cb][s], s == 0 ? kZero4 : acc[b], 0, 0, 0);
             accx[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[rb], w_lo[cb][s], s == 0 ? kZero4 : accx[b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // one LDS-DMA piece of the next tile per two slots of the first half (see the 32x32x16 form below)
-            if (more && (sl & 1) == 0 && (sl >> 1) < CHUNKS) dma_piece(gn, (i + 1) & 1, sl >> 1);
-            __builtin_amdgcn_sched_barrier(0);
             accx[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[rb], w_hi[cb][s], accx[b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // one LDS-DMA piece of the next tile per two slots of the first half, behind a block's three MFMAs (round 5: 14.77-14.81 ms
+            // per step against 14.89-14.98 with the piece between the second and third MFMA)
+            if (more && (sl & 1) == 0 && (sl >> 1) < CHUNKS) dma_piece(gn, (i + 1) & 1, sl >> 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
