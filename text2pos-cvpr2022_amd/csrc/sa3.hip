@@ -386,8 +386,11 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
                 {
                     const int w = sl;
                     if (w == 0) meta_m = load_meta(it_m);          // M(t+3)
+                    // the 12 staging chunks ride in the FIRST 12 of the 32 slots (the gathers of batch t + 2 leave early, the staged planes
+                    // are complete long before the barrier), the 16 deferred atomics in the LAST 16: 23.1-23.3 ms per step against
+                    // 24.2-24.3 with both spread evenly over the slots (three A/B pairs; other placements in docs/notebook.md)
 #pragma unroll
-                    for (int c = (w * 12) / (4 * S32); c < ((w + 1) * 12) / (4 * S32); c++) {
+                    for (int c = (w < 12 ? w : 12); c < (w < 12 ? w + 1 : 12); c++) {
                         const int k = c / 3, part = c % 3;
                         if (part == 0) stage_a(sbuf, k);
                         else if (part == 1) stage_b(sbuf, k);
@@ -397,8 +400,8 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
                             else put_dst(dslot, dlo, dhi);
                         }
                     }
-                    if ((w & 1) == 0) {                            // one deferred atomic per two slots: 16 per batch
-                        const int e = w >> 1, erb = e >> 3, ecb = (e >> 2) & 1, v = e & 3;
+                    if (w >= 16) {                                 // one deferred atomic per slot of the second half: 16 per batch
+                        const int e = w - 16, erb = e >> 3, ecb = (e >> 2) & 1, v = e & 3;
                         const uint32_t pair = (v & 2) ? four[erb].y : four[erb].x;
                         const uint32_t off = (v & 1) ? (pair >> 16) : (pair & 0xFFFFu);
                         if constexpr (T2P_SA3_ABL & 1) asm volatile("" ::"v"(prev[e]), "v"(off));
