@@ -318,5 +318,20 @@ def pack_text_weights(lang, device, x3: bool = False, pad_to: int = None) -> Dic
 
 
 def params_version(module: nn.Module) -> Tuple:
-    """Cheap change detector for cached packs: (data_ptr, _version) of every parameter and buffer."""
-    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+    """Cheap change detector for cached packs: (data_ptr, _version) of every parameter and buffer.  Runs once per encode call, so the
+    walk goes over the modules' own dictionaries (nn.Module.parameters() / buffers() spend ~0.5 ms per call on a coarse model in
+    generator recursion and de-duplication - a quarter of a 64-cell call); a tensor registered twice is simply listed twice."""
+    out = []
+    stack = [module]
+    while stack:
+        m = stack.pop()
+        for t in m._parameters.values():
+            if t is not None:
+                out.append((t.data_ptr(), t._version))
+        for t in m._buffers.values():
+            if t is not None:
+                out.append((t.data_ptr(), t._version))
+        for c in m._modules.values():
+            if c is not None:
+                stack.append(c)
+    return tuple(out)
