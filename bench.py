@@ -26,11 +26,15 @@ if ROOT not in sys.path:
 
 CELLS_PER_GPU = 12000
 QUERIES_PER_GPU = 1000
+CELLS_PER_GPU_MULTI = 12500     # BASELINE configs[2]: 100,000 cells / 8 GPUs
+QUERIES_PER_GPU_MULTI = 1250    # ... 10,000 queries / 8 GPUs
 TOPK = 10
 SEED = 20220002  # 20220000 + config id
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA (no sparsity)
-DOMINANT = "ws_edge_sa_k256_n256"
+DOMINANT = "ws_edge_sa_k256_n256"     # the library's profile-scope label of the dominant kernel (ops.profile_report key)
+DOMINANT_SYMBOL = "k_sa3"             # ... and its symbol as rocprofv3 prints it: t2p::k_sa3 (csrc/sa3.hip)
+COMPULSORY_BYTES_PER_OBJECT = 6168 + 1024   # xyz + rgb + centre + mean colour read, one 256-float row written
 
 
 _T0 = time.perf_counter()
@@ -230,11 +234,12 @@ def dropin_rates(model, S, torch, n_cells=2048, batch_sizes=(64, 512)):
         model.encode_objects(cells[:8], points[:8]).cpu()          # warm-up of the kernels (8 cells; their means get cached)
         for bs in batch_sizes:
             res = {}
-            # one untimed call at this batch size: the pinned staging buffers grow to the batch and the helper's thread pool starts
-            # (one-time costs of a process, not of an epoch); the cache is cleared again right below
-            model.encode_objects(cells[-bs:], points[-bs:]).cpu()
-            for epoch in ("first_epoch", "later_epochs"):
-                if epoch == "first_epoch":
+            # first_epoch_cold: nothing ran at this batch size yet - the pinned staging buffers grow to the batch and (at the first
+            # size) the helper's thread pool starts inside the timed epoch: what rounds 1-4 reported as "first epoch".
+            # first_epoch: the same with those one-time costs of a PROCESS already paid (round 5's definition) - every object's
+            # float64 means are still computed.  later_epochs: the means come from the per-cell cache.
+            for epoch in ("first_epoch_cold", "first_epoch", "later_epochs"):
+                if epoch != "later_epochs":
                     model.object_means_cache.clear()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -258,6 +263,8 @@ def dropin_rates(model, S, torch, n_cells=2048, batch_sizes=(64, 512)):
             out[f"batch_{bs}"] = res
             del d
     out["host_helper"] = "csrc/host_ext.c (_t2p_host)" if D.host_ext() is not None else "not built: NumPy route"
+    out["definitions"] = ("first_epoch_cold_cells_per_s = rounds 1-4's 'first epoch' (staging growth + pool start inside the timed epoch); "
+                          "first_epoch_cells_per_s = round 5's (those one-time process costs paid by an earlier epoch); quote like with like")
     out["note"] = ("first_epoch: every object's centre / mean colour is the float64 mean over its raw points, as the reference computes "
                    "them in every call (here: one C pass over a call's objects, bit-identical to np.mean); later_epochs: found in CellRetrievalNetwork.object_means_cache (keyed by the cell's object "
                    "list; Object3d point arrays are treated as immutable).  The dataloader's transforms are outside the timed loop, "
@@ -334,6 +341,38 @@ def executed_flops(e, e1_dedup, n_obj, n_cells, knn_edges, sa1_per_edge=True):
     graph = 2.0 * n_obj * 2 * 256 * 256 + 2.0 * knn_edges * 256 * 256 + n_cells * 262144.0
     return {"sa_edge_rows": sa2, "sa_layer1_tables": tables, "ga": ga, "heads": heads, "cell_graph": graph,
             "total": sa2 + tables + ga + heads + graph}
+
+
+def default_sizes(n_gpus, cells=None, queries=None):
+    """(cells per GPU, queries per GPU) of a run: what the command line says, else BASELINE.json's configuration for that GPU
+    count - configs[1] (12,000 + 1,000) on one GPU, configs[2]'s per-GPU share (100,000 / 8 = 12,500 cells, 10,000 / 8 = 1,250
+    queries) on several, so that `python bench.py --gpus 8` IS configs[2]."""
+    many = int(n_gpus) > 1
+    return (int(cells) if cells is not None else (CELLS_PER_GPU_MULTI if many else CELLS_PER_GPU),
+            int(queries) if queries is not None else (QUERIES_PER_GPU_MULTI if many else QUERIES_PER_GPU))
+
+
+def committed_evidence():
+    """(file name, parsed JSON) of the newest profiles/*_evidence.json (profiles/evidence.py), or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_evidence.json")))
+    if not files:
+        return None, None
+    return os.path.basename(files[-1]), json.load(open(files[-1]))
+
+
+def stale_sources(ev_doc, names):
+    """Kernel sources (csrc/<file>) whose content differs from what the evidence file was taken on; names=None: all of them."""
+    import hashlib
+    stale = []
+    for name, want in ev_doc.get("source_sha256_16", {}).items():
+        if names is not None and name not in names:
+            continue
+        path = os.path.join(ROOT, "text2pos-cvpr2022_amd", name)
+        have = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] if os.path.exists(path) else None
+        if have != want:
+            stale.append(name)
+    return stale
 
 
 def self_launch_command(n_gpus, argv, port=None):
@@ -421,8 +460,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cells", type=int, default=CELLS_PER_GPU, help="cells per GPU (default = BASELINE config 2)")
-    ap.add_argument("--queries", type=int, default=QUERIES_PER_GPU)
+    ap.add_argument("--cells", type=int, default=None,
+                    help="cells per GPU.  Default: 12,000 at --gpus 1 (BASELINE configs[1]), 12,500 at --gpus N > 1 - so that the "
+                         "driver's `--gpus 8` runs configs[2] exactly: a 100,000-cell database + 10,000 queries")
+    ap.add_argument("--queries", type=int, default=None, help="queries per GPU (default: 1,000 at --gpus 1, 1,250 at --gpus N > 1)")
+    ap.add_argument("--cells-total", type=int, default=0,
+                    help="size of the whole database instead of --cells x N: cut into contiguous blocks by distributed.shard_range, "
+                         "the first (total mod N) ranks holding one cell more (the padded-shard branch of all_gather_rows)")
+    ap.add_argument("--queries-total", type=int, default=0, help="the same for the query set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--chunk-objects", type=int, default=0)
@@ -460,11 +505,20 @@ def main():
                     help="start the ranks through torch.distributed.run even at --gpus 1 (what --gpus N > 1 does by itself when "
                          "it is not already running under a launcher; test hook)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end evaluate() measurement from raw scenes")
+    ap.add_argument("--weights", default="random",
+                    help="weights of the benchmarked model.  'random' (default; SURVEY 8(d)): random init + --bn.  'trained': a checkpoint "
+                         "trained HERE by train_checkpoint.py (320 Adam steps of the reference's training loop on synthetic (description, cell) "
+                         "pairs through this repo's HIP training path, saved with torch.save(model) and loaded back through "
+                         "io.load_reference_checkpoint).  Anything else: the path of a checkpoint file in the reference's format (whole pickled "
+                         "module) or a bare state_dict.  With 'random' the JSON line still carries a `trained_weights` block: the same step "
+                         "re-timed with a checkpoint trained behind the timed region (--no-trained skips it)")
+    ap.add_argument("--no-trained", action="store_true", help="skip the `trained_weights` block (the training run behind the timed region)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="dry run of the N > 1 code paths on a box with ONE GPU: every rank uses cuda:0 and the process group is "
                          "gloo (RCCL refuses two ranks on one device; gloo's all-gather is staged through the host).  The sharding, the "
                          "exchange bookkeeping and every rank > 0 branch of this file run as they will on N GPUs; the timing means nothing")
     args = ap.parse_args()
+    args.cells, args.queries = default_sizes(args.gpus, args.cells, args.queries)
 
     if needs_self_launch(args.gpus, args.self_launch):
         # `python bench.py --gpus N`: this process becomes the launcher; rank 0's JSON line is the last line of the ranks'
@@ -484,7 +538,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
-    n_cells_total, n_q_total = args.cells * world, args.queries * world
+    n_cells_total = args.cells_total or args.cells * world
+    n_q_total = args.queries_total or args.queries * world
     c_lo, c_hi = TD.shard_range(n_cells_total, rank, world)
     q_lo, q_hi = TD.shard_range(n_q_total, rank, world)
 
@@ -542,6 +597,19 @@ def main():
             m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
             m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
     model = model.to(dev).eval()
+    weights_info = None
+    if args.weights != "random":
+        import train_checkpoint as TC
+        path = None if args.weights == "trained" else args.weights
+        if world > 1 and path is None:       # one training run for the whole job: rank 0 writes the file, every rank loads it
+            path = f"/tmp/t2p_bench_trained_{os.environ.get('MASTER_PORT', '0')}.pth"
+            if rank == 0:
+                if os.path.exists(path):
+                    os.unlink(path)
+                TC.trained_model(path, precision=args.precision, device=dev, log=log)
+            dist.barrier()
+        model, weights_info = TC.trained_model(path, precision=args.precision, device=dev, log=log)
+        args.bn = "checkpoint"
     if os.environ.get("T2P_ABLATION_RUN"):   # development: T2P_ABL builds of the library compute garbage on purpose
         model.overflow_detected = lambda: 0
     model.tuning = args.tuning
@@ -579,21 +647,25 @@ def main():
     side = torch.cuda.Stream(device=dev)   # the text branch is independent of the cell branch: its (latency-bound)
                                            # biLSTM runs on a second HIP stream underneath the cell kernels
 
-    gather_events = []   # (start, end) torch events around the one exchange step, on the stream it runs on
+    gather_events = []   # per step: torch events (step begin, exchange begin, exchange end, step end) on the stream the exchange runs on
+
+    cur = [model]   # the model the step runs (the `trained_weights` block swaps a trained checkpoint in behind the timed region)
 
     def step():
         """One pass of the path through distributed.sharded_retrieval (the function pipeline.run_coarse runs): this rank's
         cell block -> (N > 1: the one all-gather) -> this rank's query block ranked against the full database."""
         with torch.no_grad():
             main = torch.cuda.current_stream()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]   # step begin | exchange begin | exchange end | step end
+            ev[0].record(main)
             side.wait_stream(main)
             with torch.cuda.stream(side):   # launched first: the text branch runs underneath the cell kernels
-                queries = model.language_encoder.encode_tokens(d_tok, d_len, normalize=True)
+                queries = cur[0].language_encoder.encode_tokens(d_tok, d_len, normalize=True)
 
             def encode_cells(lo, hi):
                 assert (lo, hi) == (c_lo, c_hi)
                 # the fp16-range guard accumulates in a device word during the step; it is read once after the timed region
-                return model.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
+                return cur[0].encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr,
                                                    chunk_objects=args.chunk_objects, check_overflow=False,
                                                    streams=args.cell_streams or None)
 
@@ -603,16 +675,16 @@ def main():
                 queries.record_stream(main)
                 return queries
 
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-
             def around_exchange(what):      # events around the one exchange step (RCCL over xGMI), on the stream it runs on
-                ev[0 if what == "begin" else 1].record(main)
+                ev[1 if what == "begin" else 2].record(main)
                 if what == "end":
                     gather_events.append(ev)
 
-            return TD.sharded_retrieval(encode_cells, encoded_queries, lambda q, c, k: ops.sim_topk(q, c, k),
-                                        n_cells_total, n_q_total, TOPK, gather_result=False, around_exchange=around_exchange,
-                                        force_exchange=args.force_exchange)
+            res = TD.sharded_retrieval(encode_cells, encoded_queries, lambda q, c, k: ops.sim_topk(q, c, k),
+                                       n_cells_total, n_q_total, TOPK, gather_result=False, around_exchange=around_exchange,
+                                       force_exchange=args.force_exchange)
+            ev[3].record(main)
+            return res
 
     def barrier():
         torch.cuda.synchronize()
@@ -629,7 +701,7 @@ def main():
     barrier()
     log("timed region")
     gather_events.clear()
-    single = args.cell_streams == 1 or (args.cell_streams == 0 and args.cells < 2048)   # (then the timed region itself is profiled)
+    single = args.cell_streams == 1 or (args.cell_streams == 0 and n_cells_total // world < 2048)   # (then the timed region itself is profiled)
     ops.profile_enable(single)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -647,18 +719,26 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # self-check of the first multi-GPU runs: per-rank time of the all-gather and what RCCL reports about itself
-        mine = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else 0.0
-        per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
-        per_rank[rank] = mine
+        # self-check of the first multi-GPU runs: per-rank time of the three phases of a step (this rank's encoders - cells on the
+        # main stream(s), text beside them; the one collective; the ranking of this rank's query block against the whole database)
+        # and what RCCL reports about itself
+        mine = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in gather_events])) if gather_events else 0.0 for i in range(3)]
+        per_rank = torch.zeros((world, 3), dtype=torch.float64, device=dev)
+        per_rank[rank] = torch.tensor(mine, dtype=torch.float64, device=dev)
         dist.all_reduce(per_rank)
+        shard_rows = [hi - lo for lo, hi in (TD.shard_range(n_cells_total, r, world) for r in range(world))]
         exchange = {"collective": "all_gather_into_tensor (RCCL)", "backend": dist.get_backend(),
-                    "world_size": dist.get_world_size(), "bytes_per_rank": int((c_hi - c_lo) * 256 * 4),
+                    "world_size": dist.get_world_size(), "bytes_per_rank": int(max(shard_rows) * 256 * 4),
                     "bytes_gathered": int(n_cells_total * 256 * 4),
-                    "all_gather_ms_per_rank": [round(float(v), 4) for v in per_rank.tolist()],
+                    "cells_per_rank": shard_rows if len(set(shard_rows)) > 1 else shard_rows[0],
+                    "padded_shards": len(set(shard_rows)) > 1,
+                    "encode_ms_per_rank": [round(float(v), 4) for v in per_rank[:, 0].tolist()],
+                    "all_gather_ms_per_rank": [round(float(v), 4) for v in per_rank[:, 1].tolist()],
+                    "ranking_ms_per_rank": [round(float(v), 4) for v in per_rank[:, 2].tolist()],
                     "events_recorded": len(gather_events), "forced_at_world_1": bool(args.force_exchange and world == 1),
-                    "note": "mean over the timed steps of the event-bracketed collective on each rank (includes waiting "
-                            "for the slowest rank's encoder)"}
+                    "note": "mean over the timed steps of event-bracketed phases on each rank's main stream: encode = this rank's "
+                            "cell block (+ waiting for its text block on the side stream), all_gather = the one collective (includes "
+                            "waiting for the slowest rank's encoder), ranking = sim + top-k of this rank's queries over all cells"}
         assert len(gather_events) == args.steps, (len(gather_events), args.steps)
 
     # ---- per-kernel times: the same step with the whole cell encoder on ONE stream (an event pair around a launch then times
@@ -751,6 +831,80 @@ def main():
         log(f"fp32 pass: {fp32_info['fp32_ms_per_step']:.1f} ms per step, max|f16x3 - fp32| = {delta:.2e} "
             f"({n_flip} cells with a kNN tie flip: {delta_all:.2e})")
 
+    # ---- the same step with TRAINED weights (behind the timed region; VERDICT r5: every earlier number is on random init) -----------
+    trained_info = None
+    if args.weights == "random" and not args.no_trained and args.precision == "f16x3" and args.cell_variant == "ragged":
+        try:
+            import train_checkpoint as TC
+            tpath = None
+            if world > 1:       # one training run for the whole job: rank 0 writes the file, every rank loads it
+                tpath = f"/tmp/t2p_bench_trained_{os.environ.get('MASTER_PORT', '0')}.pth"
+                if rank == 0:
+                    if os.path.exists(tpath):
+                        os.unlink(tpath)
+                    TC.trained_model(tpath, device=dev, log=log)
+                dist.barrier()
+            tmodel, tinfo = TC.trained_model(tpath, device=dev, log=log)
+            tmodel.tuning, tmodel.cell_streams = model.tuning, model.cell_streams
+            cur[0] = tmodel
+            try:
+                step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                barrier()
+                t_el = time.perf_counter() - t1
+                t_code = tmodel.overflow_detected()
+                with torch.no_grad():
+                    a_cells, a_tr = tmodel.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr, want_trace=("obj_emb", "knn_idx"),
+                                                                 check_overflow=False)
+                    tmodel.precision = "fp32"
+                    try:
+                        b_cells, b_tr = tmodel.encode_objects_packed(d_xyz, d_rgb, d_center, d_mean, cell_ptr, d_ptr, want_trace=("obj_emb", "knn_idx"))
+                    finally:
+                        tmodel.precision = "f16x3"
+                t_code |= tmodel.overflow_detected()
+                fo = (a_tr["knn_idx"] != b_tr["knn_idx"]).any(dim=1)
+                cof = torch.repeat_interleave(torch.arange(c_hi - c_lo, device=dev), (d_ptr[1:] - d_ptr[:-1]).long())
+                fc = torch.zeros(c_hi - c_lo, dtype=torch.bool, device=dev)
+                fc[cof[fo]] = True
+                pc = (a_cells - b_cells).abs().max(dim=1).values
+                smp = a_cells[:512]
+                cm = (smp @ smp.T)[torch.triu(torch.ones(smp.shape[0], smp.shape[0], dtype=torch.bool, device=dev), 1)]
+                vals = torch.tensor([t_el, float((a_tr["obj_emb"] - b_tr["obj_emb"]).abs().max()), float(pc[~fc].max()), float(pc.max())],
+                                    dtype=torch.float64, device=dev)
+                nfl = torch.tensor([float(fc.sum()), float(t_code != 0)], dtype=torch.float64, device=dev)
+                if world > 1:
+                    dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+                    dist.all_reduce(nfl)
+                t_el = float(vals[0])
+                trained_info = {
+                    "ms_per_step": t_el / args.steps * 1e3, "value": (n_cells_total + n_q_total) / (t_el / args.steps),
+                    "unit": "cells+queries/s", "steps": args.steps,
+                    "ratio_to_headline_ms": (t_el / args.steps) / (elapsed / args.steps),
+                    "fp16_range_guard": "clear" if nfl[1].item() == 0 else f"FIRED ({t_code:#x} on rank 0)",
+                    "f16x3_vs_fp32": {"max_abs_object_embeddings_all_objects": float(vals[1]),
+                                      "max_abs_cell_embeddings_cells_with_identical_knn_graph": float(vals[2]),
+                                      "max_abs_cell_embeddings_all_cells": float(vals[3]),
+                                      "cells_with_a_knn_tie_flip": int(nfl[0].item()), "cells": n_cells_total,
+                                      "mean_pairwise_cosine_of_512_cell_embeddings": float(cm.mean())},
+                    "checkpoint": tinfo,
+                    "note": "the timed step re-run with a checkpoint TRAINED on this box behind the timed region (train_checkpoint.py: the "
+                            "reference's training loop on synthetic (description, cell) pairs through the HIP training path, torch.save(model), "
+                            "io.load_reference_checkpoint); same inputs, same streams.  hit@k is on 2,048 held-out pairs (chance: k / 2048)"}
+                del a_cells, b_cells, a_tr, b_tr
+            finally:
+                cur[0] = model
+                del tmodel
+            log(f"trained weights: {trained_info['ms_per_step']:.2f} ms per step, guard {trained_info['fp16_range_guard']}, "
+                f"hit@k {tinfo.get('hit_at_k_held_out_2048_cells')}")
+        except Exception as e:      # report-only: the headline line must not die of it
+            if world > 1:
+                raise
+            trained_info = {"error": f"{type(e).__name__}: {e}"}
+            log(f"trained-weights block failed: {trained_info['error']}")
+
     # per-phase rates (outside the timed region; SURVEY 8(d) sub-metrics): each phase alone, events on torch's stream
     def timed(fn, reps):
         """median wall time of `reps` synchronised calls (after one untimed call)"""
@@ -816,21 +970,30 @@ def main():
             gbps = 6168.0 * n_obj * prof_steps / (sg_ms * 1e-3) / 1e9
             phase_rates["roofline"]["sample_group"] = {"bound": "latency / issue (scan)", "achieved_gbps": gbps, "peak_gbps": 8000.0,
                                                        "frac": gbps / 8000.0, "ms_per_step": sg_ms / prof_steps}
-        # HBM traffic of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this command;
-        # bench.py cannot host rocprofv3 itself): newest profiles/*_pmc_traffic.json, kernel k_sa3 (k_ws_sa2<256, 256, ...> in older sets)
-        traffic, traffic_source = None, None
+        # HBM traffic and MFMA-busy fraction of the dominant kernel from the committed counter passes (separate rocprofv3 --pmc runs
+        # of this command: bench.py cannot host rocprofv3 itself): newest profiles/*_evidence.json, which carries the content hashes
+        # of the kernel sources it was taken on - a figure whose kernel source has changed since is refused, not quoted
+        traffic, traffic_source, mfma_busy, step_bytes = None, None, None, None
         try:
-            import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            if files and args.precision == "f16x3" and args.cells == CELLS_PER_GPU and args.cell_variant == "ragged":
-                kern = json.load(open(files[-1]))["kernels"]
-                key = [k for k in kern if k.startswith("k_sa3") or k.startswith("k_ws_sa2<256, 256") or k.startswith("k_ws_sa<256, 256")]
-                if key:
-                    traffic = kern[key[0]]["hbm_bytes_per_launch"]
-                    traffic_source = ("profiles/" + os.path.basename(files[-1]) + " (separate rocprofv3 --pmc FETCH_SIZE / "
-                                      "WRITE_SIZE passes of this command; not measured in this run)")
-        except Exception:
-            traffic = None
+            ev_file, ev_doc = committed_evidence()
+            if ev_doc and args.precision == "f16x3" and args.cells == CELLS_PER_GPU and args.cell_variant == "ragged":
+                stale = stale_sources(ev_doc, ("csrc/sa3.hip", "csrc/t2p_common.h"))
+                if stale:
+                    traffic_source = (f"REFUSED: profiles/{ev_file} was taken on other sources ({', '.join(stale)} changed since): "
+                                      "re-run profiles/collect.sh")
+                else:
+                    row = ev_doc["kernels"].get(DOMINANT_SYMBOL, {})
+                    traffic = row.get("hbm_bytes_per_launch")
+                    mfma_busy = {"frac_of_kernel_cycles": row.get("mfma_busy"), "frac_at_2400mhz": row.get("mfma_busy_at_2400mhz"),
+                                 "shader_clock_ghz": row.get("shader_clock_ghz"),
+                                 "counter": "SQ_VALU_MFMA_BUSY_CYCLES / (1,024 SIMDs x the kernel's busy cycles from the GRBM_GUI_ACTIVE pass)"}
+                    traffic_source = (f"profiles/{ev_file} (tag {ev_doc.get('tag')}; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ / GRBM "
+                                      f"passes of this command on sources with csrc/sa3.hip sha256 {ev_doc['source_sha256_16'].get('csrc/sa3.hip')}: "
+                                      "same as this tree's; not measured in this run)")
+                    if not stale_sources(ev_doc, None):      # whole-step bytes need every kernel source unchanged
+                        step_bytes = ev_doc.get("whole_run", {}).get("hbm_bytes_per_step")
+        except Exception as e:
+            traffic_source = f"no usable evidence file ({type(e).__name__}: {e})"
         # the other SA levels and the whole step, same convention (algorithmic FLOPs executed / hipEvent time)
         sizes_np = np.diff(cell_ptr).astype(np.int64)
         knn_edges = int((sizes_np * np.minimum(sizes_np, 8)).sum())
@@ -845,7 +1008,10 @@ def main():
             sa_levels[name] = {"edge_rows_per_step": rows_l, "ms_per_step": ms / prof_steps, "achieved_tflops": tf,
                                "frac_of_peak": tf / peak if tf else None,
                                "frac_of_f16x3_ceiling": (3.0 * tf / peak if tf else None) if args.precision == "f16x3" else None}
-        whole_step = {"executed_flop_per_step": ex, "achieved_tflops": ex["total"] / (ms_per_step * 1e-3) / 1e12,
+        compulsory = float(COMPULSORY_BYTES_PER_OBJECT) * n_obj
+        whole_step = {"hbm_bytes_per_step": step_bytes, "compulsory_bytes_per_step": compulsory,
+                      "hbm_bytes_over_compulsory": (step_bytes / compulsory) if step_bytes else None,
+                      "executed_flop_per_step": ex, "achieved_tflops": ex["total"] / (ms_per_step * 1e-3) / 1e12,
                       "frac_of_peak": ex["total"] / (ms_per_step * 1e-3) / 1e12 / peak,
                       "note": "algorithmic FLOPs this plan executes (layer 1 of the SA MLPs per point at levels 2 / 3, per edge at level 1; "
                               "SA1 rows after t2p_dedup_rows) over the whole timed step, text branch and ranking excluded"}
@@ -859,18 +1025,27 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"{args.cells} cells/GPU ({dict(ragged='n~U{6..26}', fixed16='16', single='1')[args.cell_variant]} objects x 256 pts, {n_obj} objects on rank 0) "
                                     f"+ {args.queries} queries/GPU (6 hints), embed_dim=256, top-{TOPK} over {n_cells_total} cells"),
+                       "baseline_config": ("configs[1]: 1 x MI355X, 12k cells + 1k queries, top-10" if (world, n_cells_total, n_q_total) == (1, 12000, 1000)
+                                           else "configs[2]: 8 x MI355X, 100k-cell DB sharded per GPU, one RCCL all-gather, 10k queries top-10"
+                                           if (world, n_cells_total, n_q_total) == (8, 100000, 10000)
+                                           else f"configs[2]'s per-GPU share (12,500 cells + 1,250 queries) on {world} GPUs"
+                                           if world > 1 and (n_cells_total, n_q_total) == (12500 * world, 1250 * world) else "custom sizes"),
                        "cells_total": n_cells_total, "queries_total": n_q_total, "objects_rank0": n_obj,
-                       "weights": "random init (torch.manual_seed(1234)), BatchNorm statistics " +
-                                  ("calibrated by one train-mode pass over 64 cells (deviation from SURVEY 8(d), which randomises "
-                                   "them: random statistics collapse every embedding onto one direction; --bn random restores it)"
-                                   if args.bn == "calibrated" else "random (SURVEY 8(d))"),
+                       "weights": (("random init (torch.manual_seed(1234)), BatchNorm statistics " +
+                                   ("calibrated by one train-mode pass over 64 cells (deviation from SURVEY 8(d), which randomises "
+                                    "them: random statistics collapse every embedding onto one direction; --bn random restores it)"
+                                    if args.bn == "calibrated" else "random (SURVEY 8(d))") +
+                                   "; the same step on a TRAINED checkpoint: `trained_weights`") if weights_info is None else
+                                  {"kind": "trained checkpoint (train_checkpoint.py)" if args.weights == "trained" else "checkpoint file",
+                                   "file": None if args.weights == "trained" else os.path.basename(args.weights), **weights_info}),
                        "cell_streams": ("product default: 2 parts of the cell batch on 2 HIP streams" if args.cell_streams == 0 and not single
                                         else (args.cell_streams or 1)),
                        "parallelism": f"cells+queries sharded x{world}, 1 all-gather" if world > 1 else "single GPU"},
             "kernel_ms_per_step": phases, "phase_rates": phase_rates,
-            "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": achieved, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "t2p::" + DOMINANT_SYMBOL, "kernel_file": "text2pos-cvpr2022_amd/csrc/sa3.hip",
+                         "profile_scope": DOMINANT, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
-                         "traffic": traffic, "traffic_source": traffic_source, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
+                         "traffic": traffic, "traffic_source": traffic_source, "mfma_busy": mfma_busy, "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
                          "measured_in": ("the timed region (single stream)" if single_stream is None else
                                          f"a single-stream pass of the same step right behind the timed region ({prof_steps} steps; hipEvents on "
                                          "the launch stream): in the multi-stream timed region an event pair around one launch also spans "
@@ -896,6 +1071,8 @@ def main():
             out.update(fp32_info)
         if exchange:
             out["exchange"] = exchange
+        if trained_info:
+            out["trained_weights"] = trained_info
         if not args.no_dropin and world == 1 and args.cell_variant == "ragged":
             log("drop-in caller shape: encode_objects(objects, object_points) at batch 64 / 512")
             out["dropin"] = dropin_rates(model, S, torch)

@@ -46,6 +46,18 @@ def hip_model(vocab, oracle_model):
     return m.to("cuda:0").eval()
 
 
+@pytest.fixture(scope="session")
+def trained_checkpoint(tmp_path_factory):
+    """A TRAINED coarse checkpoint in the reference's file format, made on this box by the repo's own training path
+    (train_checkpoint.py: 320 Adam steps of training/coarse.py:31-62 on synthetic (description, cell) pairs, then
+    `torch.save(model, path)`).  Returns (path, info: epoch losses, hit@k on held-out pairs before / after)."""
+    import train_checkpoint as TC
+    path = str(tmp_path_factory.mktemp("ckpt") / "coarse_trained.pth")
+    model, info = TC.trained_model(path)
+    del model
+    return path, info
+
+
 def fine_args(num_layers):
     from oracle import model as OM
     return OM.default_args(embed_dim=128, num_layers=num_layers, sinkhorn_iters=50)

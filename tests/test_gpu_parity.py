@@ -541,6 +541,24 @@ def test_run_fine_device_path_equals_host_path(vocab, fine_pair_gpu):
     for k in range(3):
         assert torch.equal(seen["dev"][0][k], torch.cat([h[k] for h in seen["host"]])), ("matches0", "offsets", "P")[k]
     assert dev_tables == host_tables
+    # `queries_per_call` is the memory knob of the on-device path too (7 queries per call: 3 calls for 20 queries), and a
+    # model that offers forward_packed without the rest of what that path calls takes the host chain instead of failing
+    dev7 = E.run_fine(Spy(), poses, cells_dict, retr, tf, pad, [1, kmax], [5, 10, 15], queries_per_call=7,
+                      scene_dev=DeviceScene(cells, _dev(), n_pad=pad))
+    assert len(seen["dev"]) == 4 and dev7 == host_tables
+    assert torch.equal(torch.cat([d[2] for d in seen["dev"][1:]]), seen["dev"][0][2])
+
+    class OnlyPacked(torch.nn.Module):
+        device = _dev()
+        forward_packed = prod.forward_packed
+
+        def forward(self, objects, hints, points):
+            seen["host"].append(None)
+            return prod(objects, hints, points)
+    n_host = len(seen["host"])
+    assert E.run_fine(OnlyPacked(), poses, cells_dict, retr, tf, pad, [1, kmax], [5, 10, 15],
+                      scene_dev=DeviceScene(cells, _dev(), n_pad=pad)) == host_tables
+    assert len(seen["host"]) == n_host + 1 and len(seen["dev"]) == 4
     P = seen["dev"][0][2]
     assert bool(torch.isfinite(P).all()) and float(P[:, :-1, :-1].std()) > 0.0      # (not a degenerate comparison)
 

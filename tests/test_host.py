@@ -498,6 +498,83 @@ class Net(nn.Module):
         assert all(torch.equal(got[k], want[k]) for k in want)
 
 
+def test_product_modules_pickle_the_reference_way(tmp_path):
+    """training/coarse.py:323-324 saves checkpoints with `torch.save(model, path)`: the product modules must survive that (their
+    caches of ctypes descriptors / streams / pinned staging stay out of the pickle), and the file must read back both as a
+    module and - through the loader a reference checkpoint goes through - as a state_dict with the training arguments."""
+    import text2pos_amd as t2p
+    from text2pos_amd import io as IO, synthetic as S
+    from text2pos_amd.data import HostStaging, ObjectMeansCache
+    torch.manual_seed(5)
+    m = t2p.CellRetrievalNetwork(S.LABELS + ["pad"], S.COLOR_NAMES, S.known_words(), S.default_args(variation=1))
+    m._pack = ("stale", object(), lambda: None, True)          # what a used model holds: not picklable
+    m.language_encoder._pack = ("stale", {}, lambda: None)
+    m._staging.buffer(0, "xyz", 1000)
+    m.object_means_cache.put([1], np.zeros((1, 3)), np.zeros((1, 3)))
+    torch.save(m, tmp_path / "coarse.pth")
+    assert m._pack[0] == "stale" and len(m.object_means_cache.d) == 1      # saving leaves the live model alone
+    back = torch.load(tmp_path / "coarse.pth", weights_only=False)
+    assert back._pack is None and back.language_encoder._pack is None and back._overflow is None
+    assert isinstance(back._staging, HostStaging) and not back._staging.sets[0]
+    assert isinstance(back.object_means_cache, ObjectMeansCache) and not back.object_means_cache.d
+    sd, args = IO.load_reference_checkpoint(str(tmp_path / "coarse.pth"), return_args=True)
+    assert args["variation"] == 1 and args["embed_dim"] == 256 and args["use_features"] == ["class", "color", "position"]
+    want = m.state_dict()
+    assert list(sd.keys()) == list(want.keys()) and all(torch.equal(sd[k], want[k]) for k in want)
+    fine = t2p.SuperGlueMatch(S.LABELS + ["pad"], S.COLOR_NAMES, S.known_words(),
+                              S.default_args(embed_dim=128, num_layers=1, sinkhorn_iters=5))
+    fine._opack = ("stale", {}, lambda: None)
+    torch.save(fine, tmp_path / "fine.pth")
+    assert torch.load(tmp_path / "fine.pth", weights_only=False)._opack is None
+    assert set(IO.load_reference_checkpoint(str(tmp_path / "fine.pth"))) == set(fine.state_dict())
+
+
+def test_paired_texts_describe_their_cells():
+    """synthetic.make_paired_texts (the training pairs of train_checkpoint.py): text i names six DIFFERENT objects of cell i by the
+    attributes make_objects draws for them; a pure function of (seed, global cell index), so any block equals the same rows of
+    the whole; every word is in the vocabulary; the benchmark's random queries (make_texts) are untouched."""
+    from text2pos_amd import synthetic as S
+    from text2pos_amd.data import COLORS
+    from text2pos_amd.modules import tokenize
+    seed, n = 31, 40
+    texts = S.make_paired_texts(seed, n)
+    assert texts[7:19] == S.make_paired_texts(seed, n, 7, 19) and len(texts) == n
+    sizes = S.cell_sizes(seed, n)
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    shape, color_id, center = S.object_attributes(seed, 0, int(ptr[-1]))
+    _, _, got_center, got_mean = S.make_objects(seed, 0, int(ptr[-1]))
+    assert np.array_equal(got_center, center.astype(np.float32))
+    assert np.abs(got_mean - COLORS[color_id]).max() < 0.05          # (clipped N(0, 0.05^2) noise around the named colour)
+    for c, t in enumerate(texts):
+        hints = [h.strip() + "." for h in t.split(".") if h.strip()]
+        assert len(hints) == 6 and len(set(hints)) >= 1
+        own = {S.describe_object(shape[i], color_id[i], center[i]) for i in range(ptr[c], ptr[c + 1])}
+        assert set(hints) <= own, (c, set(hints) - own)
+    tok, lens = tokenize(texts, {w: i + 1 for i, w in enumerate(S.known_words())})
+    assert (tok[np.arange(tok.shape[1])[None, :] < lens[:, None]] > 0).all(), "a word outside the known vocabulary"
+    assert set(w for g in S.LABEL_GROUPS for w in g) == set(S.LABELS)
+    # a cell with fewer objects than hints repeats them in order
+    short = S.make_paired_texts(seed, 4, fixed_n=2)
+    assert all(len(set(h.strip() for h in t.split(".") if h.strip())) <= 2 for t in short)
+
+
+def test_train_checkpoint_collate_is_the_reference_batch_shape():
+    """train_checkpoint.collate: what Kitti360CoarseDataset.collate_fn yields (dataloading/kitti360pose/cells.py:98-110) for
+    synthetic pairs - and the Object3d accessors return the generator's centre / mean colour (models/object_encoder.py:121-131)."""
+    import train_checkpoint as TC
+    from text2pos_amd import synthetic as S
+    b = TC.collate(77, 20, 3, 8)
+    xyz, rgb, center, mean_rgb, ptr = S.make_cells(77, 20, 3, 8)
+    assert set(b) == {"texts", "objects", "object_points"} and len(b["texts"]) == len(b["objects"]) == len(b["object_points"]) == 5
+    assert b["texts"] == S.make_paired_texts(77, 20, 3, 8)
+    for c in range(5):
+        a, e = int(ptr[c]), int(ptr[c + 1])
+        assert len(b["objects"][c]) == e - a
+        assert np.array_equal(b["object_points"][c].pos.numpy().reshape(e - a, 256, 3), xyz[a:e])
+        assert np.array_equal(b["object_points"][c].x.numpy().reshape(e - a, 256, 3), rgb[a:e])
+        assert np.allclose(b["objects"][c][0].get_center(), center[a]) and np.allclose(b["objects"][c][-1].get_color_rgb(), mean_rgb[e - 1])
+
+
 def _stack_global_payload(module, name, args=()):
     """A protocol-4 pickle that resolves `module`.`name` with STACK_GLOBAL and calls it (REDUCE) with `args`."""
     import pickle
@@ -676,6 +753,13 @@ def test_device_scene_host_side():
         cells.append(D.Cell(i, "s", objs, 30.0, np.arange(6.0)))
     np.random.seed(3)
     sc = DeviceScene(cells, "cpu", n_pad=16)
+    # the padding objects come from `pad_seed`, not from the process-global np.random (every rank of a process group
+    # builds its own scene): same seed, same pads whatever np.random did in between; another seed, other pads
+    np.random.seed(99)
+    np.random.rand(5)
+    again, other = DeviceScene(cells, "cpu", n_pad=16), DeviceScene(cells, "cpu", n_pad=16, pad_seed=1)
+    assert torch.equal(again.raw_xyz, sc.raw_xyz) and np.array_equal(again.center64, sc.center64)
+    assert not torch.equal(other.raw_xyz[-8 * 16:], sc.raw_xyz[-8 * 16:]) and torch.equal(other.raw_xyz[:-8 * 16], sc.raw_xyz[:-8 * 16])
     flat = [o for c in cells for o in c.objects]
     assert sc.n_cells == 40 and sc.n_objects == len(flat) + 16 and sc.cell_ids[3] == cells[3].id and sc.row_of[cells[3].id] == 3
     assert np.array_equal(sc.raw_xyz.numpy()[: sc.obj_ptr[len(flat)]], np.concatenate([o.xyz for o in flat]).astype(np.float32))
@@ -760,6 +844,43 @@ def test_bench_self_launch_argv_and_conditions():
     assert bench.needs_self_launch(1, force=True, environ={})
     assert not bench.needs_self_launch(8, environ={"RANK": "3", "WORLD_SIZE": "8"})       # already under a launcher
     assert not bench.needs_self_launch(1, force=True, environ={"RANK": "0", "WORLD_SIZE": "1"})
+
+
+def test_bench_default_sizes_are_baseline_configs():
+    """`python bench.py` = configs[1] (12,000 cells + 1,000 queries on one GPU); `python bench.py --gpus 8` (the driver's scaling
+    command) = configs[2] (100,000-cell database + 10,000 queries: 12,500 + 1,250 per rank); explicit --cells / --queries win, so
+    `--gpus 8 --cells 12000` keeps the per-GPU share of the 1-GPU line.  The blocks every rank derives from the totals tile them."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from text2pos_amd import distributed as TD
+    assert bench.default_sizes(1) == (12000, 1000)
+    for n in (2, 4, 8):
+        assert bench.default_sizes(n) == (12500, 1250)
+    assert 8 * bench.default_sizes(8)[0] == 100000 and 8 * bench.default_sizes(8)[1] == 10000
+    assert bench.default_sizes(8, cells=12000) == (12000, 1250) and bench.default_sizes(1, queries=7) == (12000, 7)
+    blocks = [TD.shard_range(100000, r, 8) for r in range(8)]
+    assert blocks[0] == (0, 12500) and blocks[-1] == (87500, 100000) and all(b[1] == c[0] for b, c in zip(blocks, blocks[1:]))
+    uneven = [TD.shard_range(1001, r, 2) for r in range(2)]          # --cells-total 1001 --gpus 2: the padded-shard branch
+    assert uneven == [(0, 501), (501, 1001)]
+
+
+def test_bench_refuses_counter_evidence_taken_on_other_sources(tmp_path, monkeypatch):
+    """roofline.traffic / mfma_busy come from committed rocprofv3 --pmc passes (profiles/*_evidence.json) that carry the content
+    hashes of the kernel sources they were taken on: unchanged sources pass, a changed csrc/sa3.hip is named as stale."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import bench
+    import evidence
+    doc = {"source_sha256_16": evidence.source_hashes()}
+    assert "csrc/sa3.hip" in doc["source_sha256_16"] and "csrc/t2p_common.h" in doc["source_sha256_16"]
+    assert bench.stale_sources(doc, None) == [] and bench.stale_sources(doc, ("csrc/sa3.hip",)) == []
+    doc["source_sha256_16"]["csrc/sa3.hip"] = "0" * 16
+    assert bench.stale_sources(doc, ("csrc/sa3.hip", "csrc/t2p_common.h")) == ["csrc/sa3.hip"]
+    assert bench.stale_sources(doc, ("csrc/ga2.hip",)) == []
+    name, got = bench.committed_evidence()
+    assert (name is None) == (got is None)
+    if got is not None:
+        assert "k_sa3" in got["kernels"] and got["kernels"]["k_sa3"]["hbm_bytes_per_launch"] > 1e9
 
 
 def test_bench_plain_multi_gpu_command_launches_ranks_and_propagates_failure():

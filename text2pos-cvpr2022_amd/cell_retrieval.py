@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import ops, packing
 from .data import HostStaging, ObjectMeansCache, pack_cells
-from .modules import LanguageEncoder, get_mlp
+from .modules import LanguageEncoder, PicklableModule, get_mlp
 from .object_encoder import ObjectEncoder
 
 
@@ -29,7 +29,12 @@ class DynamicEdgeConv(nn.Module):
         self.nn, self.k, self.aggr = nn_, k, aggr
 
 
-class CellRetrievalNetwork(nn.Module):
+class CellRetrievalNetwork(PicklableModule):
+    # what `torch.save(model, path)` (training/coarse.py:323-324) must not try to pickle: packed-weight descriptors, the guard word,
+    # HIP streams, pinned staging, the per-cell means memo (it would drag the dataset's objects into the checkpoint)
+    _TRANSIENT = {"_pack": None, "_overflow": None, "_aux_streams": None, "_copy_stream": None, "_staging": HostStaging,
+                  "object_means_cache": ObjectMeansCache}
+
     def __init__(self, known_classes: List[str], known_colors: List[str], known_words: List[str], args,
                  add_self_loops: bool = True, precision: str = "f16x3", on_overflow: str = "raise"):
         """add_self_loops=True reproduces torch_geometric's PointConv default, which the reference relies on

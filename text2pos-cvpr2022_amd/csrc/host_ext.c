@@ -103,17 +103,21 @@ static struct {
     int n_threads;
     const job_t* jobs;
     int n_jobs, next, pending;
-} pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, NULL, 0, 0, 0};
+    int active, limit;   /* helpers working on the current batch / allowed to: a batch asked for `threads` runs on at most threads - 1
+                          * helpers + the caller, however many helpers earlier (larger) batches created */
+} pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, NULL, 0, 0, 0, 0, 0};
 
 static void* worker(void* arg) {
     (void)arg;
     pthread_mutex_lock(&pool.mu);
     for (;;) {
-        while (pool.next >= pool.n_jobs) pthread_cond_wait(&pool.work, &pool.mu);
+        while (pool.next >= pool.n_jobs || pool.active >= pool.limit) pthread_cond_wait(&pool.work, &pool.mu);
         const job_t* j = &pool.jobs[pool.next++];
+        pool.active++;
         pthread_mutex_unlock(&pool.mu);
         run_job(j);
         pthread_mutex_lock(&pool.mu);
+        pool.active--;      /* (this helper loops and takes the next job itself: nobody else needs waking) */
         if (--pool.pending == 0) pthread_cond_signal(&pool.done);
     }
     return NULL;
@@ -127,6 +131,7 @@ static void pool_after_fork_child(void) {
     pool.n_threads = 0;
     pool.jobs = NULL;
     pool.n_jobs = pool.next = pool.pending = 0;
+    pool.active = pool.limit = 0;
 }
 
 /* Runs the jobs on up to `threads` threads (the caller included) and returns when all are done.  GIL not needed. */
@@ -147,6 +152,8 @@ static void pool_run(const job_t* jobs, int n_jobs, int threads) {
     pool.n_jobs = n_jobs;
     pool.next = 0;
     pool.pending = n_jobs;
+    pool.active = 0;
+    pool.limit = threads - 1;
     pthread_cond_broadcast(&pool.work);
     while (pool.next < pool.n_jobs) {
         const job_t* j = &pool.jobs[pool.next++];

@@ -257,6 +257,11 @@ __device__ __forceinline__ void aten_column_sums(const float* __restrict__ pts, 
 
 // T.NormalizeScale of the wave's staged points, written to q [n_pts][3].
 __device__ __forceinline__ void normalize_scale_store(const float* __restrict__ pts, int n_pts, int lane, float* __restrict__ q) {
+    // the callers staged `pts` lane-strided; the column sums read it in another lane layout: order the wave's LDS stores before
+    // its LDS loads explicitly (in-order LDS issue makes it work without, but nothing would stop a future compiler from moving them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float sx, sy, sz;
     aten_column_sums(pts, n_pts, lane, sx, sy, sz);
     const float mx = sx / (float)n_pts, my = sy / (float)n_pts, mz = sz / (float)n_pts;

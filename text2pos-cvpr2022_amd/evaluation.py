@@ -11,7 +11,7 @@ The top-k indices come from `retrieve_topk` (csrc/sim_topk.hip), so `eval_retrie
 `eval_epoch` that follows the two encoding loops.
 """
 from copy import copy
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -117,11 +117,13 @@ def positions_in_cell(center_xy: np.ndarray, matches0: np.ndarray, offsets: np.n
 
 
 def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Sequence[str]], transform, pad_size: int,
-             top_k, threshs, queries_per_call: int = 64, group=None, scene_dev=None):
+             top_k, threshs, queries_per_call: Optional[int] = None, group=None, scene_dev=None):
     """Fine localisation of every query against its max(top_k) retrieved cells (evaluation/pipeline.py:172-279).
     `model(objects, hints, object_points)` is SuperGlueMatch (or anything returning .matches0 [B, pad] / .offsets
     [B, hints, 2]); unlike the reference, which calls the model once per query (10 samples), `queries_per_call` queries
-    share a call.  Returns (accuracies_mean, accuracies_offset, accuracies_mean_conf).
+    share a call - the memory knob of this function: one call packs queries_per_call x max(top_k) x pad_size objects.  None = 64
+    on the host chain, 256 on the on-device path (256 queries x 10 candidates x 16 objects fill the GPU); a given value is honoured
+    on both.  Returns (accuracies_mean, accuracies_offset, accuracies_mean_conf).
     With an initialised torch.distributed process group the queries are split over the ranks in contiguous blocks
     (samples are independent) and the per-query estimates are all-gathered: every rank returns the same tables.
     scene_dev (scene.DeviceScene holding every cell of `retrievals` and >= pad_size padding objects) + a counter-based
@@ -149,13 +151,18 @@ def run_fine(model, poses, cells_dict: Dict[str, object], retrievals: List[Seque
     pos_mean = np.zeros((nq, kmax, 2))
     pos_off = np.zeros((nq, kmax, 2))
     conf = np.zeros((nq, kmax), dtype=np.int64)
-    on_dev = scene_dev is not None and hasattr(transform, "keys") and hasattr(model, "forward_packed")
+    # the on-device path needs everything it calls on the model: a model that only has forward_packed takes the host chain
+    on_dev = (scene_dev is not None and hasattr(transform, "keys")
+              and all(hasattr(model, a) for a in ("forward_packed", "encode_hints", "args", "object_encoder")))
+    if queries_per_call is None:
+        queries_per_call = 256 if on_dev else 64
+    queries_per_call = max(1, int(queries_per_call))
     if on_dev:
         ids_of_cell = scene_dev.padded_object_ids(pad_size)                                  # [n_cells, pad]
         cell_rows = np.array([[scene_dev.row_of[cid] for cid in r] for r in retrievals], dtype=np.int64).reshape(nq, kmax)
         class_all, color_all = scene_dev.feature_indices(model)
         want_rgb = "color" in model.args.use_features or bool(getattr(model.args, "class_embed", False))
-        per_call = max(int(queries_per_call), 256)          # 256 queries x kmax candidates x pad objects fill the GPU
+        per_call = queries_per_call
         slot = np.arange(pad_size, dtype=np.int64)
         for q0 in range(q_lo, q_hi, per_call):
             q1 = min(q0 + per_call, q_hi)

@@ -162,7 +162,7 @@ class _CheckpointUnpickler(pickle.Unpickler):
         # not) becomes an inert shell: a bare nn.Module or a dict that keeps the state the pickle assigns
         key = f"{module}.{name}"
         if key not in _shells:
-            base = _DictShell if module.startswith("easydict") or name in ("Namespace", "EasyDict") else _Shell
+            base = _DictShell if module.startswith("easydict") or name in ("Namespace", "SimpleNamespace", "EasyDict") else _Shell
             _shells[key] = type(name, (base,), {"__module__": module})
         return _shells[key]
 

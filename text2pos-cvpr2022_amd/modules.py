@@ -149,7 +149,24 @@ class _LstmTrainFn(torch.autograd.Function):
         return (None, None, d_emb) + tuple(grads)
 
 
-class LanguageEncoder(nn.Module):
+class PicklableModule(nn.Module):
+    """`torch.save(model, path)` is how the reference writes its checkpoints (training/coarse.py:323-324: the whole module,
+    pickled).  The product modules cache things a pickle cannot carry - ctypes weight descriptors, HIP streams, pinned staging
+    buffers - under the attribute names a class lists in `_TRANSIENT` ({name: value or zero-argument factory}); they leave the
+    pickle as that fresh value and are rebuilt on first use after loading."""
+    _TRANSIENT = {}
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for name, fresh in self._TRANSIENT.items():
+            if name in state:
+                state[name] = fresh() if callable(fresh) else fresh
+        return state
+
+
+class LanguageEncoder(PicklableModule):
+    _TRANSIENT = {"_pack": None}
+
     def __init__(self, known_words, embedding_dim, bi_dir, num_layers=1):
         super().__init__()
         if not bi_dir or num_layers != 1:

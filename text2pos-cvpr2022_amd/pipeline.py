@@ -61,7 +61,8 @@ def on_device_input(model, transform) -> bool:
 
 @torch.no_grad()
 def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], threshs: Sequence[int], cells_per_call: int = 512,
-               texts_per_call: int = 1024, group=None, topk_fn=None, scene_dev=None, timings: Optional[dict] = None):
+               texts_per_call: int = 1024, group=None, topk_fn=None, scene_dev=None, timings: Optional[dict] = None,
+               on_device: Optional[bool] = None):
     """Encode every cell and every query, rank in float64, report hit@k / close-by@k and recall within the thresholds
     when the retrieved cell's centre is the estimate.  Returns (retrievals, accuracies dict).
 
@@ -75,13 +76,20 @@ def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], thresh
     normalised and encoded on the GPU (model.encode_scene_cells) - the same packed inputs, bit for bit, as the host chain
     `transform.for_cell(i)` + encode_objects, which remains the path of every other transform / model (cells_per_call cells per
     call there: the reference's loader hands over 64, evaluation/pipeline.py:303-308; cells are independent).
+    on_device: None (default) = the on-device input side whenever transform and model allow it, falling back to the host chain
+    (with a warning) when this rank's block cannot be held as one DeviceScene (an empty cell, more than 2^31 raw points); True =
+    insist (such a block raises); False = the host chain.
     topk_fn(queries, cells, k): the ranking kernel (default retrieval.retrieve_topk; the gloo CPU test injects the oracle's).
     timings: optional dict that receives the wall time of the upload (`scene_s`)."""
     import time
+    import warnings
     from . import distributed as TD
     cells, poses = scenes.all_cells, scenes.all_poses
     texts = scenes.texts
-    on_dev = (scene_dev is not None or on_device_input(model, transform)) and hasattr(model, "encode_scene_cells")
+    can = (scene_dev is not None or on_device_input(model, transform)) and hasattr(model, "encode_scene_cells")
+    if on_device and not can:
+        raise RuntimeError("run_coarse(on_device=True) needs a counter-based transform (PerCellTransform) and a model with encode_scene_cells")
+    on_dev = can and on_device is not False
 
     def encode_cells(lo, hi):
         if on_dev:
@@ -89,10 +97,18 @@ def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], thresh
                 return model.encode_scene_cells(scene_dev, transform, lo, hi)
             from .scene import DeviceScene
             t0 = time.perf_counter()
-            block = DeviceScene(cells[lo:hi], model.device)
-            if timings is not None:
-                timings["scene_s"] = time.perf_counter() - t0
-            return model.encode_scene_cells(block, transform, 0, hi - lo, cell_offset=lo)
+            try:
+                block = DeviceScene(cells[lo:hi], model.device)
+            except RuntimeError as e:
+                if on_device:
+                    raise
+                warnings.warn(f"run_coarse: cells [{lo}, {hi}) do not fit one DeviceScene ({e}); this block takes the host chain",
+                              RuntimeWarning)
+                block = None
+            if block is not None:
+                if timings is not None:
+                    timings["scene_s"] = time.perf_counter() - t0
+                return model.encode_scene_cells(block, transform, 0, hi - lo, cell_offset=lo)
         enc = []
         for a in range(lo, hi, cells_per_call):
             b = min(a + cells_per_call, hi)
@@ -125,22 +141,41 @@ def run_coarse(model, scenes: IO.Scenes, transform, top_k: Sequence[int], thresh
 
 @torch.no_grad()
 def evaluate(model_coarse, model_fine, scenes: IO.Scenes, transform, top_k=(1, 5, 10), threshs=(5, 10, 15), pad_size=16,
-             queries_per_call: int = 64, group=None, topk_fn=None, timings: Optional[dict] = None) -> Dict[str, object]:
+             queries_per_call: Optional[int] = None, group=None, topk_fn=None, timings: Optional[dict] = None,
+             on_device: Optional[bool] = None) -> Dict[str, object]:
     """Coarse retrieval + fine localisation.  `group`: torch.distributed process group (None = the default group when one
     is initialised, else single GPU); every rank returns the same tables.
     With a PerCellTransform and the product models the whole scene is uploaded once (scene.DeviceScene, with the fine stage's
     padding objects) and serves both stages: the coarse stage resamples and encodes its cells from it, the fine stage packs its
-    (query, candidate cell) samples from it - no per-object host work after the upload.
+    (query, candidate cell) samples from it - no per-object host work after the upload.  The WHOLE scene is uploaded on every rank
+    only when the fine stage needs it (its candidates are cells of any rank's block); a coarse-only evaluation uploads each rank's own
+    block (run_coarse), so input-side cost and HBM use shrink with the number of ranks.
+    on_device: None (default) = on-device input wherever possible, host chain (with a warning) when the scene cannot be held as one
+    DeviceScene (an empty cell, more than 2^31 raw points); True = insist; False = the host chain for both stages.
+    queries_per_call: evaluation.run_fine's memory knob (None = its defaults).
     timings: optional dict that receives wall times (`scene_s` upload, `coarse_s`, `fine_s`)."""
     import time
+    import warnings
     scene_dev = None
     t0 = time.perf_counter()
-    if on_device_input(model_coarse, transform) and hasattr(model_coarse, "encode_scene_cells"):
+    coarse_can = on_device_input(model_coarse, transform) and hasattr(model_coarse, "encode_scene_cells")
+    fine_can = (model_fine is not None and on_device_input(model_fine, transform)
+                and all(hasattr(model_fine, a) for a in ("forward_packed", "encode_hints")))
+    if on_device and not coarse_can:
+        raise RuntimeError("evaluate(on_device=True) needs a counter-based transform (PerCellTransform) and the product models")
+    if on_device is not False and coarse_can and fine_can:
         from .scene import DeviceScene
-        fine_on_dev = model_fine is not None and on_device_input(model_fine, transform) and hasattr(model_fine, "forward_packed")
-        scene_dev = DeviceScene(scenes.all_cells, model_coarse.device, n_pad=pad_size if fine_on_dev else 0)
+        try:
+            scene_dev = DeviceScene(scenes.all_cells, model_coarse.device, n_pad=pad_size,
+                                    pad_seed=getattr(transform, "seed", 0))
+        except RuntimeError as e:
+            if on_device:
+                raise
+            warnings.warn(f"evaluate: the scene does not fit one DeviceScene ({e}); both stages take the host chain", RuntimeWarning)
+            on_device = False
     t1 = time.perf_counter()
-    retrievals, out = run_coarse(model_coarse, scenes, transform, top_k, threshs, group=group, topk_fn=topk_fn, scene_dev=scene_dev)
+    retrievals, out = run_coarse(model_coarse, scenes, transform, top_k, threshs, group=group, topk_fn=topk_fn, scene_dev=scene_dev,
+                                 on_device=on_device, timings=timings if scene_dev is None else None)
     out["retrievals"] = retrievals
     t2 = time.perf_counter()
     if model_fine is not None:
@@ -148,7 +183,8 @@ def evaluate(model_coarse, model_fine, scenes: IO.Scenes, transform, top_k=(1, 5
                                      list(top_k), list(threshs), queries_per_call, group=group, scene_dev=scene_dev)
         out.update(fine_mean=mean, fine_offset=off, fine_mean_conf=conf)
     if timings is not None:
-        timings.update(scene_s=t1 - t0, coarse_s=t2 - t1, fine_s=time.perf_counter() - t2)
+        own_upload = timings.get("scene_s", 0.0) if scene_dev is None else 0.0      # (run_coarse's upload of this rank's block)
+        timings.update(scene_s=(t1 - t0) + own_upload, coarse_s=(t2 - t1) - own_upload, fine_s=time.perf_counter() - t2)
     return out
 
 

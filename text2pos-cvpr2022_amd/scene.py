@@ -23,9 +23,11 @@ class DeviceScene:
     per object), `cell_ptr` (objects per cell, CSR over the scene's objects, int64 [n_cells + 1]), `center64` (float64 object
     centres: the fine stage's pose estimate adds offsets to them, models/superglue_matcher.py:139-161), `labels`.
     n_pad > 0 appends that many padding objects (Object3d.create_padding: dataloading/kitti360pose/eval.py:147-149 fills a
-    sample's object list up to pad_size with them); their scene ids are `pad_ids`."""
+    sample's object list up to pad_size with them); their scene ids are `pad_ids`.  The padding objects' eight points (within 1 mm of
+    the origin) are drawn from `pad_seed`, not from the process-global np.random the reference uses: every rank of a process group
+    builds its own scene, and the fine stage must see the same padding on each of them (and in the single-process run)."""
 
-    def __init__(self, cells: Sequence, device, n_pad: int = 0, threads: Optional[int] = None):
+    def __init__(self, cells: Sequence, device, n_pad: int = 0, threads: Optional[int] = None, pad_seed: int = 0):
         self.device = torch.device(device)
         groups = [c.objects if isinstance(c.objects, list) else list(c.objects) for c in cells]
         counts = np.fromiter((len(g) for g in groups), dtype=np.int64, count=len(groups))
@@ -37,7 +39,8 @@ class DeviceScene:
         self.row_of = {cid: i for i, cid in enumerate(self.cell_ids)}
         n_real = int(self.cell_ptr[-1])
         if n_pad > 0:
-            groups = groups + [[D.Object3d.create_padding() for _ in range(n_pad)]]
+            pad_rng = np.random.default_rng([int(pad_seed), 0x7061_6400])
+            groups = groups + [[D.Object3d.create_padding(rng=pad_rng) for _ in range(n_pad)]]
         self.pad_ids = np.arange(n_real, n_real + max(n_pad, 0), dtype=np.int64)
         flat = [o for g in groups for o in g]
         self.n_objects = len(flat)

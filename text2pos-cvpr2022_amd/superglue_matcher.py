@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import ops, packing
 from .data import HostStaging, ObjectMeansCache, pack_cells
-from .modules import LanguageEncoder, tokenize
+from .modules import LanguageEncoder, PicklableModule, tokenize
 from .object_encoder import ObjectEncoder
 
 MATCH_THRESHOLD = 0.2  # models/superglue_matcher.py:80
@@ -72,7 +72,9 @@ class MatchOutputs(dict):
     __setattr__ = dict.__setitem__
 
 
-class SuperGlueMatch(nn.Module):
+class SuperGlueMatch(PicklableModule):
+    _TRANSIENT = {"_opack": None, "_mpack": None, "_side": None, "_overflow": None, "_staging": None, "object_means_cache": None}
+
     def __init__(self, known_classes: List[str], known_colors: List[str], known_words: List[str], args,
                  add_self_loops: bool = True, precision: str = "f16x3"):
         super().__init__()

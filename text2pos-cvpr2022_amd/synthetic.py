@@ -9,6 +9,11 @@ Object: shape in {planar patch 45 %, pole 25 %, box surface 30 %}; m = round(exp
 centre ~ U[0,1]^2 x U[0,0.3]; mean_rgb = mean of the drawn rgb.
 Cell: n ~ U{6..26} objects (or a fixed n).  Text: 6 hints "The pose is {dir} of a {color} {label}."
 (dataloading/kitti360pose/base.py:63-65) joined by a space (dataloading/kitti360pose/cells.py:82).
+
+Two kinds of text: `make_texts` draws every hint at random (the benchmark's queries: the encoders' work does not depend on what
+a sentence says); `make_paired_texts` DESCRIBES cell i - six of its objects, each by the direction of its centre from the cell's
+middle, its colour name and a label that follows from its shape and height - so that a (text, cell) pair carries the signal the
+reference trains on (training/coarse.py:31-62) and a model trained on the pairs retrieves above chance.
 """
 from types import SimpleNamespace
 
@@ -108,6 +113,57 @@ def make_objects(seed: int, obj_lo: int, obj_hi: int, n_pts: int = 256):
     center = (cu * np.array([1.0, 1.0, 0.3])).astype(np.float32)
     mean_rgb = rgb.astype(np.float64).mean(axis=1).astype(np.float32)
     return xyz, rgb, center, mean_rgb
+
+
+# labels a paired text can use for an object: by the generator's shape class (planar patch / pole / box surface), seven each;
+# which of the seven follows from the height of the object's centre, a feature the model sees (models/object_encoder.py:127-131)
+LABEL_GROUPS = (("road", "sidewalk", "parking", "terrain", "wall", "fence", "guard rail"),
+                ("pole", "traffic light", "traffic sign", "stop", "smallpole", "lamp", "trash bin"),
+                ("building", "garage", "vending machine", "box", "bridge", "tunnel", "vegetation"))
+
+
+def object_attributes(seed: int, obj_lo: int, obj_hi: int):
+    """What make_objects draws for objects [obj_lo, obj_hi) besides their points: shape class (0 planar patch, 1 pole, 2 box
+    surface), colour index into COLORS / COLOR_NAMES, centre [n, 3] (float64, before the cast to fp32)."""
+    oid = np.arange(obj_lo, obj_hi, dtype=np.uint64)
+    shape_u = _u01(_key(seed, oid, 1))
+    shape = np.where(shape_u < 0.45, 0, np.where(shape_u < 0.70, 1, 2)).astype(np.int64)
+    color_id = (_u01(_key(seed, oid, 6)) * 8.0).astype(np.int64)
+    center = _u01(_key(seed, oid[:, None], 8, np.arange(3)[None, :])) * np.array([1.0, 1.0, 0.3])
+    return shape, color_id, center
+
+
+def describe_object(shape: int, color_id: int, center) -> str:
+    """One hint in the reference's template (dataloading/kitti360pose/base.py:63-65) for an object seen from the middle of its
+    cell: direction as datapreparation/kitti360pose/descriptions.py words it (on-top when close, else the dominant axis)."""
+    dx, dy = float(center[0]) - 0.5, float(center[1]) - 0.5
+    if max(abs(dx), abs(dy)) < 0.1:
+        direction = "on-top"
+    elif abs(dx) >= abs(dy):
+        direction = "east" if dx > 0 else "west"
+    else:
+        direction = "north" if dy > 0 else "south"
+    label = LABEL_GROUPS[int(shape)][min(6, int(float(center[2]) / 0.3 * 7.0))]
+    return f"The pose is {direction} of a {COLOR_NAMES[int(color_id)]} {label}."
+
+
+def make_paired_texts(seed: int, n_cells: int, cell_lo: int = 0, cell_hi: int = None, n_hints: int = 6, fixed_n: int = 0):
+    """Text i describes cell i of the `seed` database (cells [cell_lo, cell_hi)): `n_hints` of its objects, chosen by a hash of
+    (seed, cell, object) without repetition (a cell with fewer objects repeats them in order)."""
+    cell_hi = n_cells if cell_hi is None else cell_hi
+    sizes = cell_sizes(seed, n_cells, fixed_n)
+    ptr = np.zeros(n_cells + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(sizes)
+    o_lo, o_hi = int(ptr[cell_lo]), int(ptr[cell_hi])
+    shape, color_id, center = object_attributes(seed, o_lo, o_hi)
+    order_key = _key(seed, np.arange(o_lo, o_hi, dtype=np.uint64), 13)
+    texts = []
+    for c in range(cell_lo, cell_hi):
+        a, b = int(ptr[c]) - o_lo, int(ptr[c + 1]) - o_lo
+        order = a + np.argsort(order_key[a:b], kind="stable")
+        picks = [int(order[j % (b - a)]) for j in range(n_hints)]
+        texts.append(" ".join(describe_object(shape[i], color_id[i], center[i]) for i in picks))
+    return texts
 
 
 def cell_sizes(seed: int, n_cells: int, fixed_n: int = 0) -> np.ndarray:
