@@ -899,3 +899,40 @@ def test_bench_plain_multi_gpu_command_launches_ranks_and_propagates_failure():
     assert "self-launch:" in r.stderr and "--nproc-per-node=2" in r.stderr
     assert "generated " in r.stderr, r.stderr[-2000:]           # the ranks came up and did their host-side work (rank 0 logs it)
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_oracle_full_check_machinery(oracle_model):
+    """bench.py --oracle-cells: spawned oracle workers over blocks of the workload, neighbour lists as global
+    object rows, per-path summary.  Fed with the oracle's OWN embeddings as the 'HIP path' it must report no difference at all;
+    with one cell's embedding nudged and one neighbour list edited, exactly those."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from text2pos_amd import synthetic as S
+    seed, n_total, n = 99, 40, 12
+    sd = {k: v.clone() for k, v in oracle_model.state_dict().items()}
+    xyz, rgb, center, mean_rgb, cp = S.make_cells(seed, n_total, 0, n)
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as f:
+        path = f.name
+    torch.save(sd, path)
+    try:
+        lo, hi, cells, knn = bench._oracle_chunk((path, seed, n_total, 0, n, 4))
+    finally:
+        os.unlink(path)
+    assert (lo, hi) == (0, n) and cells.shape == (n, 256) and knn.shape == (int(cp[-1]), 8)
+    cell_of = np.repeat(np.arange(n), np.diff(cp))
+    assert (cell_of[np.maximum(knn, 0)] == cell_of[:, None])[knn >= 0].all()          # global rows, inside their own cell
+    same = bench.oracle_full_check(seed, n_total, n, sd, {"self": (torch.from_numpy(cells), knn)}, cp, processes=2)
+    assert same["oracle_processes"] == 1 and same["self"]["cells_with_a_knn_graph_difference"] == 0      # (12 cells: one block of 64)
+    assert same["self"]["cells_beyond_1e-4"] == 0 and same["self"]["max_abs_all_cells"] < 1e-6      # (thread count changes the rounding)
+    cells2, knn2 = cells.copy(), knn.copy()
+    cells2[3, 0] += 1e-3
+    o = int(cp[7])
+    knn2[o, 0], knn2[o, 1] = knn2[o, 1], knn2[o, 0]            # same set, other order: not a difference
+    knn2[int(cp[9]), 7] = -1 if knn2[int(cp[9]), 7] >= 0 else int(cp[9])
+    got = bench.oracle_full_check(seed, n_total, n, sd, {"hip": (torch.from_numpy(cells2), knn2)}, cp, processes=1)["hip"]
+    assert got["cells_with_a_knn_graph_difference"] == 1 and got["cells_beyond_1e-4"] == 1
+    assert got["cells_beyond_1e-4_without_a_graph_difference"] == 1 and abs(got["max_abs_all_cells"] - 1e-3) < 1e-6
+    # chunk-local neighbour rows -> global rows
+    g = bench.global_knn(np.array([[0, 1], [1, -1], [0, 1], [1, 0]]), np.array([0, 2, 4]), chunk_objects=2)
+    assert g.tolist() == [[0, 1], [1, -1], [2, 3], [3, 2]]

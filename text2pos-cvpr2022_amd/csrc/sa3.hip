@@ -30,6 +30,9 @@
 // feeds both column blocks), but the smaller shape sustains 3-4 % more at the power cap (profiles/microbench/mfma_shapes.hip), and here:
 // 26.45-26.64 -> 25.40-25.68 ms per step in three interleaved A/B pairs (round 5).  Lane = 16 q + i holds row 16 rb + i of the A
 // operand, column 16 cb + i of the B operand, k = 64 q + 8 s + e of step s (s < 8), and rows 16 rb + 4 q + v of a result block.
+#ifndef T2P_SA3_SPLIT_ASM
+#define T2P_SA3_SPLIT_ASM 1
+#endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define AS4 __attribute__((address_space(4)))
 
@@ -267,10 +270,15 @@ __global__ __launch_bounds__(NT, 2) void k_sa3(SaParams p) {
             pl.x = __float_as_uint(vv[2]);
             pl.y = __float_as_uint(vv[3]);
         } else {
+#if T2P_SA3_SPLIT_ASM
+            pl.x = split_lo_pk(vh01, vv[0], vv[1]);     // (one asm statement per pair: no s_nop between the pieces, t2p_common.h)
+            pl.y = split_lo_pk(vh23, vv[2], vv[3]);
+#else
             const fp16x2 l01 = cvt_pk_f16(sub_half<0>(vv[0], vh01), sub_half<1>(vv[1], vh01));
             const fp16x2 l23 = cvt_pk_f16(sub_half<0>(vv[2], vh23), sub_half<1>(vv[3], vh23));
             pl.x = __builtin_bit_cast(uint32_t, l01);
             pl.y = __builtin_bit_cast(uint32_t, l23);
+#endif
         }
         if constexpr (T2P_SA3_ABL & 4) asm volatile("" ::"v"(pl.x), "v"(pl.y));
         else *(uint2*)(dsth + PLANE + (4 * wave + k) * LDHH + c4 * 4) = pl;

@@ -39,6 +39,33 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gl_void;
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+// T2P_ROWS_AGPR (round 6): the weight matrix does not fit the 256 architectural VGPRs next to the loop's working set, and hipcc parks
+// what does not fit (39 of the 64 half8 operands) in AGPRs as SPILL space: 96 v_accvgpr_read_b32 per tile copy them back, operand by
+// operand, in front of their MFMAs (ISA census: 96 of the loop's 859 non-MFMA instructions - with one wave per SIMD every one of
+// them comes out of the MFMA stream).  gfx950's MFMA reads its B operand from an AGPR just as well: here the MFMAs are inline asm whose
+// weight operand is constrained to the register file the operand LIVES in - the whole lo plane and the first WA_HI_STEPS steps of
+// the hi plane in AGPRs (moved there once, at kernel start), the rest in VGPRs - and the accumulators stay in AGPRs, where
+// ds_max_f32 reads them.  Same instructions, same order of accumulation: same bits.
+#ifndef T2P_ROWS_AGPR
+#define T2P_ROWS_AGPR 1
+#endif
+constexpr int WA_HI_STEPS = 3;     // AGPR budget: 64 accumulator registers + 128 (lo plane) + 16 * WA_HI_STEPS (hi plane) <= 256
+__device__ __forceinline__ constexpr bool w_in_agpr(bool lo_plane, int s) { return lo_plane || s < WA_HI_STEPS; }
+// c (+)= a x w on v_mfma_f32_32x32x16_f16; `agpr`: where w lives; `zero`: start from 0 (inline constant) instead of c
+__device__ __forceinline__ void mfma_w(f32x16& c, const half8& a, const half8& w, bool agpr, bool zero) {
+#if T2P_ROWS_AGPR
+    if (zero) {
+        if (agpr) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "a"(w));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(w));
+    } else {
+        if (agpr) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "a"(w));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(w));
+    }
+#else
+    constexpr f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    c = MFMA16(a, w, zero ? z : c);
+#endif
+}
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #if T2P_RABL & 2
 #define DS_MAX_STR "; no atomic %0 %1 %2"
@@ -126,6 +153,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                 const int idx = (((nt * C::S16 + step_) * 2 + half_) * 32) + rr;
                 w_hi[nt][s] = __builtin_bit_cast(half8, wp[idx]);
                 w_lo[nt][s] = __builtin_bit_cast(half8, wp[PLANE_U4 + idx]);
+#if T2P_ROWS_AGPR
+                // into the AGPR file, once (an empty asm whose AGPR output is tied to the loaded value)
+                if (w_in_agpr(false, s)) asm volatile("" : "=a"(w_hi[nt][s]) : "0"(w_hi[nt][s]));
+                asm volatile("" : "=a"(w_lo[nt][s]) : "0"(w_lo[nt][s]));
+#endif
             }
     }
     // The bias is NOT part of the accumulation: a tile's first MFMAs start from 0, the LDS accumulator takes a FLOAT max of the
@@ -359,9 +391,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                 };
                 auto prep_b = [&](const float (&v)[2], uint32_t& wh, uint32_t& wl) {
                     const fp16x2 hh = cvt_pk_f16(v[0], v[1]);
-                    const fp16x2 ll = cvt_pk_f16(sub_half_r<0>(v[0], hh), sub_half_r<1>(v[1], hh));
                     wh = __builtin_bit_cast(uint32_t, hh);
+#if T2P_ROWS_AGPR
+                    wl = split_lo_pk(hh, v[0], v[1]);      // (one asm statement: t2p_common.h)
+#else
+                    const fp16x2 ll = cvt_pk_f16(sub_half_r<0>(v[0], hh), sub_half_r<1>(v[1], hh));
                     wl = __builtin_bit_cast(uint32_t, ll);
+#endif
                 };
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 auto row_addr = [&](const uint2 (&f4)[4], int e) -> uint32_t {
@@ -403,16 +439,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                     SB();
                     if (s == 0) {
 #pragma unroll
-                        for (int nt = 0; nt < C::NTW - 1; nt++) acc[nt] = MFMA16(a_hi, w_hi[nt][0], kZero16);
+                        for (int nt = 0; nt < C::NTW - 1; nt++) mfma_w(acc[nt], a_hi, w_hi[nt][0], w_in_agpr(false, 0), true);
                         if (pend) {   // the previous tile's last result block: its MFMAs are long done, its registers are free below
 #pragma unroll
                             for (int e = 0; e < 16; e++)
                                 asm volatile(DS_MAX_STR ::"v"(row_addr(fourp, e)), "a"(acc[C::NTW - 1][e]), "n"((C::NTW - 1) * 128) : "memory");
                         }
-                        acc[C::NTW - 1] = MFMA16(a_hi, w_hi[C::NTW - 1][0], kZero16);
+                        mfma_w(acc[C::NTW - 1], a_hi, w_hi[C::NTW - 1][0], w_in_agpr(false, 0), true);
                     } else {
 #pragma unroll
-                        for (int nt = 0; nt < C::NTW; nt++) acc[nt] = MFMA16(a_hi, w_hi[nt][s], acc[nt]);
+                        for (int nt = 0; nt < C::NTW; nt++) mfma_w(acc[nt], a_hi, w_hi[nt][s], w_in_agpr(false, s), false);
                     }
                     SB();
                     uint32_t nh[4], nl[4];
@@ -428,8 +464,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                             if (c == 6) brow_n = (uint32_t)C::BT_OFF + ((m_nxt >> 8) & 127u) * (uint32_t)C::BT_STRIDE + (uint32_t)(h * 32);
                         }
                         if ((s & 1) && (c & 1)) dma_piece(vn, s >> 1, c >> 1);   // refill of slot (s - 1) / 2, emptied in step s - 1
-                        if (c < 4) acc[c] = MFMA16(a_hi, w_lo[c][s], acc[c]);
-                        else acc[c - 4] = MFMA16(a_lo, w_hi[c - 4][s], acc[c - 4]);
+                        if (c < 4) mfma_w(acc[c], a_hi, w_lo[c][s], w_in_agpr(true, s), false);
+                        else mfma_w(acc[c - 4], a_lo, w_hi[c - 4][s], w_in_agpr(false, s), false);
                         SB();
                     }
                     a_hi = __builtin_bit_cast(half8, u32x4{nh[0], nh[1], nh[2], nh[3]});
@@ -451,9 +487,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
 #pragma unroll
                     for (int i = 0; i < 3 * C::NTW; i++) {
                         const int nt = i / 3, k = i % 3;
-                        if (k == 0) acc[nt] = MFMA16(a_hi, w_hi[nt][s], acc[nt]);
-                        else if (k == 1) acc[nt] = MFMA16(a_hi, w_lo[nt][s], acc[nt]);
-                        else acc[nt] = MFMA16(a_lo, w_hi[nt][s], acc[nt]);
+                        if (k == 0) mfma_w(acc[nt], a_hi, w_hi[nt][s], w_in_agpr(false, s), false);
+                        else if (k == 1) mfma_w(acc[nt], a_hi, w_lo[nt][s], w_in_agpr(true, s), false);
+                        else mfma_w(acc[nt], a_lo, w_hi[nt][s], w_in_agpr(false, s), false);
                         if (i < 4) {
 #pragma unroll
                             for (int e = 4 * i; e < 4 * i + 4; e++) ad[e] = row_addr(four, e);

@@ -19,6 +19,11 @@ namespace t2p {
 
 namespace {
 
+// T2P_FPS_PK: the distance pass of the production FPS / ball-query loop on packed fp32 operations (A/B switch; same bits either way)
+#ifndef T2P_FPS_PK
+#define T2P_FPS_PK 1
+#endif
+
 constexpr int kMaxPts = 256;
 constexpr int kMaxNbr = 32;
 
@@ -191,11 +196,34 @@ __device__ void level_fast(const float* px, const float* py, const float* pz, in
         }
         float d[PPL];
         unsigned long long m[PPL];
+        if constexpr (T2P_FPS_PK && PPL % 2 == 0) {
+            // the same eight IEEE operations per point as dist2(), two points per instruction (v_pk_add_f32 / v_pk_mul_f32 are
+            // plain single-precision adds / multiplies on a register pair, un-contracted like the scalar form: same bits as
+            // oracle/primitives.c:35-40) - the scan is bound by VALU issue, and this is 16 of its ~85 instructions per step
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            d[j] = dist2(x[j], y[j], z[j], cx, cy, cz);
-            mind[j] = min(mind[j], __float_as_uint(d[j]));   // one v_min_u32 (a float compare + select takes two and an s_nop)
-            m[j] = __ballot(d[j] < r2);
+            for (int j = 0; j < PPL; j += 2) {
+#pragma clang fp contract(off)
+                const f32x2 dx = f32x2{x[j], x[j + 1]} - c2x, dy = f32x2{y[j], y[j + 1]} - c2y, dz = f32x2{z[j], z[j + 1]} - c2z;
+                const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                const f32x2 sxy = xx + yy;
+                const f32x2 dd = sxy + zz;
+                d[j] = dd[0];
+                d[j + 1] = dd[1];
+            }
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                mind[j] = min(mind[j], __float_as_uint(d[j]));
+                m[j] = __ballot(d[j] < r2);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                d[j] = dist2(x[j], y[j], z[j], cx, cy, cz);
+                mind[j] = min(mind[j], __float_as_uint(d[j]));   // one v_min_u32 (a float compare + select takes two and an s_nop)
+                m[j] = __ballot(d[j] < r2);
+            }
         }
         int lower = 0, count = 0;
 #pragma unroll

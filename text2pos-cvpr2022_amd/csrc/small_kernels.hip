@@ -143,7 +143,10 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int di
 // Linear+BN+ReLU, then F.normalize.  A block owns 32 objects: the hidden layer goes to LDS, every thread then owns one
 // (or two) output columns for all 32 objects, so a W2 element is fetched once per 32 objects (one wave per object
 // re-read the whole 64 x D matrix per object: 12 GB of L2 traffic per call at 192 k objects).
-constexpr int kMlp3Rows = 32;
+// ROWS = 32 for large batches; 8 for small ones (round 6): a thread's 64-step fma chain per row is serial, so a block of 32 rows takes
+// ~32 us whatever the batch, and a 1,000-object call (the reference's 64-cell batches) filled 31 of the 256 CUs with it.  The
+// summation order of an output does not depend on ROWS: same bits.
+template <int kMlp3Rows>
 __global__ __launch_bounds__(256) void k_mlp3_norm(const float* __restrict__ in3, int64_t n_rows,
                                                    const float* __restrict__ w1, const float* __restrict__ b1,
                                                    const float* __restrict__ w2, const float* __restrict__ b2, int D,
@@ -563,8 +566,12 @@ int launch_mlp3_norm(const float* in3, int64_t n_rows, const float* w1, const fl
     T2P_CHECK_ARG(D % 64 == 0 && D <= 512, "mlp3_norm: D=%d must be a multiple of 64, <= 512", D);
     if (n_rows == 0) return 0;
     ProfScope ps_("mlp3_norm", st);
-    hipLaunchKernelGGL(k_mlp3_norm, dim3((unsigned)((n_rows + kMlp3Rows - 1) / kMlp3Rows)), dim3(256), 0, st, in3, n_rows, w1, b1, w2, b2, D,
-                       out, ld_out, col0);
+    if (n_rows >= 16384)
+        hipLaunchKernelGGL(k_mlp3_norm<32>, dim3((unsigned)((n_rows + 31) / 32)), dim3(256), 0, st, in3, n_rows, w1, b1, w2, b2, D, out, ld_out,
+                           col0);
+    else
+        hipLaunchKernelGGL(k_mlp3_norm<8>, dim3((unsigned)((n_rows + 7) / 8)), dim3(256), 0, st, in3, n_rows, w1, b1, w2, b2, D, out, ld_out,
+                           col0);
     T2P_CHECK_LAUNCH("mlp3_norm");
     return 0;
 }

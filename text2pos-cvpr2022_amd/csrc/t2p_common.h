@@ -56,6 +56,19 @@ __device__ __forceinline__ t2p_fp16x2 cvt_pk_f16(float a, float b) {
     return __builtin_bit_cast(t2p_fp16x2, __builtin_convertvector((f32x2_){a, b}, h16x2_));
 #endif
 }
+// Low piece of the f16x3 split of a pair: fp16(v0 - hi[0]) | fp16(v1 - hi[1]) << 16, the two differences formed exactly in fp32
+// by v_fma_mix_f32 (hi half extended, times -1, plus v).  ONE asm statement: behind a stand-alone inline-asm v_fma_mix hipcc puts an
+// s_nop in front of the dependent v_cvt_pk (it cannot see that the asm writes whole dwords) - one wait state per pair, in the
+// staging arithmetic that rides beside the MFMA stream of the SA kernels.
+__device__ __forceinline__ uint32_t split_lo_pk(t2p_fp16x2 hi, float v0, float v1) {
+    uint32_t lo;
+    float t0, t1;
+    asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %0, %1, %2"
+        : "=v"(lo), "=&v"(t0), "=&v"(t1) : "v"(hi), "v"(v0), "v"(v1));
+    return lo;
+}
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 int num_cus();  // cached multiProcessorCount of the current device
