@@ -12,17 +12,17 @@
 //
 //   * one workgroup (4 waves) per CU walks a balanced contiguous object range; the tiles of an object go round-robin to
 //     the waves, the object's max-accumulator [n_cent][C] and centroid table B_i = W1p pos_i [n_cent][H] live in LDS;
-//   * ring of 4 slots x 4 KB per wave = one whole tile of prefetch: slot u holds the 128-byte pieces (k = 32 u .. 32 u + 31)
-//     of the tile's 32 rows, 8 rows x 128 B per DMA instruction (full cache lines), XOR-swizzled on the SOURCE address so
-//     that the lane-linear LDS image is read conflict-free with ds_read_b128; counted s_waitcnt vmcnt(12) (three slots stay
-//     in flight), never vmcnt(0) inside the stream;
-//   * everything a wave loads travels by LDS-DMA (row lists and centroid positions of the objects ahead included): an
-//     ordinary VGPR load beside outstanding DMAs would make hipcc drain the whole ring at its first use;
+//   * (rounds 3-5; still built with -DT2P_ROWS_DIRECT=0) ring of 4 slots x 4 KB per wave = one whole tile of prefetch: slot u holds
+//     the 128-byte pieces (k = 32 u .. 32 u + 31) of the tile's 32 rows, 8 rows x 128 B per DMA instruction, XOR-swizzled on the SOURCE
+//     address so that the lane-linear LDS image is read conflict-free with ds_read_b128; counted s_waitcnt vmcnt(8), never vmcnt(0)
+//     inside the stream.  Round 6 (default): every lane loads its own operand bytes straight into registers - T2P_ROWS_DIRECT below;
+//   * the row lists and centroid positions of the objects ahead travel by LDS-DMA;
 //   * natural k order (lane half h owns k = 16 s + 8 h .. + 7 of MFMA step s): the host's register-order weight image is
 //     re-indexed at load time; every fp32 accumulation runs hi.hi, hi.lo, lo.hi per step like ws_sa2.hip, with another
 //     grouping of the k's (results agree to fp32 rounding, not bit for bit).
 // T2P_RABL (development only, results are wrong): 1 = no ring DMA, 2 = no atomics, 4 = no drain stores / table build,
-// 8 = no MFMAs (first and last of a step kept), 16 = no object barriers
+// 8 = no MFMAs (first and last of a step kept), 16 = no object barriers.  An ablation that leaves ZEROS where data was also lowers the
+// matrix pipe's power and with it the time of this kernel and of those behind it: read the table with that in mind.
 #ifndef T2P_RABL
 #define T2P_RABL 0
 #endif
@@ -49,6 +49,33 @@ typedef const __attribute__((address_space(1))) void gl_void;
 #ifndef T2P_ROWS_AGPR
 #define T2P_ROWS_AGPR 1
 #endif
+// T2P_ROWS_DIRECT (round 6): the tile's rows no longer travel through an LDS ring.  The ring (global_load_lds pieces of 8 rows x
+// 128 B, read back with ds_read_b128) cost ~60 cycles of issue per piece among the MFMAs of a one-wave SIMD - 16 pieces per tile, 2.1 ms
+// of SA2's 19.2 ms per step by ablation (profiles/r06_d_sa2_ablation.txt), 4.5 ms of the step through the power cap.  The MFMA A operand
+// of lane (h, rr) is 32 contiguous bytes of ITS OWN row rr per step (k = 16 s + 8 h .. + 7): each lane now fetches exactly those with two
+// global_load_dwordx4 per step from `row base + 64 s + 32 h` into a window of registers (the registers the AGPR-resident weights
+// freed).  No ring slots, no ds_bpermute address shuffle, no M0 writes, and the 64 KB of ring leave LDS.
+// The loads are ordinary loads, so hipcc places the waits - and across the tile loop's back edge it only ever waits for ALL outstanding
+// loads (vmcnt(0)) at the first use of a batch.  The schedule is built around that: two bursts of eight loads per tile, each issued
+// right BEHIND a wait and used three to four steps (>= 2,000 cycles) later, so that a wait never finds a young load outstanding:
+//   burst Y(t)   = steps 5, 6, 7 of tile t and step 0 of tile t + 1, issued in steps 0 - 1 of tile t, first used in step 4
+//   burst X(t+1) = steps 1 - 4 of tile t + 1,                        issued in steps 4 - 5 of tile t, first used in step 0 of tile t + 1
+// (the conversion of step s + 1 runs inside step s; step 0 of a tile inside its predecessor's last step).
+// Measured (three interleaved A/B pairs, profiles/r06_f_ab_direct.txt): 19.2-19.3 ms per step against 19.6-19.8 with the ring (-2 %) for
+// 630 instead of 818 instructions per tile - and exactly as much with the same loads as inline asm under the ring's counted waits
+// (vmcnt(8), 6-7 steps of prefetch): neither instruction issue nor prefetch depth is what the rows cost, the bytes are.  (The
+// "no ring DMA" ablation's 2.1 ms was mostly its all-zero operands: zeros cost the matrix pipe less power.)
+#ifndef T2P_ROWS_DIRECT
+#define T2P_ROWS_DIRECT 1
+#endif
+// load issued behind conversion chunk c of step s (S16 = 8 steps): 2 L + j = piece j of logical step L (L >= 8: next tile), or -1
+__device__ __forceinline__ constexpr int rows_load_slot(int s, int c) {
+    if (s == 0) return c == 0 || c == 4 ? -1 : 10 + (c < 4 ? c - 1 : c - 2);      // c = 1,2,3,5,6,7 -> steps 5, 6, 7
+    if (s == 1) return c == 1 ? 16 : (c == 3 ? 17 : -1);                          // next tile's step 0 (its row offset exists from step 0 on)
+    if (s == 4) return (c & 1) ? 18 + (c >> 1) : -1;                              // c = 1,3,5,7 -> next tile's steps 1, 2
+    if (s == 5) return (c & 1) ? 22 + (c >> 1) : -1;                              //             -> next tile's steps 3, 4
+    return -1;
+}
 constexpr int WA_HI_STEPS = 3;     // AGPR budget: 64 accumulator registers + 128 (lo plane) + 16 * WA_HI_STEPS (hi plane) <= 256
 __device__ __forceinline__ constexpr bool w_in_agpr(bool lo_plane, int s) { return lo_plane || s < WA_HI_STEPS; }
 // c (+)= a x w on v_mfma_f32_32x32x16_f16; `agpr`: where w lives; `zero`: start from 0 (inline constant) instead of c
@@ -97,7 +124,7 @@ struct RowsCfg {
     static constexpr int SB_OFF = NR_OFF + kSubR * 2;
     static constexpr int DSTL_OFF = SB_OFF + kSubR * 4;
     static constexpr int RING_OFF = (DSTL_OFF + NW * 64 + 1023) / 1024 * 1024;
-    static constexpr size_t lds_bytes() { return (size_t)RING_OFF + (size_t)NW * RING_BYTES; }
+    static constexpr size_t lds_bytes() { return (size_t)RING_OFF + (T2P_ROWS_DIRECT ? (size_t)0 : (size_t)NW * RING_BYTES); }
     static_assert(K % 32 == 0 && N % 32 == 0 && NC % 64 == 0 && (NC * N / 4) % NT == 0, "shape");
     static_assert(SLOTS == 4, "the counted waits below assume four ring slots per tile (K = 128)");
 };
@@ -280,6 +307,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
 #pragma unroll
             for (int q = 0; q < 4; q++) dma_piece(voff, u, q);
         };
+#if T2P_ROWS_DIRECT
+        // direct operand loads: lane (h, rr) reads bytes [64 s + 32 h, + 32) of its own row rr
+        constexpr int AHEAD = 5;                       // steps between a load and its use (the window holds AHEAD x 8 registers)
+        const uint32_t hoff = (uint32_t)(h * 32);
+        auto load_half = [&](uint32_t roff, int s_, int j, f32x4 (&x)[2]) {
+            if constexpr (!(T2P_RABL & 1)) x[j] = *(const f32x4*)((const char*)p.A + (size_t)roff + (size_t)(s_ * 64 + j * 16));
+        };
+        auto load_step = [&](uint32_t roff, int s_, f32x4 (&x)[2]) {
+            load_half(roff, s_, 0, x);
+            load_half(roff, s_, 1, x);
+        };
+#endif
 
         // ---- per-object phases --------------------------------------------------------------------------------------------
         auto flush = [&](int g) {   // accumulator -> output rows of object g: relu(max + bias); leaves the accumulator at -inf
@@ -332,6 +371,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
 
         bool cur_fetched = false;        // the four slots of this wave's next tile (first of object gi) are in flight / landed
         uint32_t m_cur = 0;              // ... and this is the metadata of the lane's row of it
+#if T2P_ROWS_DIRECT
+        uint32_t roff_cur = 0;           // ... its byte offset in p.A (+ the lane half's 32 bytes)
+        f32x4 xw[C::S16][2];             // rolling window of operand pieces: xw[s] = step s of the tile that needs it next
+#pragma unroll
+        for (int s0 = 0; s0 < C::S16; s0++) xw[s0][0] = xw[s0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 
         for (int gi = 0; gi < cnt; gi++) {
             // ---- tiles of object gi that belong to this wave -------------------------------------------------------------
@@ -342,18 +387,81 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
             bool have = r0 < n_g;
             const bool did_tile = have;
             half8 a_hi, a_lo;
-            bool prepped = false;    // a_hi / a_lo hold step 0 of the current tile
             f32x16 acc[C::NTW];
             bool pend = false;       // the last result block of the previous tile still waits for its atomics (rows: fourp)
             uint2 fourp[4] = {};
-            while (have) {
+            // ---- the wave's first tile of this object: fetched here unless the previous object's last tile already prefetched it; its step 0
+            // is converted here.  (Both used to sit inside the tile loop behind `!cur_fetched` / `!prepped`; they are first-iteration-only,
+            // and with ordinary loads in flight hipcc's waitcnt pass merged their register state into every iteration.)
+            auto read_step = [&](int s, uint32_t brow_, f32x4 (&x)[2], f32x4 (&b)[2]) {
+#if T2P_ROWS_DIRECT
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    x[j] = xw[s][j];                      // fetched AHEAD steps ago (a register rename: the loops are unrolled)
+                    b[j] = *(const f32x4*)(lds + brow_ + s * 64 + j * 16);
+                }
+#else
+                const int u = s >> 1, par = s & 1;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    x[j] = *(const f32x4*)(lds + rd[par][j] + u * C::SLOT_BYTES);
+                    b[j] = *(const f32x4*)(lds + brow_ + s * 64 + j * 16);
+                }
+#endif
+            };
+            // conversion of one step's 8 values in 8 half-chunks of 4 VALU operations (pair pr = values 2 pr, 2 pr + 1):
+            // first half v = relu(x - b), second half hi = fp16(v) to nearest, lo = fp16(v - hi)
+            auto prep_a = [&](int pr, const f32x4 (&x)[2], const f32x4 (&b)[2], float (&v)[2]) {
+                const int j = pr >> 1, e0 = (pr & 1) * 2;
+                v[0] = fmaxf(x[j][e0] - b[j][e0], 0.f);
+                v[1] = fmaxf(x[j][e0 + 1] - b[j][e0 + 1], 0.f);
+            };
+            auto prep_b = [&](const float (&v)[2], uint32_t& wh, uint32_t& wl) {
+                const fp16x2 hh = cvt_pk_f16(v[0], v[1]);
+                wh = __builtin_bit_cast(uint32_t, hh);
+#if T2P_ROWS_AGPR
+                wl = split_lo_pk(hh, v[0], v[1]);      // (one asm statement: t2p_common.h)
+#else
+                const fp16x2 ll = cvt_pk_f16(sub_half_r<0>(v[0], hh), sub_half_r<1>(v[1], hh));
+                wl = __builtin_bit_cast(uint32_t, ll);
+#endif
+            };
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            auto row_addr = [&](const uint2 (&f4)[4], int e) -> uint32_t {
+                const uint32_t pair = (e & 2) ? f4[e >> 2].y : f4[e >> 2].x;
+                return (uint32_t)(C::ACC_OFF + rr * 4) + ((e & 1) ? (pair >> 16) : (pair & 0xFFFFu));
+            };
+
+            if (have) {
                 if (!cur_fetched) {
                     m_cur = tile_meta(gi, r0, n_g);
+#if T2P_ROWS_DIRECT
+                    roff_cur = row_byte(gi, sb_g, m_cur) + hoff;
+#pragma unroll
+                    for (int s0 = 0; s0 < AHEAD; s0++) load_step(roff_cur, s0, xw[s0]);
+#else
                     uint32_t v0[4];
                     tile_voff(row_byte(gi, sb_g, m_cur), v0);
 #pragma unroll
                     for (int u = 0; u < C::SLOTS; u++) issue_slot(v0, u);
+#endif
                 }
+                {   // step 0 of the wave's first tile in this object: converted here, every later tile's step 0 inside its predecessor's last step
+                    if constexpr (!T2P_ROWS_DIRECT) wait_ring();
+                    f32x4 x[2], b[2];
+                    read_step(0, (uint32_t)C::BT_OFF + ((m_cur >> 8) & 127u) * (uint32_t)C::BT_STRIDE + (uint32_t)(h * 32), x, b);
+                    uint32_t nh[4], nl[4];
+#pragma unroll
+                    for (int pr = 0; pr < 4; pr++) {
+                        float v[2];
+                        prep_a(pr, x, b, v);
+                        prep_b(v, nh[pr], nl[pr]);
+                    }
+                    a_hi = __builtin_bit_cast(half8, u32x4{nh[0], nh[1], nh[2], nh[3]});
+                    a_lo = __builtin_bit_cast(half8, u32x4{nl[0], nl[1], nl[2], nl[3]});
+                }
+            }
+            while (have) {
                 // look ahead: the next tile is prefetched while this one is multiplied, if its row list is in LDS already
                 // (same object or the next one); otherwise the same addresses are fetched again to keep the DMA count of the
                 // counted waits (the slot is dead by then)
@@ -366,6 +474,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                 // its metadata: the LDS read is issued here, decoded inside step 0
                 uint32_t m_nxt = tile_meta(gi_n, r0_n, n_n);
                 uint32_t vn[4];
+#if T2P_ROWS_DIRECT
+                uint32_t roff_n = roff_cur;
+                (void)vn;
+#endif
                 // this tile: centroid of the lane's row -> table row, accumulator row
                 const uint32_t dl = (m_cur >> 8) & 127u;
                 const uint32_t brow = (uint32_t)C::BT_OFF + dl * (uint32_t)C::BT_STRIDE + (uint32_t)(h * 32);
@@ -374,51 +486,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                 asm volatile("ds_write_b16 %0, %1" ::"v"(dstl_addr + (uint32_t)(rr * 2)), "v"(dl * (uint32_t)(N * 4)) : "memory");
                 uint2 four[4];   // accumulator-row byte offsets of this lane's 16 result rows 8 q + 4 h + {0..3} (fetched in step 6)
 
-                auto read_step = [&](int s, uint32_t brow_, f32x4 (&x)[2], f32x4 (&b)[2]) {
-                    const int u = s >> 1, par = s & 1;
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        x[j] = *(const f32x4*)(lds + rd[par][j] + u * C::SLOT_BYTES);
-                        b[j] = *(const f32x4*)(lds + brow_ + s * 64 + j * 16);
-                    }
-                };
-                // conversion of one step's 8 values in 8 half-chunks of 4 VALU operations (pair pr = values 2 pr, 2 pr + 1):
-                // first half v = relu(x - b), second half hi = fp16(v) to nearest, lo = fp16(v - hi)
-                auto prep_a = [&](int pr, const f32x4 (&x)[2], const f32x4 (&b)[2], float (&v)[2]) {
-                    const int j = pr >> 1, e0 = (pr & 1) * 2;
-                    v[0] = fmaxf(x[j][e0] - b[j][e0], 0.f);
-                    v[1] = fmaxf(x[j][e0 + 1] - b[j][e0 + 1], 0.f);
-                };
-                auto prep_b = [&](const float (&v)[2], uint32_t& wh, uint32_t& wl) {
-                    const fp16x2 hh = cvt_pk_f16(v[0], v[1]);
-                    wh = __builtin_bit_cast(uint32_t, hh);
-#if T2P_ROWS_AGPR
-                    wl = split_lo_pk(hh, v[0], v[1]);      // (one asm statement: t2p_common.h)
-#else
-                    const fp16x2 ll = cvt_pk_f16(sub_half_r<0>(v[0], hh), sub_half_r<1>(v[1], hh));
-                    wl = __builtin_bit_cast(uint32_t, ll);
-#endif
-                };
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                auto row_addr = [&](const uint2 (&f4)[4], int e) -> uint32_t {
-                    const uint32_t pair = (e & 2) ? f4[e >> 2].y : f4[e >> 2].x;
-                    return (uint32_t)(C::ACC_OFF + rr * 4) + ((e & 1) ? (pair >> 16) : (pair & 0xFFFFu));
-                };
-
-                if (!prepped) {   // step 0 of this tile (first tile of an object, or a tile that was not prefetched)
-                    wait_ring();
-                    f32x4 x[2], b[2];
-                    read_step(0, brow, x, b);
-                    uint32_t nh[4], nl[4];
-#pragma unroll
-                    for (int pr = 0; pr < 4; pr++) {
-                        float v[2];
-                        prep_a(pr, x, b, v);
-                        prep_b(v, nh[pr], nl[pr]);
-                    }
-                    a_hi = __builtin_bit_cast(half8, u32x4{nh[0], nh[1], nh[2], nh[3]});
-                    a_lo = __builtin_bit_cast(half8, u32x4{nl[0], nl[1], nl[2], nl[3]});
-                }
                 uint32_t brow_n = 0;
 
                 // ---- steps 0 .. S16-2: [reads of step s+1] [4 MFMAs hi.hi] [8 x (half-chunk of the conversion, 1 MFMA)] --------
@@ -428,7 +495,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
 #pragma unroll
                 for (int s = 0; s < C::S16 - 1; s++) {
                     f32x4 x[2], b[2];
-                    if (((s + 1) & 1) == 0) wait_ring();      // first step of the next slot
+                    if (!T2P_ROWS_DIRECT && ((s + 1) & 1) == 0) wait_ring();      // first step of the next slot
                     read_step(s + 1, brow, x, b);
                     if (s == C::S16 - 2) {
                         const uint32_t a4 = dstl_addr + (uint32_t)(h * 8);
@@ -460,10 +527,21 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                         else prep_b(v, nh[c >> 1], nl[c >> 1]);
                         if (s == 0) {          // next tile: row offset of the lane's row, the rows of every DMA lane, table row
                             if (c == 2) rowbyte_n = row_byte(gi_n, sb_n, m_nxt);
+#if T2P_ROWS_DIRECT
+                            if (c == 4) roff_n = rowbyte_n + hoff;
+#else
                             if (c == 4) tile_voff(rowbyte_n, vn);
+#endif
                             if (c == 6) brow_n = (uint32_t)C::BT_OFF + ((m_nxt >> 8) & 127u) * (uint32_t)C::BT_STRIDE + (uint32_t)(h * 32);
                         }
+#if T2P_ROWS_DIRECT
+                        {   // this chunk's load, if the schedule has one (rows_load_slot): at most one per MFMA gap
+                            const int ld = rows_load_slot(s, c);
+                            if (ld >= 0) load_half(ld < 2 * C::S16 ? roff_cur : roff_n, (ld >> 1) % C::S16, ld & 1, xw[(ld >> 1) % C::S16]);
+                        }
+#else
                         if ((s & 1) && (c & 1)) dma_piece(vn, s >> 1, c >> 1);   // refill of slot (s - 1) / 2, emptied in step s - 1
+#endif
                         if (c < 4) mfma_w(acc[c], a_hi, w_lo[c][s], w_in_agpr(true, s), false);
                         else mfma_w(acc[c - 4], a_lo, w_hi[c - 4][s], w_in_agpr(false, s), false);
                         SB();
@@ -476,7 +554,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                     constexpr int s = C::S16 - 1;
                     f32x4 x[2], b[2];
                     if (chain) {
-                        wait_ring();                             // slot 0 of the next tile
+                        if constexpr (!T2P_ROWS_DIRECT) wait_ring();     // slot 0 of the next tile
                         read_step(0, brow_n, x, b);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(four[0]), "+v"(four[1]), "+v"(four[2]), "+v"(four[3])::"memory");
@@ -498,7 +576,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                             if ((i & 1) == 0) prep_a(i >> 1, x, b, v);
                             else prep_b(v, nh[i >> 1], nl[i >> 1]);
                         }
+#if !T2P_ROWS_DIRECT
                         if (i < 8 && (i & 1)) dma_piece(vn, s >> 1, i >> 1);      // refill of the last slot
+#endif
                         // block nb = (i - 4) / 3 is complete two MFMAs before chunk i = 3 nb + 4: 8 atomics here, 8 in the next chunk
                         if (i >= 4 && ((i - 4) % 3) < 2 && (i - 4) / 3 < C::NTW - 1) {
                             const int nb = (i - 4) / 3, e0 = ((i - 4) % 3) * 8;
@@ -522,11 +602,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                         pend = false;
                     }
                 }
-                prepped = chain;
                 have = chain;
                 r0 = r0_n;
                 cur_fetched = nxt_ok;
                 m_cur = m_nxt;
+#if T2P_ROWS_DIRECT
+                roff_cur = roff_n;
+#endif
             }
             if (!did_tile) cur_fetched = false;
             // ---- object gi is complete for this wave ------------------------------------------------------------------------
