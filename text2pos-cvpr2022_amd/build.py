@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libt2p_hip.so")
-SOURCES = ["api.hip", "sample_group.hip", "small_kernels.hip", "tg_gemm.hip", "tg_gemm_tn.hip", "tg_gemm_x3.hip", "train_gemm.hip", "ws_gemm.hip", "ga2.hip", "ws_sa.hip", "sa_rows.hip", "sa2p.hip", "sa3.hip", "sa_points.hip", "lstm.hip", "train_ops.hip", "sim_topk.hip", "match.hip"]
+SOURCES = ["api.hip", "sample_group.hip", "small_kernels.hip", "tg_gemm.hip", "tg_gemm_tn.hip", "tg_gemm_x3.hip", "train_gemm.hip", "ws_gemm.hip", "ga2.hip", "ws_sa.hip", "sa_rows.hip", "sa3.hip", "sa_points.hip", "lstm.hip", "train_ops.hip", "sim_topk.hip", "match.hip"]
 HEADERS = [os.path.join(CSRC, "t2p_common.h"), os.path.join(HERE, "..", "include", "t2p.h")]
 # -ffp-contract=off: the index-producing kernels (FPS, ball query, kNN) pin their fp32 distance arithmetic to the
 # oracle's un-contracted form; fused multiply-adds are written explicitly (fmaf / MFMA) where they are wanted.

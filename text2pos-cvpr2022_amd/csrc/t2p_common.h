@@ -331,11 +331,6 @@ int sa_rows_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
 bool sa_points_selected(int H, int C, const SaParams& p);
 int launch_sa_points(int H, int C, const SaParams& p, hipStream_t st);
 int sa_points_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
-// sa2p.hip: SA level 2 in sa3.hip's organisation (row pairs per staging load); selected instead of sa_rows.hip when built with
-// -DT2P_SA2_PAIRS=1 (A/B switch)
-bool sa2p_selected(int H, int C, const SaParams& p);
-int launch_sa2p(const SaParams& p, hipStream_t st);
-int sa2p_launch_shape(int64_t n_obj, int* tile_rows, int* n_wg);
 // sa3.hip: SA level 3 (H = C = 256, LDS centroid table), column-slice waves with scalar per-row control
 bool sa3_selected(int H, int C, const SaParams& p);
 int launch_sa3(const SaParams& p, hipStream_t st);

@@ -368,7 +368,6 @@ int launch_sa_balance(const SaParams& p, int tile_rows, int n_wg, hipStream_t st
 
 // tile rows / workgroup count of the kernel launch_ws_sa will pick for (H, Cout)
 static int sa_launch_shape(int H, int Cout, const SaParams& p, int64_t n_obj, int* tile_rows, int* n_wg) {
-    if (sa2p_selected(H, Cout, p)) return sa2p_launch_shape(n_obj, tile_rows, n_wg);
     if (sa_rows_selected(H, Cout, p)) return sa_rows_launch_shape(n_obj, tile_rows, n_wg);
     if (sa_points_selected(H, Cout, p)) return sa_points_launch_shape(n_obj, tile_rows, n_wg);
     if (sa3_selected(H, Cout, p)) return sa3_launch_shape(n_obj, tile_rows, n_wg);
@@ -406,7 +405,6 @@ int launch_ws_sa(int H, int Cout, const SaParams& p, hipStream_t st) {
     T2P_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.Bc) & 15) == 0, "ws_sa: tables must be 16-byte aligned");
     if (p.W_x3 != nullptr) {  // f16x3 split-precision path: one kernel per level
         T2P_CHECK_ARG(((uintptr_t)p.W_x3 & 15) == 0, "ws_sa: packed f16x3 weights must be 16-byte aligned");
-        if (sa2p_selected(H, Cout, p)) return launch_sa2p(p, st);
         if (sa_rows_selected(H, Cout, p)) return launch_sa_rows(H, Cout, p, st);
         if (sa_points_selected(H, Cout, p)) return launch_sa_points(H, Cout, p, st);
         if (sa3_selected(H, Cout, p)) return launch_sa3(p, st);
