@@ -936,3 +936,54 @@ def test_bench_oracle_full_check_machinery(oracle_model):
     # chunk-local neighbour rows -> global rows
     g = bench.global_knn(np.array([[0, 1], [1, -1], [0, 1], [1, 0]]), np.array([0, 2, 4]), chunk_objects=2)
     assert g.tolist() == [[0, 1], [1, -1], [2, 3], [3, 2]]
+
+
+def test_sa_rows_inline_asm_mfmas_keep_their_distance_from_valu_writes():
+    """k_sa_rows issues its MFMAs as inline asm (their weight operands live in AGPRs), which hipcc's hazard recogniser does not see as
+    MFMAs: gfx950 needs two wait states between a VALU write of a VGPR and an MFMA that reads it as A / B operand, and only the
+    source's structure provides them.  Compile the file for gfx950 and check the generated code: no VALU instruction writes a register
+    that an MFMA reads within the next two issue slots (an s_nop in between counts for its wait states)."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "text2pos-cvpr2022_amd", "csrc", "sa_rows.hip")
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "sa_rows.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S", src, "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read().split("\n")
+    st = [i for i, l in enumerate(text) if re.match(r"^_Z\w+:", l) and "k_sa_rows" in l][0]
+    fe = next(i for i in range(st, len(text)) if text[i].startswith(".Lfunc_end"))
+    ops = [l.strip() for l in text[st + 1: fe] if l.strip() and not l.strip().startswith((";", ".")) and not l.strip().endswith(":")]
+
+    def regs(tok):
+        tok = tok.strip()
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+    n_mfma, close = 0, []
+    for i, o in enumerate(ops):
+        if not o.startswith("v_mfma"):
+            continue
+        n_mfma += 1
+        parts = [p.strip() for p in o.split(None, 1)[1].split(",")]
+        src_regs = regs(parts[1]) | regs(parts[2])
+        states = 0
+        for j in range(i - 1, max(i - 4, -1), -1):
+            p = ops[j]
+            if p.startswith("s_nop"):
+                states += int(p.split()[1]) + 1
+                continue
+            if states >= 2:
+                break
+            if p.startswith("v_") and not p.startswith(("v_mfma", "v_cmp")) and regs(p.split(None, 1)[1].split(",")[0]) & src_regs:
+                close.append((states, p, o))
+                break
+            states += 1
+    assert n_mfma == 96, n_mfma
+    assert not close, close[:3]

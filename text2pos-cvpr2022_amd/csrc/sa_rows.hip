@@ -76,9 +76,17 @@ __device__ __forceinline__ constexpr int rows_load_slot(int s, int c) {
     if (s == 5) return (c & 1) ? 22 + (c >> 1) : -1;                              //             -> next tile's steps 3, 4
     return -1;
 }
-constexpr int WA_HI_STEPS = 3;     // AGPR budget: 64 accumulator registers + 128 (lo plane) + 16 * WA_HI_STEPS (hi plane) <= 256
+#ifndef T2P_WA_HI_STEPS
+#define T2P_WA_HI_STEPS 3
+#endif
+constexpr int WA_HI_STEPS = T2P_WA_HI_STEPS;     // AGPR budget: 64 accumulator registers + 128 (lo plane) + 16 * WA_HI_STEPS (hi plane) <= 256
 __device__ __forceinline__ constexpr bool w_in_agpr(bool lo_plane, int s) { return lo_plane || s < WA_HI_STEPS; }
-// c (+)= a x w on v_mfma_f32_32x32x16_f16; `agpr`: where w lives; `zero`: start from 0 (inline constant) instead of c
+// c (+)= a x w on v_mfma_f32_32x32x16_f16; `agpr`: where w lives; `zero`: start from 0 (inline constant) instead of c.
+// HAZARD the compiler cannot see here: an MFMA must not read, as its A / B operand, a VGPR that a VALU instruction wrote less than two
+// issue slots earlier (t2p_common.h, split_lo_pk).  The A operands of step s + 1 are assembled at the END of step s and first multiplied
+// behind the centroid-table reads that open step s + 1 (>= 2 instructions, pinned by the sched_barriers); the last step has no such reads
+// when the tile does not chain, so it opens with an explicit s_nop 1.  tests/test_host.py compiles this file and checks the distance
+// in the generated code.
 __device__ __forceinline__ void mfma_w(f32x16& c, const half8& a, const half8& w, bool agpr, bool zero) {
 #if T2P_ROWS_AGPR
     if (zero) {
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
                         if constexpr (!T2P_ROWS_DIRECT) wait_ring();     // slot 0 of the next tile
                         read_step(0, brow_n, x, b);
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(four[0]), "+v"(four[1]), "+v"(four[2]), "+v"(four[3])::"memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" : "+v"(four[0]), "+v"(four[1]), "+v"(four[2]), "+v"(four[3])::"memory");
                     SB();
                     uint32_t ad[16];
                     uint32_t nh[4], nl[4];

@@ -332,8 +332,11 @@ __device__ __attribute__((noinline)) void emit_point_table(const float* px, cons
 // 6 waves per SIMD (80 registers, some spills) measured fastest: 4 -> 3.26, 5 -> 3.08, 6 -> 2.85, 7 -> 3.5, 8 -> 3.16 ms / 3k cells
 // (FAST form, 12k cells: 5 -> 10.0, 6 -> 9.8, 7 -> 10.2, 8 -> 10.7 ms)
 // FAST: n_pts == 256 (every level fills its lanes), row lists of all levels wanted, no neighbour tables: level_fast
+#ifndef T2P_SG_WAVES
+#define T2P_SG_WAVES 6
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(64, 6) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
+__global__ __launch_bounds__(64, T2P_SG_WAVES) void k_sample_group(const float* __restrict__ xyz, int64_t n_obj, int n_pts,
                                                      float r0, float r1, float r2, GroupTables gt) {
     // dynamic LDS: coordinates of the 4 levels | FPS selection | (only when the neighbour table is wanted: nbr + cnt);
     // 5.9 KB in the production path, so the register count sets the occupancy

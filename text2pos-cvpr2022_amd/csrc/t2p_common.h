@@ -60,13 +60,21 @@ __device__ __forceinline__ t2p_fp16x2 cvt_pk_f16(float a, float b) {
 // by v_fma_mix_f32 (hi half extended, times -1, plus v).  ONE asm statement: behind a stand-alone inline-asm v_fma_mix hipcc puts an
 // s_nop in front of the dependent v_cvt_pk (it cannot see that the asm writes whole dwords) - one wait state per pair, in the
 // staging arithmetic that rides beside the MFMA stream of the SA kernels.
+// CAUTION (round 6, found the hard way): gfx950 needs two wait states between a VALU write of a VGPR and an MFMA that reads it as its
+// A / B operand.  hipcc guarantees them between instructions it KNOWS; an asm statement is one opaque non-VALU instruction to its hazard
+// recogniser, so nothing separates this statement's final v_cvt_pk from an MFMA that consumes `lo` next.  In k_sa_points the merged
+// statement sat one instruction in front of the MFMA that read the four lo registers: SA1 outputs ~1e4 off (libt2p_hip_s1a; a
+// different register assignment, s1b, happened to put two instructions between and passed).  Use it only where the consumer is an LDS /
+// global store (k_sa3) or is provably far away (k_sa_rows: the pieces of step s + 1 are converted during step s and first multiplied in
+// step s + 1, behind an explicit s_nop - see mfma_w there); k_sa_points and k_gemm_x3 keep the separate statements, behind which
+// hipcc's own v_cvt_pk -> MFMA spacing applies.  (`lo` is an early-clobber output as well: it then never shares a register with an input.)
 __device__ __forceinline__ uint32_t split_lo_pk(t2p_fp16x2 hi, float v0, float v1) {
     uint32_t lo;
     float t0, t1;
     asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
         "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
         "v_cvt_pk_f16_f32 %0, %1, %2"
-        : "=v"(lo), "=&v"(t0), "=&v"(t1) : "v"(hi), "v"(v0), "v"(v1));
+        : "=&v"(lo), "=&v"(t0), "=&v"(t1) : "v"(hi), "v"(v0), "v"(v1));
     return lo;
 }
 typedef double f64x4 __attribute__((ext_vector_type(4)));
