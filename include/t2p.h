@@ -155,7 +155,8 @@ typedef struct t2p_cell_config {
     float radius[3];           /* SA ball radii (pointnet2.py:57-59); 0.2, 0.3, 0.4 */
     int32_t chunk_objects;     /* objects processed per internal chunk (whole cells); 0 = T2P_DEFAULT_CHUNK_OBJECTS */
     int32_t precision;         /* 0 = fp32 MFMA (exact fp32 fma chains); 1 = f16x3 split-precision MFMA with fp32
-                                  accumulation (hi.hi + hi.lo + lo.hi), same 1e-4 parity bar, 5.3x the MFMA rate */
+                                  accumulation (hi.hi + hi.lo + lo.hi), same 1e-4 parity bar (for every cell whose DynamicEdgeConv
+                                  kNN graph has no near-tie: DESIGN.md section 2), 5.3x the MFMA rate */
     /* ground-truth embedding ablations (training/args.py:60-61, object_encoder.py:74-84,103-120): when class_embed
      * is set the PointNet++ is skipped and the "class" feature is F.normalize(class_embedding[class_idx]); when
      * color_embed is set the "color" feature is F.normalize(color_embedding[color_idx]).  Index arrays are DEVICE

