@@ -821,7 +821,8 @@ def main():
         per_rank[rank] = torch.tensor(mine, dtype=torch.float64, device=dev)
         dist.all_reduce(per_rank)
         shard_rows = [hi - lo for lo, hi in (TD.shard_range(n_cells_total, r, world) for r in range(world))]
-        exchange = {"collective": "all_gather_into_tensor (RCCL)", "backend": dist.get_backend(),
+        exchange = {"collective": "all_gather_into_tensor (" + ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + ", staged through the host") + ")",
+                    "backend": dist.get_backend(),
                     "world_size": dist.get_world_size(), "bytes_per_rank": int(max(shard_rows) * 256 * 4),
                     "bytes_gathered": int(n_cells_total * 256 * 4),
                     "cells_per_rank": shard_rows if len(set(shard_rows)) > 1 else shard_rows[0],
