@@ -198,7 +198,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
     // The bias is NOT part of the accumulation: a tile's first MFMAs start from 0, the LDS accumulator takes a FLOAT max of the
     // raw products (ds_max_f32 orders negative values correctly) from a -inf start, and the drain forms relu(max + bias).
     // (A bias block as the first MFMA's C operand costs 64 registers of a budget that is full.)
-    constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x4 bias4;         // this thread's four output columns in the drain (column quad = tid % (N / 4))
     {
         const int c4 = tid % (N / 4);
@@ -302,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
             return srow * (uint32_t)(K * 4);
         };
         // ... and of the rows each DMA instruction of a slot fetches
-        auto tile_voff = [&](uint32_t rowbyte, uint32_t (&voff)[4]) {
+        [[maybe_unused]] auto tile_voff = [&](uint32_t rowbyte, uint32_t (&voff)[4]) {   // (ring build only: -DT2P_ROWS_DIRECT=0)
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 voff[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)dma_sel[q], (int)rowbyte) + dma_chunk[q];
@@ -311,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sa_rows(SaParams p) {
             if constexpr (!(T2P_RABL & 1))
                 dma16(p.A, voff[q] + (uint32_t)(u * 128), ringb + (uint32_t)(u * C::SLOT_BYTES + q * 1024));
         };
-        auto issue_slot = [&](const uint32_t (&voff)[4], int u) {
+        [[maybe_unused]] auto issue_slot = [&](const uint32_t (&voff)[4], int u) {
 #pragma unroll
             for (int q = 0; q < 4; q++) dma_piece(voff, u, q);
         };
