@@ -738,7 +738,7 @@ def main():
     h_pinned = [torch.from_numpy(a).pin_memory() for a in (xyz, rgb, center, mean_rgb)] if rank == 0 else None
     del xyz, rgb
 
-    side = torch.cuda.Stream(device=dev)   # the text branch is independent of the cell branch: its (latency-bound)
+    side = ops.concurrent_stream(dev)      # the text branch is independent of the cell branch: its (latency-bound)
                                            # biLSTM runs on a second HIP stream underneath the cell kernels
 
     gather_events = []   # per step: torch events (step begin, exchange begin, exchange end, step end) on the stream the exchange runs on

@@ -1204,6 +1204,39 @@ def test_execution_plans_are_bit_identical(hip_model):
             assert torch.equal(got, out0) and torch.equal(again, got), f"{n} streams"
 
 
+def test_streams_handed_out_run_beside_each_other(hip_model):
+    """HIP maps streams onto a few hardware queues by first use; two streams in one queue serialise and the two-stream encode loses its
+    gain (88.0 -> 90.2 ms per step when the process had used three streams before, profiles/r06_t_stream_queues_ab.txt).
+    ops.concurrent_stream probes for it: whatever the process did before (here: five streams created and used), the stream it hands
+    out overlaps the current stream and the ones it is told to stand beside; the cell encoder's second stream comes from it and is
+    re-picked when the caller's current stream changes."""
+    from text2pos_amd import ops, synthetic as S
+    DEV = _dev()
+    used = [torch.cuda.Stream(device=DEV) for _ in range(5)]
+    for st in used:
+        with torch.cuda.stream(st):
+            torch.zeros(8, device=DEV).add_(1)
+    torch.cuda.synchronize()
+    main = torch.cuda.current_stream(DEV)
+    a = ops.concurrent_stream(DEV)
+    b = ops.concurrent_stream(DEV, [a])
+    assert len({main.cuda_stream, a.cuda_stream, b.cuda_stream}) == 3
+    assert ops.streams_overlap(main, a) and ops.streams_overlap(main, b) and ops.streams_overlap(a, b)
+    assert not ops.streams_overlap(a, a)                       # (the probe itself: one queue -> two spin times)
+    args = _to_dev(*S.make_cells(78, 24)[:4])
+    cell_ptr = S.make_cells(78, 24)[4]
+    with torch.no_grad():
+        one = hip_model.encode_objects_packed(*args, cell_ptr, streams=1)
+        two = hip_model.encode_objects_packed(*args, cell_ptr, streams=2)
+        aux = hip_model._aux_streams[0]
+        assert ops.streams_overlap(main, aux)
+        with torch.cuda.stream(a):                             # another current stream: the second stream must stand beside THAT one
+            two_a = hip_model.encode_objects_packed(*args, cell_ptr, streams=2)
+            assert hip_model._aux_streams[0].cuda_stream != a.cuda_stream and ops.streams_overlap(a, hip_model._aux_streams[0])
+        torch.cuda.synchronize()
+    assert torch.equal(one, two) and torch.equal(one, two_a)
+
+
 def test_cold_cache_runs_are_bit_identical(hip_model):
     """The SA kernels of the default plan fetch their rows by LDS-DMA behind COUNTED `s_waitcnt vmcnt(n)` waits: a count that
     is one too high only shows when a fetch is slow.  Same cells with L2 / MALL flushed in front of the launch (1 GiB

@@ -32,7 +32,7 @@ class DynamicEdgeConv(nn.Module):
 class CellRetrievalNetwork(PicklableModule):
     # what `torch.save(model, path)` (training/coarse.py:323-324) must not try to pickle: packed-weight descriptors, the guard word,
     # HIP streams, pinned staging, the per-cell means memo (it would drag the dataset's objects into the checkpoint)
-    _TRANSIENT = {"_pack": None, "_overflow": None, "_aux_streams": None, "_copy_stream": None, "_staging": HostStaging,
+    _TRANSIENT = {"_pack": None, "_overflow": None, "_aux_streams": None, "_aux_beside": None, "_copy_stream": None, "_staging": HostStaging,
                   "object_means_cache": ObjectMeansCache}
 
     def __init__(self, known_classes: List[str], known_colors: List[str], known_words: List[str], args,
@@ -225,8 +225,12 @@ class CellRetrievalNetwork(PicklableModule):
         cuts.append(n_cells)
         main = torch.cuda.current_stream(dev)
         aux = getattr(self, "_aux_streams", None) or []
-        while len(aux) < n_streams - 1:
-            aux.append(torch.cuda.Stream(device=dev))
+        if aux and getattr(self, "_aux_beside", None) != main.cuda_stream:
+            aux = []                       # (picked beside another current stream)
+        self._aux_beside = main.cuda_stream
+        if len(aux) < n_streams - 1:
+            # (streams that really run beside the current one: ops.pick_concurrent_streams - a one-time probe of ~1 ms per candidate)
+            aux = aux + ops.pick_concurrent_streams(dev, [main] + aux, n_streams - 1 - len(aux))
         self._aux_streams = aux
         out = torch.empty((n_cells, self.kernel_dim), dtype=torch.float32, device=dev)
         pack = self._cell_pack()
@@ -267,7 +271,7 @@ class CellRetrievalNetwork(PicklableModule):
         bounds = list(range(0, n_cells, int(cells_per_chunk))) + [n_cells]
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream(device=dev)
+            self._copy_stream = ops.concurrent_stream(dev, getattr(self, "_aux_streams", None) or [])
         copy = self._copy_stream
 
         def stage(b):

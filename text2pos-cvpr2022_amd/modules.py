@@ -45,7 +45,7 @@ _LSTM_SIDE = {}
 def _lstm_side_stream(dev):
     key = str(dev)
     if key not in _LSTM_SIDE:
-        _LSTM_SIDE[key] = torch.cuda.Stream(device=dev)
+        _LSTM_SIDE[key] = ops.concurrent_stream(dev)
     return _LSTM_SIDE[key]
 
 

@@ -4,6 +4,7 @@ PyTorch is used for device memory, streams and torch.distributed only; all arith
 Shape / dtype / device / contiguity violations raise RuntimeError before anything is launched.
 """
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -54,6 +55,95 @@ def workspace(device, nbytes: int, tag: str) -> torch.Tensor:
 
 def release_workspaces():
     _workspaces.clear()
+
+
+# ---- streams that really run side by side ----------------------------------------------------------------------
+def _spin_cycles(device) -> int:
+    """Argument of torch.cuda._sleep for a ~0.4 ms single-thread spin on this device (its unit is device dependent)."""
+    key = ("spin", str(device))
+    if key not in _workspaces:
+        st = torch.cuda.current_stream(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)             # (first launch: module load)
+        torch.cuda.synchronize(device)
+        cycles = 20000
+        for _ in range(8):
+            e0.record(st)
+            torch.cuda._sleep(cycles)
+            e1.record(st)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if 0.3 <= ms <= 0.8:
+                break
+            cycles = max(1000, int(cycles * min(8.0, 0.45 / max(ms, 1e-3))))
+        _workspaces[key] = cycles
+    return _workspaces[key]
+
+
+def streams_overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
+    """True when a kernel on stream `b` runs BESIDE a kernel on stream `a`.  HIP maps a process's streams onto a handful of hardware
+    queues (4 by default) in the order of their first use; two streams that share a queue serialise, and nothing in the API says which
+    do.  Measured with a single-thread spin kernel per stream behind a common start event: side by side they take one spin time,
+    in one queue two.  (A 12,000-cell encode in two parts loses its whole two-stream gain, ~3 %, when the second part's stream
+    shares the first's queue - which depends on what the process created before: docs/notebook.md, round 6.)"""
+    dev = a.device
+    cycles = _spin_cycles(dev)
+    torch.cuda.synchronize(dev)
+    start, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    start.record(a)
+    b.wait_event(start)
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(cycles)
+        ea.record(a)
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(cycles)
+        eb.record(b)
+    ea.synchronize()
+    eb.synchronize()
+    solo, both = start.elapsed_time(ea), max(start.elapsed_time(ea), start.elapsed_time(eb))
+    return both < 1.6 * solo
+
+
+def concurrent_stream(device, beside=(), max_candidates: int = 8) -> "torch.cuda.Stream":
+    """A new HIP stream that runs beside the device's current stream, beside every stream in `beside` and - when the hardware queues
+    allow - beside every stream this function handed out before (streams_overlap, ~1 ms per candidate and partner, once).  A
+    candidate that shares a queue with the current stream or with `beside` is dropped; among the others the one with the fewest
+    earlier streams in its queue wins.  Dropped candidates stay alive for the life of the process (torch hands its pooled streams out
+    round-robin; the queue a stream got at first use stays its queue).  Plain `torch.cuda.Stream()` when the spin kernel is
+    unavailable or T2P_NO_STREAM_PROBE is set (the switch exists for A/B measurements of this function)."""
+    device = torch.device(device)
+    if not hasattr(torch.cuda, "_sleep") or os.environ.get("T2P_NO_STREAM_PROBE"):
+        return torch.cuda.Stream(device=device)
+    must = [torch.cuda.current_stream(device)] + [b for b in beside if b is not None]
+    earlier = [e for e in _streams_out if e.device == device and all(e.cuda_stream != m.cuda_stream for m in must)]
+    best, best_shared = None, None
+    for _ in range(max_candidates):
+        c = torch.cuda.Stream(device=device)
+        if any(c.cuda_stream == o.cuda_stream for o in must + earlier + _streams_kept):
+            continue                       # (the pool came round to a stream already in use)
+        _streams_kept.append(c)
+        if not all(streams_overlap(m, c) for m in must):
+            continue
+        shared = sum(0 if streams_overlap(e, c) else 1 for e in earlier)
+        if best is None or shared < best_shared:
+            best, best_shared = c, shared
+        if shared == 0:
+            break
+    if best is None:
+        best = torch.cuda.Stream(device=device)
+    _streams_out.append(best)
+    return best
+
+
+def pick_concurrent_streams(device, beside, n: int):
+    """`n` streams from concurrent_stream, each beside `beside` and beside the ones picked before it."""
+    picked = []
+    for _ in range(n):
+        picked.append(concurrent_stream(device, list(beside) + picked))
+    return picked
+
+
+_streams_out, _streams_kept = [], []
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -190,7 +190,7 @@ class SuperGlueMatch(PicklableModule):
         # underneath the object encoder
         main = torch.cuda.current_stream(dev)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+            self._side = ops.concurrent_stream(dev)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             if encoded:

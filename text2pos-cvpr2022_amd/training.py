@@ -6,6 +6,7 @@ from typing import Iterable, Optional
 import numpy as np
 import torch
 
+from . import ops
 from .losses import HardestRankingLoss, PairwiseRankingLoss
 
 
@@ -23,6 +24,9 @@ def make_criterion(args) -> torch.nn.Module:
     raise NotImplementedError(f"ranking_loss={kind!r}: 'pairwise' and 'hardest' are built")
 
 
+_TEXT_STREAMS = {}    # device -> the text branch's stream (picked once: ops.concurrent_stream probes the hardware queues)
+
+
 def train_epoch(model, dataloader: Iterable[dict], optimizer, criterion, max_batches: Optional[int] = None,
                 overlap_text: bool = True):
     """One pass over `dataloader` (training/coarse.py:31-62).  Returns (mean loss, the batches seen).
@@ -35,7 +39,11 @@ def train_epoch(model, dataloader: Iterable[dict], optimizer, criterion, max_bat
     model.train()
     epoch_losses, batches = [], []
     dev = model.device
-    side = torch.cuda.Stream(device=dev) if (overlap_text and dev.type == "cuda") else None
+    side = None
+    if overlap_text and dev.type == "cuda":
+        if str(dev) not in _TEXT_STREAMS:
+            _TEXT_STREAMS[str(dev)] = ops.concurrent_stream(dev)
+        side = _TEXT_STREAMS[str(dev)]
     for i_batch, batch in enumerate(dataloader):
         if max_batches is not None and i_batch >= max_batches:
             break
