@@ -987,3 +987,49 @@ def test_sa_rows_inline_asm_mfmas_keep_their_distance_from_valu_writes():
             states += 1
     assert n_mfma == 96, n_mfma
     assert not close, close[:3]
+
+
+def test_concurrent_stream_selection_on_a_model_of_the_hardware_queues(monkeypatch):
+    """ops.concurrent_stream's selection logic on a stand-in for the runtime: four hardware queues handed out round-robin by first use
+    (what MI355X / ROCm 7.2 does; the measurement itself runs in the GPU suite).  The stream handed out never shares a queue with the
+    current stream or the ones named, avoids streams handed out before while a free queue exists, and the set stays bounded."""
+    class FakeStream:
+        made = 0
+
+        def __init__(self, device=None):
+            self.device = torch.device("cuda:0")
+            self.cuda_stream = 1000 + FakeStream.made
+            FakeStream.made += 1
+
+    queue = lambda s: 0 if s.cuda_stream == 0 else (s.cuda_stream - 1000 + skew[0]) % 4
+    skew = [1]
+    null = FakeStream()
+    null.cuda_stream = 0
+    FakeStream.made = 0
+    current = [null]
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: current[0])
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch.cuda, "_sleep", lambda cycles: None, raising=False)
+    monkeypatch.setattr(ops, "_measure_overlap", lambda a, b: queue(a) != queue(b))
+    for name in ("_overlap_memo", "_stream_sets", "_handed_out"):
+        monkeypatch.setattr(ops, name, {})
+    monkeypatch.delenv("T2P_NO_STREAM_PROBE", raising=False)
+    for skew[0] in (0, 1, 2, 3):                  # (whatever the process used before: the first candidate's queue varies)
+        for name in ("_overlap_memo", "_stream_sets", "_handed_out"):
+            getattr(ops, name).clear()
+        FakeStream.made = 0
+        text = ops.concurrent_stream("cuda:0")
+        aux = ops.concurrent_stream("cuda:0")
+        copy = ops.concurrent_stream("cuda:0", [aux])
+        assert len({queue(s) for s in (null, text, aux, copy)}) == 4, skew
+        fifth = ops.concurrent_stream("cuda:0", [aux])          # four queues are taken: the named partners still get their own
+        assert queue(fifth) not in (queue(null), queue(aux))
+        current[0] = text                                       # a caller running under the text stream
+        beside_text = ops.concurrent_stream("cuda:0")
+        assert queue(beside_text) != queue(text)
+        current[0] = null
+        for _ in range(40):                                     # a long-lived process: the set of streams stays bounded
+            s = ops.concurrent_stream("cuda:0")
+            assert queue(s) != queue(null)
+        assert FakeStream.made <= ops._MAX_KEPT_STREAMS

@@ -60,8 +60,8 @@ def release_workspaces():
 # ---- streams that really run side by side ----------------------------------------------------------------------
 def _spin_cycles(device) -> int:
     """Argument of torch.cuda._sleep for a ~0.4 ms single-thread spin on this device (its unit is device dependent)."""
-    key = ("spin", str(device))
-    if key not in _workspaces:
+    key = str(device)
+    if key not in _spin_memo:
         st = torch.cuda.current_stream(device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda._sleep(1000)             # (first launch: module load)
@@ -76,16 +76,11 @@ def _spin_cycles(device) -> int:
             if 0.3 <= ms <= 0.8:
                 break
             cycles = max(1000, int(cycles * min(8.0, 0.45 / max(ms, 1e-3))))
-        _workspaces[key] = cycles
-    return _workspaces[key]
+        _spin_memo[key] = cycles
+    return _spin_memo[key]
 
 
-def streams_overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
-    """True when a kernel on stream `b` runs BESIDE a kernel on stream `a`.  HIP maps a process's streams onto a handful of hardware
-    queues (4 by default) in the order of their first use; two streams that share a queue serialise, and nothing in the API says which
-    do.  Measured with a single-thread spin kernel per stream behind a common start event: side by side they take one spin time,
-    in one queue two.  (A 12,000-cell encode in two parts loses its whole two-stream gain, ~3 %, when the second part's stream
-    shares the first's queue - which depends on what the process created before: docs/notebook.md, round 6.)"""
+def _measure_overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
     dev = a.device
     cycles = _spin_cycles(dev)
     torch.cuda.synchronize(dev)
@@ -104,34 +99,52 @@ def streams_overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
     return both < 1.6 * solo
 
 
-def concurrent_stream(device, beside=(), max_candidates: int = 8) -> "torch.cuda.Stream":
-    """A new HIP stream that runs beside the device's current stream, beside every stream in `beside` and - when the hardware queues
-    allow - beside every stream this function handed out before (streams_overlap, ~1 ms per candidate and partner, once).  A
-    candidate that shares a queue with the current stream or with `beside` is dropped; among the others the one with the fewest
-    earlier streams in its queue wins.  Dropped candidates stay alive for the life of the process (torch hands its pooled streams out
-    round-robin; the queue a stream got at first use stays its queue).  Plain `torch.cuda.Stream()` when the spin kernel is
-    unavailable or T2P_NO_STREAM_PROBE is set (the switch exists for A/B measurements of this function)."""
+def streams_overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
+    """True when a kernel on stream `b` runs BESIDE a kernel on stream `a`.  HIP maps a process's streams onto a handful of hardware
+    queues (4 by default) in the order of their first use; two streams that share a queue serialise, and nothing in the API says which
+    do.  Measured with a single-thread spin kernel (~0.45 ms) per stream behind a common start event: side by side the pair takes one
+    spin time, in one queue two.  A stream keeps its queue, so a pair is measured once per process.  (A 12,000-cell encode in two parts
+    loses its whole two-stream gain, ~3 %, when the second part's stream shares the text stream's queue - which depends on what the
+    process did before: docs/notebook.md, round 6.)"""
+    if a.cuda_stream == b.cuda_stream:
+        return False
+    key = (str(a.device),) + tuple(sorted((a.cuda_stream, b.cuda_stream)))
+    if key not in _overlap_memo:
+        _overlap_memo[key] = _measure_overlap(a, b)
+    return _overlap_memo[key]
+
+
+def concurrent_stream(device, beside=()) -> "torch.cuda.Stream":
+    """A HIP stream that runs beside the device's current stream and beside every stream in `beside` (streams_overlap), and - as far as
+    the hardware queues allow - beside the streams this function handed out before.  Streams come from a per-device set of at most
+    eight that lives as long as the process (a stream's queue is fixed at its first use; a destroyed stream's slot would be handed
+    out again), so two callers may get the same stream - which orders their work, never breaks it.  Cost: ~1 ms per pair of streams
+    never measured before.  Plain `torch.cuda.Stream()` when the spin kernel is unavailable, under a graph capture (the probe
+    synchronises the device) or with T2P_NO_STREAM_PROBE set (the switch exists for A/B measurements of this function)."""
     device = torch.device(device)
-    if not hasattr(torch.cuda, "_sleep") or os.environ.get("T2P_NO_STREAM_PROBE"):
+    if not hasattr(torch.cuda, "_sleep") or os.environ.get("T2P_NO_STREAM_PROBE") or torch.cuda.is_current_stream_capturing():
         return torch.cuda.Stream(device=device)
     must = [torch.cuda.current_stream(device)] + [b for b in beside if b is not None]
-    earlier = [e for e in _streams_out if e.device == device and all(e.cuda_stream != m.cuda_stream for m in must)]
-    best, best_shared = None, None
-    for _ in range(max_candidates):
-        c = torch.cuda.Stream(device=device)
-        if any(c.cuda_stream == o.cuda_stream for o in must + earlier + _streams_kept):
-            continue                       # (the pool came round to a stream already in use)
-        _streams_kept.append(c)
-        if not all(streams_overlap(m, c) for m in must):
+    kept = _stream_sets.setdefault(str(device), [])
+    best, best_score, i = None, None, 0
+    while i < _MAX_KEPT_STREAMS:
+        if i == len(kept):
+            c = torch.cuda.Stream(device=device)
+            if any(c.cuda_stream == o.cuda_stream for o in kept):
+                break                      # (torch's stream pool came round)
+            kept.append(c)
+        c, i = kept[i], i + 1
+        if any(c.cuda_stream == m.cuda_stream for m in must) or not all(streams_overlap(m, c) for m in must):
             continue
-        shared = sum(0 if streams_overlap(e, c) else 1 for e in earlier)
-        if best is None or shared < best_shared:
-            best, best_shared = c, shared
-        if shared == 0:
+        out = [o for o in kept if _handed_out.get((str(device), o.cuda_stream), 0) > 0 and all(o.cuda_stream != m.cuda_stream for m in must)]
+        score = sum(_handed_out[(str(device), o.cuda_stream)] for o in out if not streams_overlap(o, c))   # (c itself included)
+        if best is None or score < best_score:
+            best, best_score = c, score
+        if score == 0:
             break
     if best is None:
-        best = torch.cuda.Stream(device=device)
-    _streams_out.append(best)
+        return torch.cuda.Stream(device=device)
+    _handed_out[(str(device), best.cuda_stream)] = _handed_out.get((str(device), best.cuda_stream), 0) + 1
     return best
 
 
@@ -143,7 +156,8 @@ def pick_concurrent_streams(device, beside, n: int):
     return picked
 
 
-_streams_out, _streams_kept = [], []
+_MAX_KEPT_STREAMS = 8
+_overlap_memo, _stream_sets, _handed_out, _spin_memo = {}, {}, {}, {}
 
 
 # ---------------------------------------------------------------------------------------------------------------
