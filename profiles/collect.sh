@@ -25,8 +25,10 @@ cp gpurun_out/$tag/pmc_traffic.json profiles/${tag}_pmc_traffic.json
 python profiles/evidence.py gpurun_out/$tag/pmc_traffic.json gpurun_out/$tag/sq gpurun_out/$tag/grbm gpurun_out/$tag/evidence.json $tag > gpurun_out/$tag/evidence.txt 2>&1
 cp gpurun_out/$tag/evidence.json profiles/${tag}_evidence.json
 timeout 900 python bench.py --steps 20 --warmup 5 2> gpurun_out/$tag/bench.err | tail -1 > gpurun_out/$tag/bench.json
+# the driver's own form (no flags): how long the whole default run takes, wall clock
+t0=$SECONDS; timeout 900 python bench.py 2> gpurun_out/$tag/bench_default.err | tail -1 > gpurun_out/$tag/bench_default.json; echo "python bench.py (no flags): $((SECONDS - t0)) s wall" > gpurun_out/$tag/bench_default_wall.txt
 timeout 600 python bench_fine.py 2> gpurun_out/$tag/bench_fine.err | tail -1 > gpurun_out/$tag/bench_fine.json
 # keep the merge small: drop the raw traces
 cp $trace gpurun_out/$tag/kernel_trace.csv 2>/dev/null   # (kept for re-summarising; not committed)
 find gpurun_out/$tag -name "*.db" -delete; find gpurun_out/$tag -mindepth 2 -name "*.csv" -delete
-cat gpurun_out/$tag/pytest.txt 2>/dev/null; cut -c1-400 gpurun_out/$tag/bench.json; head -12 gpurun_out/$tag/kernel_stats.md
+cat gpurun_out/$tag/pytest.txt gpurun_out/$tag/bench_default_wall.txt 2>/dev/null; cut -c1-400 gpurun_out/$tag/bench.json; head -12 gpurun_out/$tag/kernel_stats.md
