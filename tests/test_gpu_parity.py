@@ -651,6 +651,28 @@ def test_encode_cells_chunking_is_invisible(hip_model):
         hip_model.encode_objects_packed(*args, cell_ptr, chunk_objects=70000)
 
 
+@pytest.mark.parametrize("variation", [0, 1])
+def test_small_calls_take_the_same_bits_as_large_ones(vocab, variation):
+    """Calls too small to occupy the chip (the reference's 64-cell batches: ~1,000 objects) run the DynamicEdgeConv kernel on groups
+    of 8 destinations instead of 32 (t2p::WsParams::knn_group).  A row's sums do not depend on the group it travels in: the first 64
+    cells of a 640-cell call (large mode: 320 groups of 32 >= the CU count) and the same 64 cells alone (small mode) agree bit for
+    bit, for max and for mean aggregation (models/cell_retrieval.py:46-54)."""
+    import weights as W
+    import text2pos_amd as t2p
+    from text2pos_amd import synthetic as S
+    hm = t2p.CellRetrievalNetwork(vocab["classes"], vocab["colors"], vocab["words"], S.default_args(variation=variation))
+    W.fill_state_dict(hm, 5 + variation)
+    hm = hm.to(_dev()).eval()
+    xyz, rgb, center, mean_rgb, cell_ptr = S.make_cells(52, 640)
+    assert (len(xyz) + 31) // 32 >= torch.cuda.get_device_properties(0).multi_processor_count > (int(cell_ptr[64]) + 31) // 32
+    args = _to_dev(xyz, rgb, center, mean_rgb)
+    n64 = int(cell_ptr[64])
+    with torch.no_grad():
+        large = hm.encode_objects_packed(*args, cell_ptr, streams=1)
+        small = hm.encode_objects_packed(*(a[:n64] for a in args), cell_ptr[:65], streams=1)
+    assert torch.equal(large[:64], small)
+
+
 def test_encode_cells_ragged_extremes_vs_oracle(hip_model, oracle_model):
     """Cell sizes the synthetic benchmark never draws: single-object cells (kNN k = min(8, n) = 1, the self loop is the
     only graph edge), a cell of 90 objects (more than one 64-row tile of the kNN / cell-graph kernels) between them, and

@@ -479,7 +479,9 @@ int encode_chunk(const float* xyz, const float* rgb, const float* center, const 
         p.out = ws.x1;
         p.ldo = D;
         p.relu = 1;
-        p.n_groups = (n + 31) / 32;
+        // small calls (the reference's 64-cell batches: ~1,000 objects = 31 groups of 32 on 256 CUs): groups of 8 destinations
+        p.knn_group = (n + 31) / 32 < num_cus() ? 8 : 32;
+        p.n_groups = (n + p.knn_group - 1) / p.knn_group;
         p.knn_idx = ws.knn;
         p.knn_k = cfg.knn_k;
         p.n_dst = n;

@@ -299,6 +299,7 @@ struct WsParams {
     int knn_k;
     int64_t n_dst;
     int mean;               // 0 = max aggregation, 1 = mean (needs knn_k == 8)
+    int knn_group;          // destinations per group: 32 (0 = 32), or 8 for calls too small to fill the CUs with 32-destination groups
 };
 int launch_ws(int mode, int K, int N, const WsParams& p, hipStream_t st);
 

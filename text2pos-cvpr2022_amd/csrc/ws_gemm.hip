@@ -132,6 +132,9 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
     f32x4 sa[C::ITERS];                  // staged source rows (in flight behind the MFMA block)
     f32x4 sb[C::EDGE ? C::ITERS : 1];    // staged destination terms (kNN edge mode)
 
+    // kNN edge mode: destinations per group (32; 8 when the call is too small to occupy the CUs with 32-destination groups - a
+    // row's MFMA sums do not depend on its tile or slot, so the results are the same bits either way)
+    const int knn_group = (C::EDGE && p.knn_group > 0) ? p.knn_group : 32;
     // Issue the global loads of one batch: rows [r0, r0+TR) of group g (n_rows valid rows in the group).
     auto stage_load = [&](int64_t g, int r0, int n_rows) {
 #pragma unroll
@@ -147,7 +150,7 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                     const int dl = rows_dst[r];
                     if (dl != 0xFF) {  // 0xFF = empty neighbour slot (mean aggregation keeps k slots per destination)
                         sa[it] = *(const f32x4*)(p.A + (int64_t)src * p.lda + c4 * 4);
-                        sb[it] = *(const f32x4*)(p.Bc + (g * 32 + dl) * K + c4 * 4);
+                        sb[it] = *(const f32x4*)(p.Bc + (g * knn_group + dl) * K + c4 * 4);
                     }
                 } else if constexpr (SPLIT_IO == 1) {
                     // A arrives as fp16 hi / lo planes: thread chunk q = 16 bytes = 8 halves of one plane row
@@ -366,8 +369,8 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
     } else {
         // ---- kNN edge stream: a group = 32 destination objects, rows = their valid neighbours ----------------------
         for (int64_t g = stream; g < p.n_groups; g += n_streams) {
-            const int64_t d0 = g * 32;
-            const int nd = (int)((p.n_dst - d0) < 32 ? (p.n_dst - d0) : 32);
+            const int64_t d0 = g * knn_group;
+            const int nd = (int)((p.n_dst - d0) < knn_group ? (p.n_dst - d0) : knn_group);
             int my = 0;
             if (tid < nd)
                 for (int e = 0; e < p.knn_k; e++) my += p.knn_idx[(d0 + tid) * p.knn_k + e] >= 0 ? 1 : 0;
@@ -391,7 +394,7 @@ __global__ __launch_bounds__((WN > 4 || W8) ? 512 : 256, (WN > 4 || W8) ? 2 : 1)
                     else if (p.mean) { rows_src[off] = 0; rows_dst[off] = 0xFF; off++; }
                 }
             }
-            for (int i = tid; i < kAccFloats; i += C::NTH) acc_lds[i] = 0;
+            for (int i = tid; i < nd * NW; i += C::NTH) acc_lds[i] = 0;
             __syncthreads();
 
             const int n_batches = (n_rows + C::TR - 1) / C::TR;
