@@ -102,9 +102,14 @@ __device__ unsigned long long t2p_pprof_sums[16];
 #define PPROF_COUNT(i)
 #endif
 
-template <int NW>
+// PARTS = 1: a wave owns whole objects.  PARTS = 4 (calls of a few hundred objects - the reference's 64-cell batches -, where a
+// wave per object leaves most of the chip idle and the call waits for one object's ~130 tiles): a wave owns a QUARTER of an
+// object's centroids = four halves of the window below; it finds its stretch of the (centroid-sorted) row list by a wave-wide
+// search.  Every row goes through the same arithmetic either way and the maximum does not care who owns it: same bits.
+template <int NW, int PARTS>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p) {
     using C = PtsCfg<NW>;
+    static_assert(PARTS == 1 || (C::NH % PARTS == 0 && C::NH / PARTS >= 3), "a part is a whole number (>= 3: two open + one fetched ahead) of halves");
     constexpr int K = C::K, N = C::N, NC = C::NC;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -184,12 +189,43 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
     for (;;) {
         int gi = 0;
         if (lane == 0) gi = atomicAdd(ctr, 1);
-        const int g = g_begin + __builtin_amdgcn_readfirstlane(gi);
+        gi = __builtin_amdgcn_readfirstlane(gi);
+        const int g = g_begin + (PARTS > 1 ? gi / PARTS : gi);
         if (g >= g_end) break;
+        constexpr int HP = C::NH / PARTS;                        // halves per part
+        const int hs = PARTS > 1 ? (gi % PARTS) * HP : 0;        // this wave's halves: [hs, hend)
+        const int hend = hs + HP;
         PPROF_MARK(0);      // drawing an object
         PPROF_COUNT(9);
-        const int n = __builtin_amdgcn_readfirstlane((int)p.n_rows[g]);
+        int n = __builtin_amdgcn_readfirstlane((int)p.n_rows[g]);
         const uint16_t* list = p.rows + (int64_t)g * C::MAXR;
+        if constexpr (PARTS > 1) {
+            // first list index whose centroid is >= target (n if none): 64 probes `step` apart, then the stretch between two probes
+            auto lower = [&](int target) -> int {
+                if (target <= 0 || n <= 0) return 0;
+                if (target >= NC) return n;
+                const int step = (n + 63) >> 6;
+                const int i0 = lane * step;
+                const uint32_t c0 = i0 < n ? (((uint32_t)list[i0] >> 8) & 127u) : 255u;
+                const unsigned long long ge = __ballot(c0 >= (uint32_t)target);
+                const int fl = ge ? (int)__builtin_ctzll(ge) : 64;      // first probe at or past the target
+                if (fl == 0) return 0;
+                int hi = fl * step;
+                hi = hi < n ? hi : n;                                    // list[hi] >= target (or hi == n); list[(fl - 1) step] < target
+                const int base = (fl - 1) * step + 1;
+                for (int b = base; b < hi; b += 64) {
+                    const int i = b + lane;
+                    const uint32_t c = i < hi ? (((uint32_t)list[i] >> 8) & 127u) : 255u;
+                    const unsigned long long m = __ballot(c >= (uint32_t)target);
+                    if (m) return b + (int)__builtin_ctzll(m);
+                }
+                return hi;
+            };
+            const int r_lo = __builtin_amdgcn_readfirstlane(lower(hs * C::HS));
+            const int r_hi = __builtin_amdgcn_readfirstlane(lower(hend * C::HS));
+            list += r_lo;
+            n = r_hi - r_lo;
+        }
         const int first = __builtin_amdgcn_readfirstlane(p.first[g]);
         const uint32_t sb0 = (uint32_t)(first * C::ND + (g - first) * NC);
 
@@ -221,7 +257,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
             const int64_t ai = (int64_t)sb0 + c;
             return Side{*(const f32x3*)pc, *(const f32x3*)(p.pos_src + ai * 3), *(const f32x3*)(p.feat_src + ai * 3)};
         };
-        const Side side0 = fetch_side(0), side1 = fetch_side(1);     // the first two halves are opened before the first tile
+        const Side side0 = fetch_side(hs), side1 = fetch_side(hs + 1);     // the first two halves are opened before the first tile
 
         // ---- the object's points -> LDS records [r g b x y z] (lane l: points 4 l .. 4 l + 3 = 96 contiguous bytes) --------------
         {
@@ -295,11 +331,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
                 *(i32x4*)(lds + a0 + q4 * 16) = i32x4{(int)0xFF800000, (int)0xFF800000, (int)0xFF800000, (int)0xFF800000};
         };
 
-        open_half(0, side0);
-        open_half(1, side1);
-        Side side_n = fetch_side(2);     // runs one half ahead of the window
-        int hf = 2;                      // the half `side_n` belongs to
-        int hd = 0, ho = 2;              // halves drained / opened (hd <= ho <= hd + 2)
+        open_half(hs, side0);
+        open_half(hs + 1, side1);
+        Side side_n = fetch_side(hs + 2);     // runs one half ahead of the window
+        int hf = hs + 2;                      // the half `side_n` belongs to
+        int hd = hs, ho = hs + 2;             // halves drained / opened (hd <= ho <= hd + 2)
         int r0 = 0;
         uint32_t e_cur = n > 0 ? ring_read(0) : 0u;
         while (r0 < n) {
@@ -318,12 +354,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
                     hd++;
                 }
                 if (ho < hd) ho = hd;        // (halves skipped without a row were never opened)
-                const int want = h0 + 2 < C::NH ? h0 + 2 : C::NH;
+                const int want = h0 + 2 < hend ? h0 + 2 : hend;
                 while (ho < want) {
                     if (hf != ho) side_n = fetch_side(ho);
                     open_half(ho, side_n);
                     ho++;
-                    if (ho < C::NH) {
+                    if (ho < hend) {
                         side_n = fetch_side(ho);
                         hf = ho;
                     }
@@ -430,7 +466,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
         }
         // ---- close what is open, write the halves behind the list's end -------------------------------------------------------
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (; hd < C::NH; hd++) drain(hd, hd < ho);
+        for (; hd < hend; hd++) drain(hd, hd < ho);
         flush_out();
         PPROF_MARK(7);      // last drains
     }
@@ -450,6 +486,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sa_points(SaParams p)
 #define T2P_PTS_WAVES 12
 #endif
 constexpr int kPtsWaves = T2P_PTS_WAVES;
+constexpr int kPtsParts = 4;
 
 }  // namespace
 
@@ -474,8 +511,9 @@ int launch_sa_points(int H, int Cout, const SaParams& p, hipStream_t st) {
         return T2P_E_UNSUPPORTED;
     }
     using C = PtsCfg<kPtsWaves>;
-    auto kern = k_sa_points<kPtsWaves>;
+    auto kern = k_sa_points<kPtsWaves, 1>, kern_parts = k_sa_points<kPtsWaves, kPtsParts>;
     T2P_TRY(reserve_lds((const void*)kern, C::lds_bytes(), "sa_points"));
+    T2P_TRY(reserve_lds((const void*)kern_parts, C::lds_bytes(), "sa_points"));
     if (p.n_obj <= 0) return 0;
     T2P_CHECK_ARG(p.n_obj < (1 << 22), "sa_points: chunk too large");
     T2P_CHECK_ARG((((uintptr_t)p.pos_src | (uintptr_t)p.feat_src | (uintptr_t)p.out | (uintptr_t)p.W_x3) & 15) == 0 && p.ldo % 4 == 0,
@@ -484,7 +522,9 @@ int launch_sa_points(int H, int Cout, const SaParams& p, hipStream_t st) {
     sa_points_launch_shape(p.n_obj, &tr, &n_wg);
     if (!p.balanced) T2P_TRY(launch_sa_balance(p, tr, n_wg, st));
     ProfScope ps_("ws_edge_sa_k32_n64", st);
-    T2P_REPEAT(ps_) hipLaunchKernelGGL(kern, dim3(n_wg), dim3(C::NT), C::lds_bytes(), st, p);
+    // fewer objects than half the chip's wave slots: a wave per QUARTER object (same bits; see the kernel)
+    const bool parts = p.n_obj * 2 <= (int64_t)n_wg * kPtsWaves;
+    T2P_REPEAT(ps_) hipLaunchKernelGGL(parts ? kern_parts : kern, dim3(n_wg), dim3(C::NT), C::lds_bytes(), st, p);
     T2P_CHECK_LAUNCH("sa_points");
     return 0;
 }
