@@ -1227,20 +1227,20 @@ def main():
                     "timed region) against both arithmetic paths of the HIP library: cells further than north_star's 1e-4 from the "
                     "oracle (each one a DynamicEdgeConv near-tie that fell the other way; tests/test_gpu_headline.py proves the ties) "
                     "and the largest difference over all other cells"))
-            if args.oracle_cells and fp32_info and args.cell_variant == "ragged":
-                n_or = min(args.oracle_cells, c_hi - c_lo)
-                log(f"oracle_full: {n_or} cells through the CPU oracle in parallel worker processes")
-                of = oracle_full_check(SEED, n_cells_total, n_or, {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                                       oracle_paths, cell_ptr)
-                of["weights"] = out["config"]["weights"] if isinstance(out["config"]["weights"], str) else out["config"]["weights"]["kind"]
-                of["note"] = ("every cell of the sample against the CPU oracle carrying the benchmarked weights (outside the timed region): a cell "
-                              "beyond 1e-4 is a cell whose DynamicEdgeConv kNN graph took the other side of a near-tie (tests/test_gpu_headline.py "
-                              "proves the ties on its sample); `cells_beyond_1e-4_without_a_graph_difference` must be 0")
-                out["oracle_full"] = of
-                if args.oracle_out:
-                    with open(args.oracle_out, "w") as f:
-                        json.dump(dict(of, bench_ms_per_step=ms_per_step, command=" ".join(sys.argv)), f, indent=1)
-            log("done")
+        if args.oracle_cells and world == 1 and fp32_info and args.cell_variant == "ragged":   # (its own switch: independent of the CPU baseline leg)
+            n_or = min(args.oracle_cells, c_hi - c_lo)
+            log(f"oracle_full: {n_or} cells through the CPU oracle in parallel worker processes")
+            of = oracle_full_check(SEED, n_cells_total, n_or, {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                                   oracle_paths, cell_ptr)
+            of["weights"] = out["config"]["weights"] if isinstance(out["config"]["weights"], str) else out["config"]["weights"]["kind"]
+            of["note"] = ("every cell of the sample against the CPU oracle carrying the benchmarked weights (outside the timed region): a cell "
+                          "beyond 1e-4 is a cell whose DynamicEdgeConv kNN graph took the other side of a near-tie (tests/test_gpu_headline.py "
+                          "proves the ties on its sample); `cells_beyond_1e-4_without_a_graph_difference` must be 0")
+            out["oracle_full"] = of
+            if args.oracle_out:
+                with open(args.oracle_out, "w") as f:
+                    json.dump(dict(of, bench_ms_per_step=ms_per_step, command=" ".join(sys.argv)), f, indent=1)
+        log("done")
     # The JSON line must be the LAST line of stdout.  RCCL writes a version banner to the C-level stdout when the communicator is
     # created; with stdout redirected it sits in libc's buffer until the process exits - i.e. behind anything Python printed.
     # So: tear the group down first, flush libc's buffers on every rank, then rank 0 prints.
